@@ -1,0 +1,203 @@
+"""CPU: the oracle (oracle/*.py) reproduces the golden vectors produced by the reference's own Python
+(tests/golden/make_golden.py) and by PyWavelets (tests/golden/make_cdf97_pywt.py)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import filled, load_golden, maxdiff, weight_checksum
+from oracle import cdf97, entropy, lifting, model, subband_ae, weights
+
+TOL = 2e-6   # fp32 round-off between two CPU evaluations of the same maths
+
+
+@pytest.mark.parametrize("name,lin", [("ref_pblock_k3", 1), ("ref_pblock_k5", 1), ("ref_pblock_linear", 0)])
+def test_pblock(name, lin):
+    g = load_golden(name)
+    k = 3 if "k3" in name or "linear" in name else 5
+    tpl = {}
+    for n, (co, ci) in zip(range(1, 5), [(16, 1), (16, 16), (16, 16), (1, 16)]):
+        tpl["P_blocks.0.conv%d.weight" % n] = torch.zeros(co, ci, k, k)
+        tpl["P_blocks.0.conv%d.bias" % n] = torch.zeros(co)
+    sd = filled(tpl)
+    assert abs(weight_checksum(sd) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    y = lifting.p_block(g["x"], sd, "P_blocks.0.", lin)
+    assert maxdiff(y, g["y"]) < TOL
+
+
+@pytest.mark.parametrize("mt", ["A", "B"])
+@pytest.mark.parametrize("k", [3, 5])
+def test_masked_conv(mt, k):
+    g = load_golden("ref_maskedconv_%s%d" % (mt, k))
+    mask = entropy.conv_mask((6, 1, k, k), mt)
+    assert torch.equal(mask, g["mask"])
+    live = int(mask[0, 0].sum())
+    assert live == {("A", 3): 4, ("B", 3): 5, ("A", 5): 12, ("B", 5): 13}[(mt, k)]
+    sd = filled({"csc_list.0.weight": torch.zeros(6, 1, k, k), "csc_list.0.bias": torch.zeros(6),
+                 "csc_list.0.mask": mask})
+    y = entropy.masked_conv(g["x"], sd, "csc_list.0.", groups=3)
+    assert maxdiff(y, g["y"]) < TOL
+
+
+def test_masked_conv_causality():
+    # output at (i,j) is independent of inputs at/after (i,j) in raster order (A) / after (B)
+    for mt in "AB":
+        mask = entropy.conv_mask((1, 1, 5, 5), mt)
+        sd = filled({"c.weight": torch.zeros(1, 1, 5, 5), "c.bias": torch.zeros(1), "c.mask": mask})
+        x = torch.rand(1, 1, 9, 9)
+        y0 = entropy.masked_conv(x, sd, "c.", 1)
+        x2 = x.clone()
+        i, j = 4, 4
+        x2[0, 0, i, j + (1 if mt == "B" else 0):] += 1.0
+        x2[0, 0, i + 1:] += 1.0
+        y1 = entropy.masked_conv(x2, sd, "c.", 1)
+        assert torch.equal(y0[0, 0, :i], y1[0, 0, :i])
+        assert torch.equal(y0[0, 0, i, :j + 1], y1[0, 0, i, :j + 1])
+
+
+def test_lower_bound_and_parametrizer():
+    g = load_golden("ref_lower_bound")
+    x = g["x"].clone().requires_grad_(True)
+    y = subband_ae.lower_bound(x, 0.11)
+    y.backward(g["gup"])
+    assert torch.equal(y.detach(), g["y"])
+    assert torch.equal(x.grad, g["gx"])
+    assert torch.equal(subband_ae.lower_bound_bwd(g["x"], 0.11, g["gup"]), g["gx"])
+    g = load_golden("ref_nonneg_param")
+    x = g["x"].clone().requires_grad_(True)
+    y = subband_ae.nonneg_param(x, 1e-6)
+    y.backward(torch.ones_like(x))
+    assert torch.equal(y.detach(), g["y"])
+    assert torch.equal(x.grad, g["gx"])
+    assert torch.equal(subband_ae.nonneg_init(torch.tensor([0.0, 0.1, 1.0, 4.0])), g["init"])
+    # SURVEY 4.4 probe
+    out = subband_ae.nonneg_param(torch.tensor([-1.0, 0.0, 0.5, 2.0]), 1e-6)
+    assert torch.allclose(out, torch.tensor([1e-6, 1e-6, 0.25, 4.0]), atol=1e-7)
+
+
+def test_gdn():
+    g = load_golden("ref_gdn")
+    tpl = {"Yl_ae.ae_down.1.beta": subband_ae.nonneg_init(torch.ones(6)),
+           "Yl_ae.ae_down.1.gamma": subband_ae.nonneg_init(0.1 * torch.eye(6))}
+    sd = filled(tpl)
+    x = g["x"].clone().requires_grad_(True)
+    b = sd["Yl_ae.ae_down.1.beta"].clone().requires_grad_(True)
+    gm = sd["Yl_ae.ae_down.1.gamma"].clone().requires_grad_(True)
+    y = subband_ae.gdn(x, b, gm, False)
+    y.sum().backward()
+    assert maxdiff(y, g["y"]) < TOL
+    assert maxdiff(subband_ae.gdn(g["x"], b.detach(), gm.detach(), True), g["y_inv"]) < TOL
+    assert maxdiff(x.grad, g["gx"]) < 1e-5
+    assert maxdiff(b.grad, g["gbeta"]) < 1e-5
+    assert maxdiff(gm.grad, g["ggamma"]) < 1e-5
+
+
+def test_skip_filters_border():
+    g = load_golden("ref_skip_filters")
+    sd = weights.autoencoder_template(dict(model.DEFAULT_CFG, dwtlevels=1))   # un-filled: CDF 9/7 lifting constants
+    for j in range(4):
+        w = sd["preProcessingList.%d.weight" % j]
+        assert torch.equal(w, g["w%d" % j])
+        assert maxdiff(lifting.skip_filter(g["imp"], w), g["imp%d" % j]) < TOL
+        assert maxdiff(lifting.skip_filter(g["ramp"], w), g["ramp%d" % j]) < TOL
+    # zero padding (not symmetric extension): predict tap [0,a,a] -> a*(x[i]+x[i+1]), last row sees a zero
+    w0 = sd["preProcessingList.0.weight"].flatten()
+    r = lifting.skip_filter(g["ramp"], sd["preProcessingList.0.weight"])
+    assert abs(float(r[0, 0, 7, 0]) - float(w0[1]) * 7.0) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["ref_lifting_L2_k5", "ref_lifting_L3_k3_rect", "ref_lifting_L2_scale_berk",
+                                  "ref_lifting_L2_different", "ref_lifting_L2_linear"])
+def test_lifting_encode_decode(name):
+    g = load_golden(name)
+    cfg = g["cfg"]
+    sd = filled(weights.autoencoder_template(cfg))
+    assert abs(weight_checksum(sd) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    x = g["x"]
+    LL, LH, HL, HH = lifting.one_level_forward(x, sd, cfg, 0)
+    for a, n in ((LL, "LL"), (LH, "LH"), (HL, "HL"), (HH, "HH")):
+        assert maxdiff(a, g[n]) < TOL, n
+    off = lifting._inv_off(cfg, 0)
+    rec1 = lifting.one_level_inverse(LL, LH, HL, HH, sd, cfg, off)
+    assert maxdiff(rec1, g["rec1"]) < 5e-6
+    if cfg["block_property"] == "same":          # perfect reconstruction
+        assert maxdiff(rec1, x) < 5e-6
+    out_xe, out_xo = model.encode(x, sd, cfg)
+    assert maxdiff(out_xe, g["out_xe"]) < 1e-5
+    for i, t in enumerate(out_xo):
+        assert maxdiff(t, g["out_xo%d" % i]) < 1e-5
+    xr = model.decode(out_xe, out_xo, sd, cfg)
+    assert maxdiff(xr, g["xr"]) < 5e-5
+
+
+@pytest.mark.parametrize("name", ["ref_wrapper_cond2_L3", "ref_wrapper_ezwt_L3", "ref_wrapper_fact_L2",
+                                  "ref_wrapper_cond2_berk_L2"])
+def test_wrapper_forward(name):
+    g = load_golden(name)
+    cfg = g["cfg"]
+    sd = filled(weights.wrapper_template(cfg))
+    assert abs(weight_checksum(sd) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    nlev = cfg["dwtlevels"]
+    # entropy layers on the REFERENCE's coefficients (no rounding-flip ambiguity)
+    for c in range(3):
+        em = model.sub(sd, "model%d.entropymodel." % c)
+        oxe = g["p%d_out_xe" % c]
+        oxo = [g["p%d_out_xo%d" % (c, i)] for i in range(nlev)]
+        si_xe, si_xo, qxe, qxo = entropy.ENTROPY_LAYERS[cfg["entropy_layer"]](oxe, oxo, em, cfg, False)
+        assert torch.equal(qxe, g["p%d_q_xe" % c])
+        assert maxdiff(si_xe, g["p%d_si_xe" % c]) < 2e-4
+        for i in range(nlev):
+            assert torch.equal(qxo[i], g["p%d_q_xo%d" % (c, i)])
+            assert maxdiff(si_xo[i], g["p%d_si_xo%d" % (c, i)]) < 2e-4
+        assert float(si_xe.min()) >= 0 and all(float(s.min()) >= 0 for s in si_xo)
+        # encode from pixels
+        e_xe, e_xo = model.encode(g["y"][:, c:c + 1], model.sub(sd, "model%d.autoencoder." % c), cfg)
+        assert maxdiff(e_xe, oxe) < 2e-5
+        for i in range(nlev):
+            assert maxdiff(e_xo[i], oxo[i]) < 2e-5
+    out = model.agent_batch(g["x"], sd, cfg)
+    assert maxdiff(out["y"], g["y"]) < 1e-6
+    assert len(out["si_xo"]) == int(g["n_si_xo"]) == 3 * nlev
+    # end to end: rounding flips are possible in principle; the fixtures were chosen where none occurs
+    assert maxdiff(out["xhat"], g["xhat"]) < 1e-4
+    for k in ("mse", "rate1", "rate2"):
+        assert abs(float(out[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), k
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+
+
+def test_cdf97_vs_pywt():
+    z = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "cdf97_pywt.npz"))
+    x = torch.tensor(z["x"])
+    ll, Yh = cdf97.dwt_forward(x, 2)
+    assert maxdiff(ll, torch.tensor(z["ll"])) < 1e-12
+    for i in range(2):
+        for j, n in enumerate(("lh", "hl", "hh")):
+            assert maxdiff(Yh[i][:, :, j], torch.tensor(z["%s%d" % (n, i)])) < 1e-12
+    assert maxdiff(cdf97.dwt_inverse(ll, Yh), x) < 1e-10
+    for a, b in ((cdf97.DEC_LO, "dec_lo"), (cdf97.DEC_HI, "dec_hi"), (cdf97.REC_LO, "rec_lo"), (cdf97.REC_HI, "rec_hi")):
+        assert np.abs(np.array(a) - z[b]).max() < 1e-14
+
+
+def test_leaf_ops_closed_form():
+    """compressai leaf ops are 'parity unpinned': check the restatement against float64 closed forms."""
+    import math
+    v = torch.tensor([0.0, 0.3, -1.2, 4.0, -7.5, 25.0])
+    s = torch.tensor([0.05, 0.5, 1.0, 2.0, 0.2, 3.0])
+    mu = torch.tensor([0.1, -0.2, 0.0, 1.5, 0.3, -2.0])
+    p = entropy.gaussian_likelihood(v, s, mu)
+    for i in range(len(v)):
+        sg = max(float(s[i]), 0.11)
+        a = abs(float(v[i]) - float(mu[i]))
+        ref = 0.5 * math.erfc(-(0.5 - a) / sg / math.sqrt(2)) - 0.5 * math.erfc(-(-0.5 - a) / sg / math.sqrt(2))
+        ref = max(ref, 1e-9)
+        assert abs(float(p[i]) - ref) < 2e-7 + 1e-5 * ref
+    # Gaussian pmf sums to 1 over the integer grid
+    k = torch.arange(-60, 61, dtype=torch.float32)
+    tot = entropy.gaussian_likelihood(k + 0.3, torch.full_like(k, 1.7), torch.full_like(k, 0.3)).sum()
+    assert abs(float(tot) - 1.0) < 1e-4
+    # factorized: pmf sums to ~1 as well, likelihood in (0,1]
+    sd = {k_: v_ for k_, v_ in weights.fill_by_name({"e." + a: b for a, b in entropy.eb_init_state(2).items()}).items()}
+    grid = torch.arange(-1500, 1501, dtype=torch.float32).view(1, 1, -1, 1).repeat(1, 2, 1, 1)
+    med = sd["e.quantiles"][:, 0, 1].view(1, 2, 1, 1)
+    q, lik = entropy.entropy_bottleneck_forward(grid + med, sd, "e.", False)
+    assert torch.allclose(q, grid + med)
+    assert abs(float(lik[0, 0].double().sum()) - 1.0) < 5e-3 and abs(float(lik[0, 1].double().sum()) - 1.0) < 5e-3
