@@ -1,0 +1,92 @@
+"""ctypes binding of the C-ABI library ``liblldwt.so`` (include/lldwt.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails this module raises.
+PyTorch is plumbing only (device memory, streams); signatures carry raw pointers and sizes.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblldwt.so")
+
+
+class LLDWTError(RuntimeError):
+    pass
+
+
+class View(C.Structure):
+    """lldwt_view: strided (Z,h,w) single-channel view (include/lldwt.h)."""
+    _fields_ = [("p", C.c_void_p), ("sz", C.c_int64), ("sy", C.c_int64), ("sx", C.c_int64)]
+
+
+class ConvDesc(C.Structure):
+    """lldwt_conv_desc (include/lldwt.h)."""
+    _fields_ = [("cin", C.c_int), ("cout", C.c_int), ("K", C.c_int), ("groups", C.c_int), ("act", C.c_int),
+                ("upsample2", C.c_int), ("transposed", C.c_int), ("tap_mask", C.c_uint32), ("oc_block", C.c_int),
+                ("oc_stride", C.c_int), ("oc_off", C.c_int), ("ytot", C.c_int)]
+
+
+ACT_NONE, ACT_TANH, ACT_LRELU = 0, 1, 2
+EB_FLOATS = 59
+
+_p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol declared in include/lldwt.h
+SIGNATURES = {
+    "lldwt_last_error": (C.c_char_p, []),
+    "lldwt_version": (_i, []),
+    "lldwt_device_ok": (_i, []),
+    "lldwt_rgb_to_ycc": (_i, [_p, _p, _i64, _i64, _i64, _p]),
+    "lldwt_ycc_to_rgb": (_i, [_p, _p, _i64, _i64, _i64, _i, _p]),
+    "lldwt_pblock_packed_floats": (_i64, [_i, _i]),
+    "lldwt_pack_pblock": (_i, [_p] * 9 + [_i, _i, _i, _p]),
+    "lldwt_lift_step_ws_bytes": (_i64, [_i64, _i64, _i64, _i]),
+    "lldwt_lift_step": (_i, [View, View, View, _i64, _i64, _i64, _i64, _p, _p, _i, _i, _i, _f, _f, _i, _p, _i64, _p]),
+    "lldwt_lifting_ws_bytes": (_i64, [_i64, _i64, _i64, _i]),
+    "lldwt_lifting_forward": (_i, [_p, _p, C.POINTER(_p), _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _f, _i, _p, _p,
+                                   _p, _i64, _p]),
+    "lldwt_lifting_inverse": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _f, _i, _p, _p,
+                                   _p, _i64, _p]),
+    "lldwt_subband_mlp": (_i, [_p, _p, _i64, _i64, _i, _i64, _i] + [_p] * 8 + [_i, _p]),
+    "lldwt_conv2d": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
+    "lldwt_conv2d_direct": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
+    "lldwt_gdn": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i64, _i, _f, _p]),
+    "lldwt_lower_bound_fwd": (_i, [_p, _p, _i64, _f, _p]),
+    "lldwt_lower_bound_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
+    "lldwt_nonneg_param_fwd": (_i, [_p, _p, _i64, _f, _p]),
+    "lldwt_nonneg_param_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
+    "lldwt_gauss_rate": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i64, _p]),
+    "lldwt_quantize": (_i, [_p, _p, _p, _i64, _p]),
+    "lldwt_factorized_rate": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
+    "lldwt_sq_err_sum": (_i, [_p, _p, _i64, _p, _p]),
+    "lldwt_sum": (_i, [_p, _i64, _p, _p]),
+    "lldwt_cdf97_ws_bytes": (_i64, [_i64, _i64, _i64]),
+    "lldwt_cdf97_forward": (_i, [_p, _p, C.POINTER(_p), _i64, _i64, _i64, _i, _p, _i64, _p]),
+    "lldwt_cdf97_inverse": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i, _p, _i64, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liblldwt.so (built by csrc/build.sh / __graft_entry__.build()); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LLDWTError(
+            "HIP library %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().lldwt_last_error()
+        raise LLDWTError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

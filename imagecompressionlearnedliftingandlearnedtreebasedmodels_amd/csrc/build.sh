@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds liblldwt.so (gfx950 only) in-tree, next to the Python package.  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../liblldwt.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable"
+mkdir -p "$HERE/obj"
+pids=()
+for f in ops lifting cdf97 conv_mfma; do
+  [ -f "$HERE/$f.hip" ] || continue
+  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/lldwt.h" -nt "$HERE/obj/$f.o" ]; then
+    ( $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj/*.o
+echo "built $OUT"

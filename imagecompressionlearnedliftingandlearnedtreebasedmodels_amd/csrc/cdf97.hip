@@ -1,0 +1,146 @@
+// cdf97.hip -- fixed CDF 9/7 (bior4.4) 2-D DWT, periodization, for gfx950.  HBM-bound (~55 MAC/px).
+// Replaces pytorch_wavelets.DWTForward/DWTInverse(mode='periodization', wave='bior4.4') as used by
+// DWTPytorchWaveletsLayer (graphs/layers/lifting_dwt_nets.py:228-231,250,274); filter taps are the reference's own
+// table get_cdf97_filters (lifting_dwt_nets.py:415-418).
+//   analysis : lo[k] = sum_m dec_lo[m] * x[(2k + 5 - m) mod N]      (same for hi)
+//   synthesis: x[n]  = sum_t [ (n+4-t) mod N even ] ( lo[((n+4-t) mod N)/2] * rec_lo[t] + hi[..] * rec_hi[t] )
+#include "common.h"
+
+namespace lldwt {
+
+__constant__ float c_dec_lo[10] = {0.0f, 0.037828455507264f, -0.023849465019557f, -0.110624404418437f, 0.377402855612831f,
+                                   0.852698679008894f, 0.377402855612831f, -0.110624404418437f, -0.023849465019557f,
+                                   0.037828455507264f};
+__constant__ float c_dec_hi[10] = {0.0f, -0.064538882628697f, 0.040689417609164f, 0.418092273221617f, -0.788485616405583f,
+                                   0.418092273221617f, 0.040689417609164f, -0.064538882628697f, 0.0f, 0.0f};
+__constant__ float c_rec_lo[10] = {0.0f, -0.064538882628697f, -0.040689417609164f, 0.418092273221617f, 0.788485616405583f,
+                                   0.418092273221617f, -0.040689417609164f, -0.064538882628697f, 0.0f, 0.0f};
+__constant__ float c_rec_hi[10] = {0.0f, -0.037828455507264f, -0.023849465019557f, 0.110624404418437f, 0.377402855612831f,
+                                   -0.852698679008894f, 0.377402855612831f, 0.110624404418437f, -0.023849465019557f,
+                                   -0.037828455507264f};
+
+struct V3 {   // (Z, rows, cols) strided view
+    float* p;
+    int64_t sz, sy, sx;
+};
+
+// analysis along `axis` (0 = rows/height, 1 = cols/width).  in: (Z,h,w); lo,hi: half size along axis.
+__global__ __launch_bounds__(256) void k_afb(V3 in, V3 lo, V3 hi, int h, int w, int axis) {
+    const int64_t z = blockIdx.z;
+    const int oh = axis == 0 ? h / 2 : h, ow = axis == 1 ? w / 2 : w;
+    const int N = axis == 0 ? h : w;
+    for (int y = blockIdx.y; y < oh; y += gridDim.y)
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < ow; x += gridDim.x * blockDim.x) {
+            const int k = axis == 0 ? y : x;
+            float a = 0.f, d = 0.f;
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {
+                int n = (2 * k + 5 - m) % N;
+                if (n < 0) n += N;
+                const int yy = axis == 0 ? n : y, xx = axis == 1 ? n : x;
+                const float v = in.p[z * in.sz + (int64_t)yy * in.sy + (int64_t)xx * in.sx];
+                a = fmaf(c_dec_lo[m], v, a);
+                d = fmaf(c_dec_hi[m], v, d);
+            }
+            lo.p[z * lo.sz + (int64_t)y * lo.sy + (int64_t)x * lo.sx] = a;
+            hi.p[z * hi.sz + (int64_t)y * hi.sy + (int64_t)x * hi.sx] = d;
+        }
+}
+
+// synthesis along `axis`.  lo,hi: half size along axis; out: (Z,h,w).
+__global__ __launch_bounds__(256) void k_sfb(V3 lo, V3 hi, V3 out, int h, int w, int axis) {
+    const int64_t z = blockIdx.z;
+    const int N = axis == 0 ? h : w;
+    for (int y = blockIdx.y; y < h; y += gridDim.y)
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+            const int n = axis == 0 ? y : x;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                int q = (n + 4 - t) % N;
+                if (q < 0) q += N;
+                if ((q & 1) == 0) {
+                    const int k = q >> 1;
+                    const int yy = axis == 0 ? k : y, xx = axis == 1 ? k : x;
+                    acc = fmaf(lo.p[z * lo.sz + (int64_t)yy * lo.sy + (int64_t)xx * lo.sx], c_rec_lo[t], acc);
+                    acc = fmaf(hi.p[z * hi.sz + (int64_t)yy * hi.sy + (int64_t)xx * hi.sx], c_rec_hi[t], acc);
+                }
+            }
+            out.p[z * out.sz + (int64_t)y * out.sy + (int64_t)x * out.sx] = acc;
+        }
+}
+
+static inline dim3 grid2d(int64_t h, int64_t w, int64_t Z) {
+    return dim3((unsigned)cdiv(w, 256), (unsigned)(h < 2048 ? h : 2048), (unsigned)Z);
+}
+
+}  // namespace lldwt
+using namespace lldwt;
+
+// workspace: lo_w, hi_w (Z*H*W/2 each) + two LL ping-pong buffers (Z*H*W/4 each)
+extern "C" int64_t lldwt_cdf97_ws_bytes(int64_t Z, int64_t H, int64_t W) {
+    return (int64_t)sizeof(float) * (Z * H * (W / 2) * 2 + Z * (H / 2) * (W / 2) * 2);
+}
+
+static int cdf_args(const char* who, int64_t Z, int64_t H, int64_t W, int levels, void* ws, int64_t ws_bytes) {
+    LLDWT_REQUIRE(Z > 0 && Z <= 65535 && levels > 0 && levels < 16, "%s: bad Z/levels", who);
+    LLDWT_REQUIRE(H > 0 && W > 0 && H % (1 << levels) == 0 && W % (1 << levels) == 0,
+                  "%s: H=%ld W=%ld must be divisible by 2^levels", who, (long)H, (long)W);
+    LLDWT_REQUIRE(ws, "%s: null workspace", who);
+    if (ws_bytes < lldwt_cdf97_ws_bytes(Z, H, W)) {
+        set_error("%s: workspace %ld < %ld bytes", who, (long)ws_bytes, (long)lldwt_cdf97_ws_bytes(Z, H, W));
+        return LLDWT_EWS;
+    }
+    return 0;
+}
+
+extern "C" int lldwt_cdf97_forward(const float* x, float* ll, float* const* yh, int64_t Z, int64_t H, int64_t W,
+                                   int levels, void* ws, int64_t ws_bytes, void* stream) {
+    int r = cdf_args("cdf97_forward", Z, H, W, levels, ws, ws_bytes);
+    if (r) return r;
+    LLDWT_REQUIRE(x && ll && yh, "cdf97_forward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    float* low = (float*)ws;
+    float* hiw = low + Z * H * (W / 2);
+    float* llb[2] = {hiw + Z * H * (W / 2), hiw + Z * H * (W / 2) + Z * (H / 2) * (W / 2)};
+    const float* cur = x;
+    for (int lev = 0; lev < levels; ++lev) {
+        const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2, sub = hh * wh;
+        V3 in{const_cast<float*>(cur), h * w, w, 1};
+        V3 lw{low, h * wh, wh, 1}, hw_{hiw, h * wh, wh, 1};
+        hipLaunchKernelGGL(k_afb, grid2d(h, wh, Z), dim3(256), 0, st, in, lw, hw_, (int)h, (int)w, 1);
+        float* llout = lev == levels - 1 ? ll : llb[lev & 1];
+        float* y = yh[lev];
+        V3 vLL{llout, sub, wh, 1}, vLH{y, 3 * sub, wh, 1}, vHL{y + sub, 3 * sub, wh, 1}, vHH{y + 2 * sub, 3 * sub, wh, 1};
+        hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, lw, vLL, vLH, (int)h, (int)wh, 0);
+        hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, hw_, vHL, vHH, (int)h, (int)wh, 0);
+        cur = llout;
+    }
+    return check_launch("cdf97_forward");
+}
+
+extern "C" int lldwt_cdf97_inverse(const float* ll, const float* const* yh, float* x, int64_t Z, int64_t H, int64_t W,
+                                   int levels, void* ws, int64_t ws_bytes, void* stream) {
+    int r = cdf_args("cdf97_inverse", Z, H, W, levels, ws, ws_bytes);
+    if (r) return r;
+    LLDWT_REQUIRE(x && ll && yh, "cdf97_inverse: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    float* low = (float*)ws;
+    float* hiw = low + Z * H * (W / 2);
+    float* llb[2] = {hiw + Z * H * (W / 2), hiw + Z * H * (W / 2) + Z * (H / 2) * (W / 2)};
+    const float* cur = ll;
+    for (int lev = levels - 1; lev >= 0; --lev) {
+        const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2, sub = hh * wh;
+        float* y = const_cast<float*>(yh[lev]);
+        V3 vLL{const_cast<float*>(cur), sub, wh, 1}, vLH{y, 3 * sub, wh, 1}, vHL{y + sub, 3 * sub, wh, 1},
+            vHH{y + 2 * sub, 3 * sub, wh, 1};
+        V3 lw{low, h * wh, wh, 1}, hw_{hiw, h * wh, wh, 1};
+        hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vLL, vLH, lw, (int)h, (int)wh, 0);
+        hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vHL, vHH, hw_, (int)h, (int)wh, 0);
+        float* out = lev == 0 ? x : llb[lev & 1];
+        V3 vo{out, h * w, w, 1};
+        hipLaunchKernelGGL(k_sfb, grid2d(h, w, Z), dim3(256), 0, st, lw, hw_, vo, (int)h, (int)w, 1);
+        cur = out;
+    }
+    return check_launch("cdf97_inverse");
+}

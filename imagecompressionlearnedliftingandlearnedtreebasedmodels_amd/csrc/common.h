@@ -1,0 +1,46 @@
+// common.h -- shared helpers for the lldwt HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/lldwt.h"
+
+namespace lldwt {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return LLDWT_EHIP;
+    }
+    return LLDWT_OK;
+}
+
+#define LLDWT_REQUIRE(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            lldwt::set_error(__VA_ARGS__); \
+            return LLDWT_EINVAL;          \
+        }                                 \
+    } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == LLDWT_ACT_TANH) return tanhf(v);
+    if (act == LLDWT_ACT_LRELU) return v >= 0.f ? v : 0.01f * v;
+    return v;
+}
+
+// 64-lane wavefront sum via DPP-free shuffles (wave = 64 on CDNA4)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+}  // namespace lldwt

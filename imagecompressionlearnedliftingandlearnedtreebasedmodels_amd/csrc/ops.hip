@@ -1,0 +1,516 @@
+// ops.hip -- elementwise / small kernels of the hot path for gfx950: colour transforms, subband MLP,
+// reference-order direct conv (fallback + cross-check of the MFMA conv engine), GDN, bound ops, rate estimation,
+// reductions.  Every kernel cites the reference code it replaces.
+#include "common.h"
+#include <string.h>
+#include <math.h>
+
+namespace lldwt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------ colour
+// compressai.transforms.functional rgb2ycbcr / ycbcr2rgb (BT.709), agents/liftingDWT_agent.py:86-87,90-94
+constexpr float KR = 0.2126f, KG = 0.7152f, KB = 0.0722f;
+
+__global__ void k_rgb_to_ycc(const float* __restrict__ rgb, float* __restrict__ ycc, int64_t B, int64_t hw) {
+    const int64_t n = B * hw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / hw, p = i - b * hw;
+        const float r = rgb[(b * 3 + 0) * hw + p], g = rgb[(b * 3 + 1) * hw + p], bl = rgb[(b * 3 + 2) * hw + p];
+        const float y = KR * r + KG * g + KB * bl;
+        const float cb = 0.5f * (bl - y) / (1.f - KB) + 0.5f;
+        const float cr = 0.5f * (r - y) / (1.f - KR) + 0.5f;
+        ycc[(0 * B + b) * hw + p] = y - 0.5f;
+        ycc[(1 * B + b) * hw + p] = cb;
+        ycc[(2 * B + b) * hw + p] = cr;
+    }
+}
+
+__global__ void k_ycc_to_rgb(const float* __restrict__ ycc, float* __restrict__ rgb, int64_t B, int64_t hw, int clamp) {
+    const int64_t n = B * hw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / hw, p = i - b * hw;
+        const float y = ycc[(0 * B + b) * hw + p] + 0.5f, cb = ycc[(1 * B + b) * hw + p], cr = ycc[(2 * B + b) * hw + p];
+        float r = y + (2.f - 2.f * KR) * (cr - 0.5f);
+        float bl = y + (2.f - 2.f * KB) * (cb - 0.5f);
+        float g = (y - KR * r - KB * bl) / KG;
+        r -= 0.5f; g -= 0.5f; bl -= 0.5f;
+        if (clamp) {
+            r = fminf(fmaxf(r, -0.5f), 0.5f);
+            g = fminf(fmaxf(g, -0.5f), 0.5f);
+            bl = fminf(fmaxf(bl, -0.5f), 0.5f);
+        }
+        rgb[(b * 3 + 0) * hw + p] = r;
+        rgb[(b * 3 + 1) * hw + p] = g;
+        rgb[(b * 3 + 2) * hw + p] = bl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ subband MLP
+// SubbandAutoEncoder (lifting_dwt_nets.py:99-110): 1 -> HD -> HD -> HD -> 1 per coefficient, tanh between.
+template <int HD>
+__global__ __launch_bounds__(256) void k_subband_mlp(const float* __restrict__ x, float* __restrict__ y, int batch, int C,
+                                                     int64_t hw, const float* __restrict__ w0, const float* __restrict__ b0,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     const float* __restrict__ w3, const float* __restrict__ b3,
+                                                     int transposed) {
+    __shared__ float sw1[HD * HD], sw2[HD * HD], sw0[HD], sb0[HD], sb1[HD], sb2[HD], sw3[HD];
+    const int c = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int64_t pc = (int64_t)plane * C + c;
+    // stage this (plane, channel)'s weights as [out j][in k]
+    for (int i = threadIdx.x; i < HD * HD; i += blockDim.x) {
+        const int j = i / HD, k = i % HD;
+        const int64_t src = transposed ? (pc * HD + k) * HD + j : (pc * HD + j) * HD + k;
+        sw1[i] = w1[src];
+        sw2[i] = w2[src];
+    }
+    for (int i = threadIdx.x; i < HD; i += blockDim.x) {
+        sw0[i] = w0[pc * HD + i];          // (C*HD,1) or (C,HD): same flat index
+        sb0[i] = b0[pc * HD + i];
+        sb1[i] = b1[pc * HD + i];
+        sb2[i] = b2[pc * HD + i];
+        sw3[i] = w3[pc * HD + i];          // (C,HD) or (C*HD,1): same flat index
+    }
+    __syncthreads();
+    const float bb3 = b3[pc];
+    const float* xp = x + (z * C + c) * hw;
+    float* yp = y + (z * C + c) * hw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = xp[i];
+        float ha[HD], hb[HD];
+#pragma unroll
+        for (int j = 0; j < HD; ++j) ha[j] = tanhf(fmaf(sw0[j], v, sb0[j]));
+#pragma unroll
+        for (int j = 0; j < HD; ++j) {
+            float a = sb1[j];
+#pragma unroll
+            for (int k = 0; k < HD; ++k) a = fmaf(sw1[j * HD + k], ha[k], a);
+            hb[j] = tanhf(a);
+        }
+#pragma unroll
+        for (int j = 0; j < HD; ++j) {
+            float a = sb2[j];
+#pragma unroll
+            for (int k = 0; k < HD; ++k) a = fmaf(sw2[j * HD + k], hb[k], a);
+            ha[j] = tanhf(a);
+        }
+        float o = bb3;
+#pragma unroll
+        for (int k = 0; k < HD; ++k) o = fmaf(sw3[k], ha[k], o);
+        yp[i] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ direct conv (reference order)
+constexpr int OCB = 8;
+__global__ __launch_bounds__(256) void k_conv_direct(const float* __restrict__ x, float* __restrict__ y,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     lldwt_conv_desc d, int batch, int h, int wd) {
+    const int K = d.K, P = K / 2, KK = K * K;
+    const int cin_g = d.cin / d.groups, cout_g = d.cout / d.groups;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int nblk = (cout_g + OCB - 1) / OCB;       // blockIdx.y = group * nblk + block-in-group
+    const int g = blockIdx.y / nblk;
+    const int ocl0 = (blockIdx.y - g * nblk) * OCB;  // first output channel inside the group
+    const int oc0 = g * cout_g + ocl0;
+    const int64_t hw = (int64_t)h * wd;
+    const int hi = d.upsample2 ? h / 2 : h, wi = d.upsample2 ? wd / 2 : wd;
+    const int64_t hwi = (int64_t)hi * wi;
+    const float* wp = w + (int64_t)plane * d.cout * cin_g * KK;
+    const float* xz = x + (z * d.cin + (int64_t)g * cin_g) * hwi;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+        const int py = (int)(p / wd), px = (int)(p - (int64_t)py * wd);
+        float acc[OCB];
+#pragma unroll
+        for (int o = 0; o < OCB; ++o) acc[o] = (bias && ocl0 + o < cout_g) ? bias[plane * d.cout + oc0 + o] : 0.f;
+        for (int ic = 0; ic < cin_g; ++ic) {
+            for (int t = 0; t < KK; ++t) {
+                if (!((d.tap_mask >> t) & 1u)) continue;
+                const int ky = t / K, kx = t - ky * K;
+                const int yy = py + ky - P, xx = px + kx - P;
+                float v = 0.f;
+                if (yy >= 0 && yy < h && xx >= 0 && xx < wd) {
+                    const int sy = d.upsample2 ? (yy >> 1) : yy, sx = d.upsample2 ? (xx >> 1) : xx;
+                    v = xz[ic * hwi + (int64_t)sy * wi + sx];
+                }
+#pragma unroll
+                for (int o = 0; o < OCB; ++o) {
+                    const int oc = oc0 + o;
+                    if (ocl0 + o < cout_g) {
+                        const float wv = d.transposed ? wp[((int64_t)ic * d.cout + oc) * KK + (KK - 1 - t)]
+                                                      : wp[((int64_t)oc * cin_g + ic) * KK + t];
+                        acc[o] = fmaf(wv, v, acc[o]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OCB; ++o) {
+            const int oc = oc0 + o;
+            if (ocl0 + o < cout_g) {
+                const int ocp = (oc / d.oc_block) * d.oc_stride + d.oc_off + oc % d.oc_block;
+                y[(z * d.ytot + ocp) * hw + p] = act_apply(acc[o], d.act);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GDN
+// graphs/layers/gdn.py:77-92 with utils/parametrizers.py:45-48 applied to beta/gamma in-kernel.
+__device__ __forceinline__ float nonneg(float v, float bound, float pedestal) {
+    const float m = fmaxf(v, bound);
+    return m * m - pedestal;
+}
+
+__global__ __launch_bounds__(256) void k_gdn(const float* __restrict__ x, float* __restrict__ y,
+                                             const float* __restrict__ beta, const float* __restrict__ gamma, int batch,
+                                             int C, int64_t hw, int inverse, float beta_bound, float gamma_bound,
+                                             float pedestal) {
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int c = blockIdx.y;
+    const float* gp = gamma + ((int64_t)plane * C + c) * C;
+    const float bt = nonneg(beta[plane * C + c], beta_bound, pedestal);
+    const float* xz = x + z * C * hw;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+        float nrm = bt;
+        for (int j = 0; j < C; ++j) {
+            const float v = xz[j * hw + p];
+            nrm = fmaf(nonneg(gp[j], gamma_bound, pedestal), v * v, nrm);
+        }
+        nrm = inverse ? sqrtf(nrm) : 1.0f / sqrtf(nrm);
+        y[(z * C + c) * hw + p] = xz[c * hw + p] * nrm;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bound ops
+// utils/bound_ops.py:22-28, utils/parametrizers.py:45-48
+__global__ void k_lower_bound_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, float b) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = fmaxf(x[i], b);
+}
+__global__ void k_lower_bound_bwd(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                                  int64_t n, float b) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = gy[i];
+        gx[i] = ((x[i] >= b) || (g < 0.f)) ? g : 0.f;
+    }
+}
+__global__ void k_nonneg_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, float b, float ped) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = nonneg(x[i], b, ped);
+}
+__global__ void k_nonneg_bwd(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                             int64_t n, float b) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // d/dx [lower_bound(x)^2 - ped] = 2*lower_bound(x) * LowerBound'(x)  with the pass-through rule on the inner grad
+        const float xv = x[i];
+        const float g = gy[i] * 2.f * fmaxf(xv, b);
+        gx[i] = ((xv >= b) || (g < 0.f)) ? g : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ block reduce -> double atomic
+__device__ __forceinline__ void block_accumulate(double v, double* out) {
+    __shared__ double part[16];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) part[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += part[i];
+        atomicAdd(out, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ Gaussian rate
+// compressai GaussianConditional.forward/_likelihood as called at LiftingBasedDWT_net.py:334,345,364,832
+__global__ __launch_bounds__(256) void k_gauss_rate(const float* __restrict__ x, const float* __restrict__ params,
+                                                    const float* __restrict__ noise, float* __restrict__ bits,
+                                                    float* __restrict__ qout, double* __restrict__ bit_sum, int C,
+                                                    int64_t hw, int64_t n) {
+    double local = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t zc = i / hw, p = i - zc * hw;
+        const int64_t z = zc / C;
+        const int c = (int)(zc - z * C);
+        const float sg = params[(z * 2 * C + 2 * c) * hw + p];
+        const float mu = params[(z * 2 * C + 2 * c + 1) * hw + p];
+        const float xv = x[i];
+        const float v = noise ? xv + noise[i] : rintf(xv - mu) + mu;
+        const float a = fabsf(v - mu);
+        const float s = fmaxf(sg, 0.11f);
+        const float cst = -0.70710678118654752440f;
+        const float up = 0.5f * erfcf(cst * ((0.5f - a) / s));
+        const float lo = 0.5f * erfcf(cst * ((-0.5f - a) / s));
+        const float lik = fmaxf(up - lo, 1e-9f);
+        const float b = -log2f(lik);
+        if (bits) bits[i] = b;
+        if (qout) qout[i] = v;
+        local += (double)b;
+    }
+    if (bit_sum) block_accumulate(local, bit_sum);
+}
+
+__global__ void k_quantize(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ q, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        q[i] = noise ? x[i] + noise[i] : rintf(x[i]);
+}
+
+// ------------------------------------------------------------------------------------------ factorized rate
+// compressai EntropyBottleneck.forward/_logits_cumulative/_likelihood (call sites LiftingBasedDWT_net.py:225,229,815,818)
+__device__ __forceinline__ float softplusf(float v) { return v > 20.f ? v : log1pf(expf(v)); }   // torch softplus, threshold 20
+
+struct EbParams {   // processed (softplus / tanh applied)
+    float m0[3], b0[3], f0[3], m1[9], b1[3], f1[3], m2[9], b2[3], f2[3], m3[9], b3[3], f3[3], m4[3], b4, median;
+};
+
+__device__ __forceinline__ float eb_logits(const float* __restrict__ e, float v) {
+    // e: processed params in LDS, same order as the packed layout
+    float l[3], t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        l[j] = e[j] * v + e[3 + j];
+        l[j] += e[6 + j] * tanhf(l[j]);
+    }
+    const float* q = e + 9;
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float a = q[j * 3 + 0] * l[0];
+            a += q[j * 3 + 1] * l[1];
+            a += q[j * 3 + 2] * l[2];
+            a += q[9 + j];
+            t[j] = a + q[12 + j] * tanhf(a);
+        }
+        l[0] = t[0]; l[1] = t[1]; l[2] = t[2];
+        q += 15;
+    }
+    float o = q[0] * l[0];
+    o += q[1] * l[1];
+    o += q[2] * l[2];
+    return o + q[3];
+}
+
+__global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict__ x, const float* __restrict__ eb,
+                                                         const float* __restrict__ noise, float* __restrict__ bits,
+                                                         float* __restrict__ qout, double* __restrict__ bit_sum,
+                                                         int batch, int C, int64_t hw) {
+    __shared__ float e[LLDWT_EB_FLOATS + 5];
+    const int c = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const float* src = eb + ((int64_t)plane * C + c) * LLDWT_EB_FLOATS;
+    if (threadIdx.x < LLDWT_EB_FLOATS) {
+        const int i = threadIdx.x;
+        float v = src[i];
+        // layout: m0(3) b0(3) f0(3) | m1(9) b1(3) f1(3) | m2 .. | m3 .. | m4(3) b4(1) median(1)
+        bool is_m, is_f;
+        if (i < 9) { is_m = i < 3; is_f = i >= 6; }
+        else if (i < 54) { const int r = (i - 9) % 15; is_m = r < 9; is_f = r >= 12; }
+        else { is_m = i < 57; is_f = false; }
+        if (is_m) v = softplusf(v);
+        else if (is_f) v = tanhf(v);
+        e[i] = v;
+    }
+    __syncthreads();
+    const float med = e[58];
+    const int64_t base = (z * C + c) * hw;
+    double local = 0;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+        const float xv = x[base + p];
+        const float v = noise ? xv + noise[base + p] : rintf(xv - med) + med;
+        const float lower = eb_logits(e, v - 0.5f);
+        const float upper = eb_logits(e, v + 0.5f);
+        const float sm = lower + upper;
+        const float sign = sm > 0.f ? -1.f : (sm < 0.f ? 1.f : 0.f);
+        const float su = 1.f / (1.f + expf(-sign * upper));
+        const float sl = 1.f / (1.f + expf(-sign * lower));
+        const float lik = fmaxf(fabsf(su - sl), 1e-9f);
+        const float b = -log2f(lik);
+        if (bits) bits[base + p] = b;
+        if (qout) qout[base + p] = v;
+        local += (double)b;
+    }
+    if (bit_sum) block_accumulate(local, bit_sum);
+}
+
+__global__ __launch_bounds__(256) void k_sq_err_sum(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                    double* __restrict__ out) {
+    double local = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        local += (double)d * d;
+    }
+    block_accumulate(local, out);
+}
+__global__ __launch_bounds__(256) void k_sum(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
+    double local = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        local += (double)x[i];
+    block_accumulate(local, out);
+}
+
+static inline unsigned ew_grid(int64_t n) {
+    int64_t g = cdiv(n, 256);
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace lldwt
+
+using namespace lldwt;
+
+extern "C" const char* lldwt_last_error(void) { return g_err; }
+extern "C" int lldwt_version(void) { return 100; }
+extern "C" int lldwt_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+extern "C" int lldwt_rgb_to_ycc(const float* rgb, float* ycc, int64_t B, int64_t H, int64_t W, void* stream) {
+    LLDWT_REQUIRE(rgb && ycc && B > 0 && H > 0 && W > 0, "rgb_to_ycc: bad arguments");
+    hipLaunchKernelGGL(k_rgb_to_ycc, dim3(ew_grid(B * H * W)), dim3(256), 0, (hipStream_t)stream, rgb, ycc, B, H * W);
+    return check_launch("rgb_to_ycc");
+}
+extern "C" int lldwt_ycc_to_rgb(const float* ycc, float* rgb, int64_t B, int64_t H, int64_t W, int clamp, void* stream) {
+    LLDWT_REQUIRE(rgb && ycc && B > 0 && H > 0 && W > 0, "ycc_to_rgb: bad arguments");
+    hipLaunchKernelGGL(k_ycc_to_rgb, dim3(ew_grid(B * H * W)), dim3(256), 0, (hipStream_t)stream, ycc, rgb, B, H * W, clamp);
+    return check_launch("ycc_to_rgb");
+}
+
+extern "C" int lldwt_subband_mlp(const float* x, float* y, int64_t planes, int64_t batch, int C, int64_t hw, int Hd,
+                                 const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                                 const float* b2, const float* w3, const float* b3, int transposed, void* stream) {
+    LLDWT_REQUIRE(x && y && w0 && b0 && w1 && b1 && w2 && b2 && w3 && b3, "subband_mlp: null pointer");
+    LLDWT_REQUIRE(planes > 0 && batch > 0 && C > 0 && hw > 0, "subband_mlp: bad dims");
+    LLDWT_REQUIRE(Hd == 32, "subband_mlp: hidden width %d unsupported (reference uses H=32, lifting_dwt_nets.py:98)", Hd);
+    LLDWT_REQUIRE(planes * batch <= 65535 && C <= 65535, "subband_mlp: grid too large");
+    int64_t gx = cdiv(hw, 256);
+    if (gx > 1024) gx = 1024;
+    dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
+    hipLaunchKernelGGL((k_subband_mlp<32>), grid, dim3(256), 0, (hipStream_t)stream, x, y, (int)batch, C, hw, w0, b0, w1, b1,
+                       w2, b2, w3, b3, transposed);
+    return check_launch("subband_mlp");
+}
+
+extern "C" int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
+                                   int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream) {
+    LLDWT_REQUIRE(x && y && w && d, "conv2d: null pointer");
+    LLDWT_REQUIRE(d->K == 1 || d->K == 3 || d->K == 5, "conv2d: K=%d unsupported", d->K);
+    LLDWT_REQUIRE(d->groups > 0 && d->cin % d->groups == 0 && d->cout % d->groups == 0, "conv2d: bad groups");
+    LLDWT_REQUIRE(!d->transposed || d->groups == 1, "conv2d: transposed needs groups==1");
+    LLDWT_REQUIRE(!d->upsample2 || (h % 2 == 0 && w_ % 2 == 0), "conv2d: upsample2 needs even output dims");
+    LLDWT_REQUIRE(d->oc_block > 0 && d->ytot >= d->cout, "conv2d: bad output placement");
+    LLDWT_REQUIRE(planes * batch <= 65535, "conv2d: planes*batch exceeds grid.z");
+    int64_t gx = cdiv(h * w_, 256);
+    if (gx > 4096) gx = 4096;
+    dim3 grid((unsigned)gx, (unsigned)(d->groups * cdiv(d->cout / d->groups, OCB)), (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_conv_direct, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, bias, *d, (int)batch, (int)h, (int)w_);
+    return check_launch("conv2d_direct");
+}
+
+extern "C" int lldwt_gdn(const float* x, float* y, const float* beta, const float* gamma, int64_t planes, int64_t batch,
+                         int C, int64_t hw, int inverse, float beta_min, void* stream) {
+    LLDWT_REQUIRE(x && y && beta && gamma && planes > 0 && batch > 0 && C > 0 && hw > 0, "gdn: bad arguments");
+    LLDWT_REQUIRE(planes * batch <= 65535 && C <= 65535, "gdn: grid too large");
+    const float ped = (float)(3.814697265625e-06 * 3.814697265625e-06);       // (2^-18)^2, parametrizers.py:31-36
+    const float bb = (float)sqrt((double)beta_min + 3.814697265625e-06 * 3.814697265625e-06);
+    const float gb = (float)sqrt(0.0 + 3.814697265625e-06 * 3.814697265625e-06);
+    int64_t gx = cdiv(hw, 256);
+    if (gx > 1024) gx = 1024;
+    dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_gdn, grid, dim3(256), 0, (hipStream_t)stream, x, y, beta, gamma, (int)batch, C, hw, inverse, bb, gb, ped);
+    return check_launch("gdn");
+}
+
+extern "C" int lldwt_lower_bound_fwd(const float* x, float* y, int64_t n, float bound, void* stream) {
+    LLDWT_REQUIRE(x && y && n >= 0, "lower_bound_fwd: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_lower_bound_fwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, bound);
+    return check_launch("lower_bound_fwd");
+}
+extern "C" int lldwt_lower_bound_bwd(const float* x, const float* gy, float* gx, int64_t n, float bound, void* stream) {
+    LLDWT_REQUIRE(x && gy && gx && n >= 0, "lower_bound_bwd: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_lower_bound_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, n, bound);
+    return check_launch("lower_bound_bwd");
+}
+static inline void nonneg_consts(float minimum, float* b, float* ped) {
+    const double p = 3.814697265625e-06 * 3.814697265625e-06;
+    *ped = (float)p;
+    *b = (float)sqrt((double)minimum + p);
+}
+extern "C" int lldwt_nonneg_param_fwd(const float* x, float* y, int64_t n, float minimum, void* stream) {
+    LLDWT_REQUIRE(x && y && n >= 0, "nonneg_param_fwd: bad arguments");
+    if (n == 0) return 0;
+    float b, ped;
+    nonneg_consts(minimum, &b, &ped);
+    hipLaunchKernelGGL(k_nonneg_fwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, b, ped);
+    return check_launch("nonneg_param_fwd");
+}
+extern "C" int lldwt_nonneg_param_bwd(const float* x, const float* gy, float* gx, int64_t n, float minimum, void* stream) {
+    LLDWT_REQUIRE(x && gy && gx && n >= 0, "nonneg_param_bwd: bad arguments");
+    if (n == 0) return 0;
+    float b, ped;
+    nonneg_consts(minimum, &b, &ped);
+    hipLaunchKernelGGL(k_nonneg_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, n, b);
+    return check_launch("nonneg_param_bwd");
+}
+
+extern "C" int lldwt_gauss_rate(const float* x, const float* params, const float* noise, float* bits, float* qout,
+                                double* bit_sum, int64_t Z, int C, int64_t hw, void* stream) {
+    LLDWT_REQUIRE(x && params && Z > 0 && C > 0 && hw > 0, "gauss_rate: bad arguments");
+    const int64_t n = Z * C * hw;
+    hipLaunchKernelGGL(k_gauss_rate, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, params, noise, bits, qout,
+                       bit_sum, C, hw, n);
+    return check_launch("gauss_rate");
+}
+extern "C" int lldwt_quantize(const float* x, const float* noise, float* q, int64_t n, void* stream) {
+    LLDWT_REQUIRE(x && q && n >= 0, "quantize: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_quantize, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, noise, q, n);
+    return check_launch("quantize");
+}
+extern "C" int lldwt_factorized_rate(const float* x, const float* eb, const float* noise, float* bits, float* qout,
+                                     double* bit_sum, int64_t planes, int64_t batch, int C, int64_t hw, void* stream) {
+    LLDWT_REQUIRE(x && eb && planes > 0 && batch > 0 && C > 0 && hw > 0, "factorized_rate: bad arguments");
+    LLDWT_REQUIRE(planes * batch <= 65535 && C <= 65535, "factorized_rate: grid too large");
+    int64_t gx = cdiv(hw, 256);
+    if (gx > 1024) gx = 1024;
+    dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_factorized_rate, grid, dim3(256), 0, (hipStream_t)stream, x, eb, noise, bits, qout, bit_sum,
+                       (int)batch, C, hw);
+    return check_launch("factorized_rate");
+}
+extern "C" int lldwt_sq_err_sum(const float* a, const float* b, int64_t n, double* out, void* stream) {
+    LLDWT_REQUIRE(a && b && out && n > 0, "sq_err_sum: bad arguments");
+    hipLaunchKernelGGL(k_sq_err_sum, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+    return check_launch("sq_err_sum");
+}
+extern "C" int lldwt_sum(const float* x, int64_t n, double* out, void* stream) {
+    LLDWT_REQUIRE(x && out && n > 0, "sum: bad arguments");
+    hipLaunchKernelGGL(k_sum, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return check_launch("sum");
+}
+
+extern "C" int lldwt_conv2d(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
+                            int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream) {
+    return lldwt_conv2d_direct(x, y, w, bias, d, planes, batch, h, w_, stream);
+}

@@ -1,0 +1,263 @@
+"""Tensor-level wrappers over the C-ABI (include/lldwt.h).  PyTorch supplies device memory and the stream only.
+
+Tensor convention: "plane-major" (P, B, C, h, w) fp32 contiguous CUDA(HIP) tensors; P = number of per-plane networks
+(3 for clrch == 1), parameters stacked on a leading P axis.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_TANH, ConvDesc, View, check  # noqa: F401
+
+_ws = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise _lib.LLDWTError("%s must be a contiguous fp32 device tensor (got %s)" % (
+            name, None if t is None else (t.device, t.dtype, t.is_contiguous())))
+    return C.c_void_p(t.data_ptr())
+
+
+def _opt(t, name="tensor"):
+    return C.c_void_p(0) if t is None else _chk(t, name)
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device (the library never allocates: include/lldwt.h conventions)."""
+    key = (device.type, device.index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def rgb_to_ycc(x):
+    """(B,3,H,W) RGB in [0,1] -> plane-major (3,B,1,H,W) YCbCr with Y-0.5 (agents/liftingDWT_agent.py:86-87)."""
+    lib = _lib.load()
+    B, c, H, W = x.shape
+    assert c == 3
+    y = torch.empty(3, B, 1, H, W, device=x.device, dtype=torch.float32)
+    check(lib.lldwt_rgb_to_ycc(_chk(x, "x"), _chk(y), B, H, W, _stream()), "rgb_to_ycc")
+    return y
+
+
+def ycc_to_rgb(y, clamp=False):
+    """plane-major (3,B,1,H,W) -> (B,3,H,W) RGB-0.5 (agents/liftingDWT_agent.py:90-94, clamp :181)."""
+    lib = _lib.load()
+    _, B, _, H, W = y.shape
+    x = torch.empty(B, 3, H, W, device=y.device, dtype=torch.float32)
+    check(lib.lldwt_ycc_to_rgb(_chk(y, "y"), _chk(x), B, H, W, int(bool(clamp)), _stream()), "ycc_to_rgb")
+    return x
+
+
+def pblock_packed_floats(Cc, K):
+    return int(_lib.load().lldwt_pblock_packed_floats(Cc, K))
+
+
+def pack_pblock(w1, b1, w2, b2, w3, b3, w4, b4):
+    """Stacked P_block_v2 parameters (planes, ...) in PyTorch layout -> packed (planes, total) buffer."""
+    lib = _lib.load()
+    planes, Cc, _, K, _ = w1.shape
+    out = torch.empty(planes, pblock_packed_floats(Cc, K), device=w1.device, dtype=torch.float32)
+    check(lib.lldwt_pack_pblock(_chk(w1), _chk(b1), _chk(w2), _chk(b2), _chk(w3), _chk(b3), _chk(w4), _chk(b4),
+                                _chk(out), planes, Cc, K, _stream()), "pack_pblock")
+    return out
+
+
+def view_of(t, z, h, w, offset=0, sz=None, sy=None, sx=1):
+    """lldwt_view over the storage of ``t`` (element offsets/strides)."""
+    return View(C.c_void_p(t.data_ptr() + 4 * offset), sz if sz is not None else h * w, sy if sy is not None else w, sx)
+
+
+def lift_step(src, dst_in, dst_out, Z, batch, h, w, taps, packed, Cc, K, vertical, sign, res_weight, linear=False):
+    """One lifting step on lldwt_view arguments (see include/lldwt.h)."""
+    lib = _lib.load()
+    nb = lib.lldwt_lift_step_ws_bytes(Z, h, w, Cc)
+    ws = workspace(nb, taps.device)
+    check(lib.lldwt_lift_step(src, dst_in, dst_out, Z, batch, h, w, _chk(taps), _chk(packed), Cc, K, int(vertical),
+                              float(sign), float(res_weight), int(bool(linear)), C.c_void_p(ws.data_ptr()), nb,
+                              _stream()), "lift_step")
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def lifting_forward(x, taps, packed, levels, Cc, K, res_weight, linear=False, different=False, scale_nh=None,
+                    scale_nl=None):
+    """x: (P,B,1,H,W) -> (ll (P,B,1,H>>L,W>>L), [yh_i (P,B,3,H>>(i+1),W>>(i+1))])  (lifting_dwt_nets.py:728-732)."""
+    lib = _lib.load()
+    P, B, _, H, W = x.shape
+    dev = x.device
+    ll = torch.empty(P, B, 1, H >> levels, W >> levels, device=dev, dtype=torch.float32)
+    yh = [torch.empty(P, B, 3, H >> (i + 1), W >> (i + 1), device=dev, dtype=torch.float32) for i in range(levels)]
+    nb = lib.lldwt_lifting_ws_bytes(P * B, H, W, Cc)
+    ws = workspace(nb, dev)
+    check(lib.lldwt_lifting_forward(_chk(x, "x"), _chk(ll), _ptr_array(yh), P, B, H, W, levels, _chk(taps, "taps"),
+                                    _chk(packed, "packed"), int(bool(different)), Cc, K, float(res_weight),
+                                    int(bool(linear)), _opt(scale_nh), _opt(scale_nl), C.c_void_p(ws.data_ptr()), nb,
+                                    _stream()), "lifting_forward")
+    return ll, yh
+
+
+def lifting_inverse(ll, yh, taps, packed, Cc, K, res_weight, linear=False, different=False, scale_nh=None,
+                    scale_nl=None):
+    lib = _lib.load()
+    levels = len(yh)
+    P, B, _, hl, wl = ll.shape
+    H, W = hl << levels, wl << levels
+    dev = ll.device
+    x = torch.empty(P, B, 1, H, W, device=dev, dtype=torch.float32)
+    for t in yh:
+        _chk(t, "yh")
+    nb = lib.lldwt_lifting_ws_bytes(P * B, H, W, Cc)
+    ws = workspace(nb, dev)
+    check(lib.lldwt_lifting_inverse(_chk(ll, "ll"), _ptr_array(yh), _chk(x), P, B, H, W, levels, _chk(taps, "taps"),
+                                    _chk(packed, "packed"), int(bool(different)), Cc, K, float(res_weight),
+                                    int(bool(linear)), _opt(scale_nh), _opt(scale_nl), C.c_void_p(ws.data_ptr()), nb,
+                                    _stream()), "lifting_inverse")
+    return x
+
+
+def cdf97_forward(x, levels):
+    """x: (Z..., H, W) as (P,B,C,H,W) -> (ll, [yh_i (P,B,C*3? no: (P,B*C,3,h,w))]).  Channels are folded into batch."""
+    lib = _lib.load()
+    P, B, Cc, H, W = x.shape
+    Z = P * B * Cc
+    dev = x.device
+    ll = torch.empty(P, B, Cc, H >> levels, W >> levels, device=dev, dtype=torch.float32)
+    yh = [torch.empty(P, B, Cc, 3, H >> (i + 1), W >> (i + 1), device=dev, dtype=torch.float32) for i in range(levels)]
+    nb = lib.lldwt_cdf97_ws_bytes(Z, H, W)
+    ws = workspace(nb, dev)
+    check(lib.lldwt_cdf97_forward(_chk(x, "x"), _chk(ll), _ptr_array(yh), Z, H, W, levels, C.c_void_p(ws.data_ptr()), nb,
+                                  _stream()), "cdf97_forward")
+    return ll, yh
+
+
+def cdf97_inverse(ll, yh):
+    lib = _lib.load()
+    levels = len(yh)
+    P, B, Cc, hl, wl = ll.shape
+    H, W = hl << levels, wl << levels
+    Z = P * B * Cc
+    x = torch.empty(P, B, Cc, H, W, device=ll.device, dtype=torch.float32)
+    for t in yh:
+        _chk(t, "yh")
+    nb = lib.lldwt_cdf97_ws_bytes(Z, H, W)
+    ws = workspace(nb, ll.device)
+    check(lib.lldwt_cdf97_inverse(_chk(ll, "ll"), _ptr_array(yh), _chk(x), Z, H, W, levels, C.c_void_p(ws.data_ptr()), nb,
+                                  _stream()), "cdf97_inverse")
+    return x
+
+
+def subband_mlp(x, w0, b0, w1, b1, w2, b2, w3, b3, transposed=False, hidden=32):
+    """SubbandAutoEncoder encode/decode (lifting_dwt_nets.py:99-110); x: (P,B,C,h,w), weights stacked (P,...)."""
+    lib = _lib.load()
+    P, B, Cc, h, w = x.shape
+    y = torch.empty_like(x)
+    check(lib.lldwt_subband_mlp(_chk(x, "x"), _chk(y), P, B, Cc, h * w, hidden, _chk(w0), _chk(b0), _chk(w1), _chk(b1),
+                                _chk(w2), _chk(b2), _chk(w3), _chk(b3), int(bool(transposed)), _stream()), "subband_mlp")
+    return y
+
+
+def conv2d(x, w, bias, K, groups=1, act=ACT_NONE, upsample2=False, transposed=False, tap_mask=None, out=None,
+           oc_block=None, oc_stride=0, oc_off=0, direct=False):
+    """General conv layer (include/lldwt.h lldwt_conv2d).  x: (P,B,cin,h,w); w: (P,cout,cin/groups,K,K)
+    (transposed: (P,cin,cout,K,K)).  ``out``: optional pre-allocated (P,B,ytot,h,w) tensor for channel placement."""
+    lib = _lib.load()
+    P, B, cin, hi, wi = x.shape
+    cout = w.shape[2] if transposed else w.shape[1]
+    h, wd = (hi * 2, wi * 2) if upsample2 else (hi, wi)
+    if out is None:
+        out = torch.empty(P, B, cout, h, wd, device=x.device, dtype=torch.float32)
+    ytot = out.shape[2]
+    d = ConvDesc(cin, cout, K, groups, act, int(bool(upsample2)), int(bool(transposed)),
+                 (1 << (K * K)) - 1 if tap_mask is None else int(tap_mask),
+                 cout if oc_block is None else oc_block, oc_stride, oc_off, ytot)
+    fn = lib.lldwt_conv2d_direct if direct else lib.lldwt_conv2d
+    check(fn(_chk(x, "x"), _chk(out, "out"), _chk(w, "w"), _opt(bias, "bias"), C.byref(d), P, B, h, wd, _stream()),
+          "conv2d")
+    return out
+
+
+def gdn(x, beta, gamma, inverse=False, beta_min=1e-6):
+    lib = _lib.load()
+    P, B, Cc, h, w = x.shape
+    y = torch.empty_like(x)
+    check(lib.lldwt_gdn(_chk(x, "x"), _chk(y), _chk(beta), _chk(gamma), P, B, Cc, h * w, int(bool(inverse)),
+                        float(beta_min), _stream()), "gdn")
+    return y
+
+
+def lower_bound_fwd(x, bound):
+    y = torch.empty_like(x)
+    check(_lib.load().lldwt_lower_bound_fwd(_chk(x), _chk(y), x.numel(), float(bound), _stream()), "lower_bound_fwd")
+    return y
+
+
+def lower_bound_bwd(x, gy, bound):
+    gx = torch.empty_like(x)
+    check(_lib.load().lldwt_lower_bound_bwd(_chk(x), _chk(gy), _chk(gx), x.numel(), float(bound), _stream()),
+          "lower_bound_bwd")
+    return gx
+
+
+def nonneg_param_fwd(x, minimum):
+    y = torch.empty_like(x)
+    check(_lib.load().lldwt_nonneg_param_fwd(_chk(x), _chk(y), x.numel(), float(minimum), _stream()), "nonneg_param_fwd")
+    return y
+
+
+def nonneg_param_bwd(x, gy, minimum):
+    gx = torch.empty_like(x)
+    check(_lib.load().lldwt_nonneg_param_bwd(_chk(x), _chk(gy), _chk(gx), x.numel(), float(minimum), _stream()),
+          "nonneg_param_bwd")
+    return gx
+
+
+def quantize(x, noise=None):
+    q = torch.empty_like(x)
+    check(_lib.load().lldwt_quantize(_chk(x), _opt(noise), _chk(q), x.numel(), _stream()), "quantize")
+    return q
+
+
+def gauss_rate(x, params, noise=None, want_q=False, bit_sum=None):
+    """x: (P,B,C,h,w); params: (P,B,2C,h,w) (sigma even, mu odd channels) -> (bits, q or None)."""
+    P, B, Cc, h, w = x.shape
+    assert params.shape == (P, B, 2 * Cc, h, w)
+    bits = torch.empty_like(x)
+    q = torch.empty_like(x) if want_q else None
+    bs = C.c_void_p(0) if bit_sum is None else C.c_void_p(bit_sum.data_ptr())
+    check(_lib.load().lldwt_gauss_rate(_chk(x), _chk(params), _opt(noise), _chk(bits), _opt(q), bs, P * B, Cc, h * w,
+                                       _stream()), "gauss_rate")
+    return bits, q
+
+
+def factorized_rate(x, eb, noise=None, bit_sum=None):
+    """x: (P,B,C,h,w); eb: (P,C,59) packed EntropyBottleneck parameters -> (bits, q)."""
+    P, B, Cc, h, w = x.shape
+    assert eb.shape == (P, Cc, _lib.EB_FLOATS)
+    bits = torch.empty_like(x)
+    q = torch.empty_like(x)
+    bs = C.c_void_p(0) if bit_sum is None else C.c_void_p(bit_sum.data_ptr())
+    check(_lib.load().lldwt_factorized_rate(_chk(x), _chk(eb), _opt(noise), _chk(bits), _chk(q), bs, P, B, Cc, h * w,
+                                            _stream()), "factorized_rate")
+    return bits, q
+
+
+def sq_err_sum(a, b, out):
+    check(_lib.load().lldwt_sq_err_sum(_chk(a), _chk(b), a.numel(), C.c_void_p(out.data_ptr()), _stream()), "sq_err_sum")
+
+
+def sum_into(x, out):
+    check(_lib.load().lldwt_sum(_chk(x), x.numel(), C.c_void_p(out.data_ptr()), _stream()), "sum")

@@ -1,0 +1,187 @@
+/*
+ * lldwt.h -- C-ABI of the MI355X-native learned-lifting DWT + CNN entropy-model hot path.
+ *
+ * Drop-in boundary.  The reference (uberkk/ImageCompressionLearnedLiftingandLearnedTreeBasedModels)
+ * is pure PyTorch and defines no FFI; its boundary for this path is the Python module API
+ * (agents/liftingDWT_agent.py, graphs/models/LiftingBasedDWT_net.py).  The entry points below are what the
+ * host-side mirror of those modules binds through ctypes; each one cites the reference
+ * code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (allocated by the host
+ *    framework, e.g. PyTorch's caching allocator).  The library never allocates or frees user-visible memory;
+ *    scratch space is passed in as `ws` and sized by the matching *_ws_bytes() query.
+ *  - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, no call synchronises.
+ *  - return value: 0 on success, negative LLDWT_E* otherwise; lldwt_last_error() gives a message
+ *    (thread-local, valid until the next failing call on the thread).  No exceptions cross the boundary.
+ *  - tensors are fp32, dense, "plane-major NCHW": shape (Z, C, h, w) with Z = planes*batch, plane-major
+ *    (z = plane*batch + b).  A *plane* is one colour channel processed by its own network (clrch == 1:
+ *    LiftingBasedDWT_net.py:43-46); parameters of the `planes` networks are stacked on a leading axis and
+ *    addressed as base + plane*stride.
+ */
+#ifndef LLDWT_H
+#define LLDWT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLDWT_OK 0
+#define LLDWT_EINVAL (-1)   /* bad argument / unsupported shape */
+#define LLDWT_EHIP (-2)     /* HIP runtime error (launch failed) */
+#define LLDWT_EWS (-3)      /* workspace too small */
+
+#define LLDWT_ACT_NONE 0
+#define LLDWT_ACT_TANH 1
+#define LLDWT_ACT_LRELU 2   /* LeakyReLU(0.01) */
+
+const char* lldwt_last_error(void);
+int lldwt_version(void);
+/* 1 if the calling process sees a gfx950 device, 0 otherwise (no compute is launched). */
+int lldwt_device_ok(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Strided view of a (Z, h, w) single-channel tensor: element (z,y,x) at p[z*sz + y*sy + x*sx].
+ * Used for the polyphase components: the even/odd rows (or columns) of an array are views with sy (sx)
+ * doubled, so the split (wavelet_forward_v2.py:27-28,33-34,45-46) and the merge
+ * (wavelet_inverse_v2.py:49-53) are pure addressing -- no copies, bit-exact by construction.            */
+typedef struct lldwt_view {
+    float* p;
+    int64_t sz, sy, sx;
+} lldwt_view;
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Colour transforms of the agent (agents/liftingDWT_agent.py:86-87,90-94; compressai RGB2YCbCr/YCbCr2RGB,
+ * BT.709).  rgb: (B,3,H,W) NCHW in [0,1].  ycc: plane-major (3,B,1,H,W) with 0.5 subtracted from Y only.
+ * inverse: ycc -> rgb, then "- 0.5" (agents/liftingDWT_agent.py:94) and optional clamp to [-0.5,0.5] (:181). */
+int lldwt_rgb_to_ycc(const float* rgb, float* ycc, int64_t B, int64_t H, int64_t W, void* stream);
+int lldwt_ycc_to_rgb(const float* ycc, float* rgb, int64_t B, int64_t H, int64_t W, int clamp, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * P/U block parameters (graphs/layers/P_block_v2.py:15-33) packed for the kernels.
+ * lldwt_pack_pblock: in = the four conv weights/biases of `planes` stacked blocks in PyTorch layout
+ *   w1 (planes,C,1,K,K)  w2,w3 (planes,C,C,K,K)  w4 (planes,1,C,K,K), b1,b2,b3 (planes,C), b4 (planes,1);
+ *   out = packed buffer of lldwt_pblock_packed_floats(C,K) floats PER PLANE holding both orientations
+ *   (vertical pass uses W, horizontal pass uses W transposed in (kh,kw): conv(x^T,W)^T == conv(x,W^T), which
+ *   removes every torch.transpose of wavelet_forward_v2.py:32,38-39,43,50-51).                           */
+int64_t lldwt_pblock_packed_floats(int C, int K);
+int lldwt_pack_pblock(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                      const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
+                      void* stream);
+
+/* One lifting step (wavelet_forward_v2.py:60-62 and the three like it; inverse wavelet_inverse_v2.py:76-90):
+ *     skip = conv3x1(src, taps)            zero padded, along rows if vertical else along columns
+ *     net  = P_block(skip)                 conv1 -> tanh -> conv2 -> tanh -> conv3 (+conv1 pre-act) -> conv4
+ *     dst_out = dst_in + sign * (skip + res_weight * net)
+ * src/dst_in/dst_out are (Z,h,w) views; dst_out may alias dst_in.  taps: (planes,3) device floats
+ * (preProcessingList.{j}.weight, lifting_dwt_nets.py:785-819).  packed: lldwt_pack_pblock output.
+ * linear != 0 drops the tanh (linearity_flag != 1, P_block_v2.py:42-49).
+ * ws: >= lldwt_lift_step_ws_bytes(Z,h,w,C) bytes.                                                        */
+int64_t lldwt_lift_step_ws_bytes(int64_t Z, int64_t h, int64_t w, int C);
+int lldwt_lift_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, int64_t Z, int64_t batch, int64_t h,
+                    int64_t w, const float* taps, const float* packed, int C, int K, int vertical, float sign,
+                    float res_weight, int linear, void* ws, int64_t ws_bytes, void* stream);
+
+/* Whole multi-level transform of LiftingBasedNeuralWaveletv4.encode (lifting_dwt_nets.py:728-732), all planes
+ * and images in one call.  x: (Z,1,H,W) plane-major; ll: (Z,1,H>>L,W>>L); yh[i]: (Z,3,H>>(i+1),W>>(i+1)) with
+ * channels (LH,HL,HH), finest first (the layout of out_xo_list before the subband auto-encoder, :739-740).
+ * taps: (4,planes,3) = preProcessingList.{j}.weight of every plane, j-major; packed: (planes, nblocks, 2 (P,U), packed_floats) -- nblocks = 2 for
+ * block_property=="same", 2*2*levels for "different" (lifting_dwt_nets.py:688-722).
+ * scale_nh/scale_nl: device (planes) floats = lifting_coeff[4/5] + n*0.1 when config.scale==1, else NULL.  */
+int64_t lldwt_lifting_ws_bytes(int64_t Z, int64_t H, int64_t W, int C);
+int lldwt_lifting_forward(const float* x, float* ll, float* const* yh, int64_t planes, int64_t batch, int64_t H,
+                          int64_t W, int levels, const float* taps, const float* packed, int different, int C,
+                          int K, float res_weight, int linear, const float* scale_nh, const float* scale_nl,
+                          void* ws, int64_t ws_bytes, void* stream);
+/* Inverse (LiftingBasedNeuralWaveletv4.decode, lifting_dwt_nets.py:762-781; wavelet_inverse_v2.py:20-92).  */
+int lldwt_lifting_inverse(const float* ll, const float* const* yh, float* x, int64_t planes, int64_t batch,
+                          int64_t H, int64_t W, int levels, const float* taps, const float* packed, int different,
+                          int C, int K, float res_weight, int linear, const float* scale_nh, const float* scale_nl,
+                          void* ws, int64_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * SubbandAutoEncoder (lifting_dwt_nets.py:99-110): per-coefficient scalar MLP 1 -> Hd -> Hd -> Hd -> 1, tanh
+ * between, grouped 1x1 convs (groups == channels).  x,y: (Z,C,h,w).  Parameters per plane, PyTorch layouts:
+ *   encode: w0 (C*Hd,1) b0 (C*Hd)  w1,w2 (C*Hd,Hd) b1,b2 (C*Hd)  w3 (C,Hd) b3 (C)         [Conv2d]
+ *   decode: ConvTranspose2d weights (in, out/groups): w0 (C,Hd) w1,w2 (C*Hd,Hd) w3 (C*Hd,1); transposed != 0. */
+int lldwt_subband_mlp(const float* x, float* y, int64_t planes, int64_t batch, int C, int64_t hw, int Hd,
+                      const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* w3, const float* b3, int transposed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * General conv layer for the context models and the Berk auto-encoder
+ * (LiftingBasedDWT_net.py:271-289,299-317,793-795; lifting_dwt_nets.py:139-150; masked_conv2d.py:19-21).
+ *   y[z, oc', :, :] = act( bias[oc] + sum_{ic,ky,kx} w[oc, ic, ky, kx] * x[z, g*cin_g + ic, .+ky-K/2, .+kx-K/2] )
+ * zero padded, stride 1.  x: (Z,cin,h,w) (if upsample2: (Z,cin,h/2,w/2), read through the nearest-neighbour 2x
+ * upsampling of LiftingBasedDWT_net.py:348,367,822,835).  w: (planes,cout,cin/groups,K,K) (if transposed:
+ * ConvTranspose2d layout (planes,cin,cout,K,K), groups must be 1), bias (planes,cout) or NULL.
+ * tap_mask: bit (ky*K+kx) set = tap is live (MaskedConv2d type A/B; the caller has already applied
+ * weight *= mask as the reference does); pass (1<<K*K)-1 for a dense conv.
+ * Output channel placement (removes the chunk/cat regrouping of LiftingBasedDWT_net.py:357-359):
+ *   oc' = (oc / oc_block) * oc_stride + oc_off + oc % oc_block   in a tensor of ytot channels;
+ *   dense placement is oc_block = cout, oc_stride = 0, oc_off = 0, ytot = cout.                           */
+typedef struct lldwt_conv_desc {
+    int cin, cout, K, groups;
+    int act;          /* LLDWT_ACT_* */
+    int upsample2;
+    int transposed;
+    uint32_t tap_mask;
+    int oc_block, oc_stride, oc_off, ytot;
+} lldwt_conv_desc;
+int lldwt_conv2d(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
+                 int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+/* Same contract, always the reference-order direct kernel (VALU); used to cross-check the MFMA engine on the GPU. */
+int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
+                        int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+
+/* GDN / inverse GDN (graphs/layers/gdn.py:77-92) with the NonNegativeParametrizer re-parametrisation
+ * (utils/parametrizers.py:45-48) applied in-kernel to the raw beta (planes,C) / gamma (planes,C,C).         */
+int lldwt_gdn(const float* x, float* y, const float* beta, const float* gamma, int64_t planes, int64_t batch,
+              int C, int64_t hw, int inverse, float beta_min, void* stream);
+
+/* LowerBound (utils/bound_ops.py:22-28) and NonNegativeParametrizer (utils/parametrizers.py:45-48), elementwise. */
+int lldwt_lower_bound_fwd(const float* x, float* y, int64_t n, float bound, void* stream);
+int lldwt_lower_bound_bwd(const float* x, const float* gy, float* gx, int64_t n, float bound, void* stream);
+int lldwt_nonneg_param_fwd(const float* x, float* y, int64_t n, float minimum, void* stream);
+int lldwt_nonneg_param_bwd(const float* x, const float* gy, float* gx, int64_t n, float minimum, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Rate estimation, fused quantise + likelihood + both LowerBounds + -log2 + sum of bits.
+ * Gaussian (compressai GaussianConditional.forward as called at LiftingBasedDWT_net.py:334,345,364,832):
+ *   v = mode==0 ? round(x - mu) + mu : x + noise       (noise: U(-.5,.5) tensor or NULL -> eval)
+ *   p = Phi((.5-|v-mu|)/max(sigma,0.11)) - Phi((-.5-|v-mu|)/max(sigma,0.11)),  bits = -log2(max(p,1e-9))
+ * params: (Z, 2C, h, w) with sigma = channel 2c, mu = channel 2c+1 (:332-333).  x, bits, qout: (Z,C,h,w).
+ * qout (optional) receives v (what onlyEZWT hands to the decoder, :832-834).  bits (optional).
+ * bit_sum (optional): one device double, accumulated atomically (caller zeroes it).                       */
+int lldwt_gauss_rate(const float* x, const float* params, const float* noise, float* bits, float* qout,
+                     double* bit_sum, int64_t Z, int C, int64_t hw, void* stream);
+/* quantize(x, mode, means=None): round(x) or x + noise (LiftingBasedDWT_net.py:330,341,352). */
+int lldwt_quantize(const float* x, const float* noise, float* q, int64_t n, void* stream);
+
+/* Factorized (compressai EntropyBottleneck.forward, call sites LiftingBasedDWT_net.py:225,229,815,818):
+ * per channel c of plane p: 5 tiny matrices softplus(_matrix{i}) (1x3,3x3,3x3,3x3,3x1), biases, tanh(_factor).
+ * eb: packed per (plane,channel) block of LLDWT_EB_FLOATS floats =
+ *   [m0(3) b0(3) f0(3) m1(9) b1(3) f1(3) m2(9) b2(3) f2(3) m3(9) b3(3) f3(3) m4(3) b4(1) median(1)] raw values. */
+#define LLDWT_EB_FLOATS 59
+int lldwt_factorized_rate(const float* x, const float* eb, const float* noise, float* bits, float* qout,
+                          double* bit_sum, int64_t planes, int64_t batch, int C, int64_t hw, void* stream);
+
+/* sum((a-b)^2) and sum(x) into a double (graphs/losses/rate_dist.py:36-41). */
+int lldwt_sq_err_sum(const float* a, const float* b, int64_t n, double* out, void* stream);
+int lldwt_sum(const float* x, int64_t n, double* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Fixed CDF 9/7 (bior4.4) DWT, periodization (DWTPytorchWaveletsLayer, lifting_dwt_nets.py:228-231,250,274).
+ * Same tensor conventions as lldwt_lifting_forward/inverse.                                                */
+int64_t lldwt_cdf97_ws_bytes(int64_t Z, int64_t H, int64_t W);
+int lldwt_cdf97_forward(const float* x, float* ll, float* const* yh, int64_t Z, int64_t H, int64_t W, int levels,
+                        void* ws, int64_t ws_bytes, void* stream);
+int lldwt_cdf97_inverse(const float* ll, const float* const* yh, float* x, int64_t Z, int64_t H, int64_t W,
+                        int levels, void* ws, int64_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLDWT_H */

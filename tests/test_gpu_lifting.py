@@ -1,0 +1,134 @@
+"""GPU parity: HIP lifting kernels (through the C-ABI) vs the oracle and the reference golden vectors."""
+import pytest
+import torch
+
+from helpers import filled, load_golden, maxdiff
+from oracle import lifting, model, weights
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # north_star: fp within 1e-4 on subband coefficients
+
+
+def _ops():
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    import gpu_util
+    return ops, gpu_util
+
+
+@pytest.mark.parametrize("K", [3, 5])
+@pytest.mark.parametrize("vertical", [1, 0])
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_lift_step_vs_oracle(K, vertical, sign):
+    ops, gu = _ops()
+    cfg = dict(model.DEFAULT_CFG, filtersize=K, dwtlevels=1)
+    sds = [filled(weights.autoencoder_template(cfg), "m%d." % p) for p in range(2)]
+    g = torch.Generator().manual_seed(5)
+    P, B, h, w = 2, 2, 19, 45          # ragged: not multiples of the 16x32 tile
+    src = torch.rand(P, B, 1, h, w, generator=g) - 0.5
+    dst = torch.rand(P, B, 1, h, w, generator=g) - 0.5
+    taps, packed = gu.lifting_params(sds)
+    src_d, dst_d = gu.dev(src), gu.dev(dst)
+    out_d = torch.empty_like(dst_d)
+    Z = P * B
+    v = lambda t: ops.view_of(t, Z, h, w)
+    # step index 1 = U0 with taps[1]
+    ops.lift_step(v(src_d), v(dst_d), v(out_d), Z, B, h, w, taps[1].contiguous(), packed[:, 0, 1].contiguous(), 16, K,
+                  vertical, sign, 0.1)
+    for p in range(P):
+        s, d = src[p], dst[p]
+        if not vertical:
+            s, d = s.transpose(2, 3), d.transpose(2, 3)
+        skip = lifting.skip_filter(s, sds[p]["preProcessingList.1.weight"])
+        ref = d + sign * (skip + 0.1 * lifting.p_block(skip, sds[p], "U_blocks.0."))
+        if not vertical:
+            ref = ref.transpose(2, 3)
+        assert maxdiff(out_d[p].cpu(), ref) < 2e-5, (p, K, vertical, sign)
+
+
+def test_split_merge_indexing_bit_exact():
+    """Zero P/U weights and zero taps make every lifting step the identity, so the transform is the pure polyphase
+    split (wavelet_forward_v2.py:27-28,33-34,45-46) and its inverse the merge (wavelet_inverse_v2.py:49-53)."""
+    ops, gu = _ops()
+    cfg = dict(model.DEFAULT_CFG, dwtlevels=2)
+    sd = {k: torch.zeros_like(v) for k, v in weights.autoencoder_template(cfg).items()}
+    taps, packed = gu.lifting_params([sd])
+    B, H, W = 2, 24, 40
+    x = torch.arange(B * H * W, dtype=torch.float32).reshape(1, B, 1, H, W)
+    ll, yh = ops.lifting_forward(gu.dev(x), taps, packed, 2, 16, 5, 0.1)
+    x0 = x[0]
+    # level 0: rows then columns; HL = even rows/odd cols, LH = odd rows/even cols
+    assert torch.equal(yh[0][0][:, 0].cpu(), x0[:, 0, 1::2, 0::2])   # LH
+    assert torch.equal(yh[0][0][:, 1].cpu(), x0[:, 0, 0::2, 1::2])   # HL
+    assert torch.equal(yh[0][0][:, 2].cpu(), x0[:, 0, 1::2, 1::2])   # HH
+    l1 = x0[:, 0, 0::2, 0::2]
+    assert torch.equal(yh[1][0][:, 0].cpu(), l1[:, 1::2, 0::2])
+    assert torch.equal(yh[1][0][:, 1].cpu(), l1[:, 0::2, 1::2])
+    assert torch.equal(yh[1][0][:, 2].cpu(), l1[:, 1::2, 1::2])
+    assert torch.equal(ll[0][:, 0].cpu(), l1[:, 0::2, 0::2])
+    xr = ops.lifting_inverse(ll, yh, taps, packed, 16, 5, 0.1)
+    assert torch.equal(xr.cpu(), x)
+
+
+@pytest.mark.parametrize("name", ["ref_lifting_L2_k5", "ref_lifting_L3_k3_rect", "ref_lifting_L2_different",
+                                  "ref_lifting_L2_linear", "ref_lifting_L2_scale_berk"])
+def test_lifting_vs_reference_golden(name):
+    ops, gu = _ops()
+    g = load_golden(name)
+    cfg = g["cfg"]
+    sd = filled(weights.autoencoder_template(cfg))
+    L, K = cfg["dwtlevels"], cfg["filtersize"]
+    different = cfg["block_property"] == "different"
+    nblocks = 2 * 2 * L if different else 2
+    taps, packed = gu.lifting_params([sd], nblocks)
+    linear = cfg["linearity_flag"] != 1
+    nh = nl = None
+    if cfg["scale"] == 1:
+        nh = gu.dev((lifting.LIFTING_COEFF[4] + sd["nh"] * 0.1).reshape(1))
+        nl = gu.dev((lifting.LIFTING_COEFF[5] + sd["nl"] * 0.1).reshape(1))
+    x = gu.pm(g["x"])
+    ll, yh = ops.lifting_forward(x, taps, packed, L, 16, K, 0.1, linear, different, nh, nl)
+    # one-level outputs stored by the reference run
+    for j, n in enumerate(("LH", "HL", "HH")):
+        assert maxdiff(yh[0][0][:, j:j + 1].cpu(), g[n]) < TOL, n
+    # oracle for the deeper levels (the oracle itself is pinned to the same fixture on CPU)
+    oLL, oYh = lifting.lifting_forward(g["x"], sd, cfg)
+    assert maxdiff(ll[0].cpu(), oLL) < TOL
+    for i in range(L):
+        assert maxdiff(yh[i][0].cpu(), oYh[i][:, 0]) < TOL
+    if L == 1:
+        assert maxdiff(ll[0].cpu(), g["LL"]) < TOL
+    xr = ops.lifting_inverse(ll, yh, taps, packed, 16, K, 0.1, linear, different, nh, nl)
+    oxr = lifting.lifting_inverse(oLL, oYh, sd, cfg)
+    assert maxdiff(xr[0].cpu(), oxr) < TOL
+    if not different:       # perfect reconstruction
+        assert maxdiff(xr[0].cpu(), g["x"]) < 2e-5
+
+
+def test_lifting_three_planes_batched():
+    """Three per-plane networks with distinct weights in one call == three oracle runs."""
+    ops, gu = _ops()
+    cfg = dict(model.DEFAULT_CFG, dwtlevels=2)
+    sds = [filled(weights.autoencoder_template(cfg), "model%d.autoencoder." % p) for p in range(3)]
+    taps, packed = gu.lifting_params(sds)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 2, 1, 32, 64, generator=g) - 0.5
+    ll, yh = ops.lifting_forward(gu.dev(x), taps, packed, 2, 16, 5, 0.1)
+    for p in range(3):
+        oLL, oYh = lifting.lifting_forward(x[p], sds[p], cfg)
+        assert maxdiff(ll[p].cpu(), oLL) < TOL
+        for i in range(2):
+            assert maxdiff(yh[i][p].cpu(), oYh[i][:, 0]) < TOL
+
+
+def test_bad_arguments_fail_loudly():
+    ops, gu = _ops()
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd._lib import LLDWTError
+    cfg = dict(model.DEFAULT_CFG, dwtlevels=2)
+    sd = filled(weights.autoencoder_template(cfg))
+    taps, packed = gu.lifting_params([sd])
+    x = torch.zeros(1, 1, 1, 20, 20, device=gu.DEV)
+    with pytest.raises(LLDWTError):
+        ops.lifting_forward(x, taps, packed, 3, 16, 5, 0.1)      # 20 not divisible by 8
+    with pytest.raises(LLDWTError):
+        ops.lifting_forward(x.cpu(), taps, packed, 2, 16, 5, 0.1)  # host tensor
