@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- Mpixels/s of (learned lifting DWT encode + entropy-model forward) at 512x512 RGB on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): learned 4-level lifting (k=5, 16 ch)
++ SubbandAutoEncoder + conditioned2ZTsepSubbands context model, 8 x 3 x 512 x 512 per GPU, fp32, eval mode, synthetic
+inputs resident in HBM, deterministic by-name weights.  One step = RGB->YCbCr, encode (lifting + subband AE), entropy
+model forward (all context CNNs + Gaussian rate) for 3 planes, sum of bits.  N > 1: the image batch is sharded across
+ranks (weak scaling, no data-path collective on the forward path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA / f32 vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(levels, device):
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import \
+        LiftingBasedDWTNetWrapper
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
+    from oracle import weights as oweights   # deterministic by-name weight filler only (no oracle compute here)
+    cfg = make_config(dwtlevels=levels, mode="validate")
+    sd = oweights.fill_by_name(oweights.wrapper_template(dict(cfg)))
+    net = LiftingBasedDWTNetWrapper(cfg)
+    net.load_state_dict(sd, strict=False)
+    return net.to(device).eval(), sd, cfg
+
+
+def cpu_baseline(sd, cfg, size, seconds_budget=25.0):
+    """Oracle (CPU port of the reference path) on a bounded sample of the same workload: 1 x 3 x size x size."""
+    from oracle import model as omodel
+    from oracle.entropy import ENTROPY_LAYERS
+    torch.set_num_threads(os.cpu_count())
+    x = torch.rand(1, 3, size, size, generator=torch.Generator().manual_seed(1337))
+
+    def run():
+        y = omodel.rgb2ycbcr(x) - omodel._YSHIFT
+        tot = 0.0
+        for c in range(3):
+            s = omodel.sub(sd, "model%d." % c)
+            oxe, oxo = omodel.encode(y[:, c:c + 1], omodel.sub(s, "autoencoder."), dict(cfg))
+            si_xe, si_xo, _, _ = ENTROPY_LAYERS[cfg["entropy_layer"]](oxe, oxo, omodel.sub(s, "entropymodel."), dict(cfg), False)
+            tot += float(si_xe.sum()) + sum(float(t.sum()) for t in si_xo)
+        return tot
+    with torch.no_grad():
+        run()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            run()
+            n += 1
+            if time.perf_counter() - t0 > seconds_budget / 2 or n >= 5:
+                break
+        dt = (time.perf_counter() - t0) / n
+    return {"value": size * size / dt / 1e6, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "oracle (torch-CPU restatement of the reference path), 1x3x%dx%d, %d timed runs after 1 warm-up" % (size, size, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import rate_planes
+    net, sd, cfg = build_model(a.levels, dev)
+    nets = net.nets()
+    x = torch.rand(a.batch, 3, a.size, a.size, device=dev, generator=torch.Generator(device=dev).manual_seed(1337 + rank))
+    bit_acc = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    # HIP events around the dominant kernel (plc second conv, 243 -> 243 3x3, LiftingBasedDWT_net.py:271-272): the
+    # kernels run on torch's current stream, which is the stream handed to the C-ABI.
+    dom = {"events": [], "flops": 0.0, "on": False}
+    conv2d_orig = ops.conv2d
+
+    def conv2d_timed(x_, w, bias, K, **kw):
+        is_dom = dom["on"] and K == 3 and w.shape[1] == 243 and w.shape[2] == 243 and not kw.get("transposed")
+        if not is_dom:
+            return conv2d_orig(x_, w, bias, K, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = conv2d_orig(x_, w, bias, K, **kw)
+        e1.record()
+        P, B, _, h, wd = x_.shape
+        dom["events"].append((e0, e1))
+        dom["flops"] += 2.0 * 243 * 243 * 9 * P * B * h * wd
+        return out
+    ops.conv2d = conv2d_timed
+    import imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net as M
+    M.ops.conv2d = conv2d_timed
+
+    def step():
+        with torch.no_grad():
+            y = ops.rgb_to_ycc(x)
+            si_xe, si_xo = rate_planes(nets, y, False)
+            ops.sum_into(si_xe, bit_acc)
+            for t in si_xo:
+                ops.sum_into(t, bit_acc)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dom["on"] = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dom["on"] = False
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom["events"])
+    n_launch = max(len(dom["events"]), 1)
+    achieved = dom["flops"] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    pixels = a.batch * a.size * a.size * world * a.steps
+    out = {
+        "metric": "Mpixels/sec (lifting DWT + entropy-model fwd) at 512x512 RGB",
+        "value": pixels / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: learned %d-level lifting (k=5,16ch) + SubbandAutoEncoder + "
+                               "conditioned2ZTsepSubbands, %dx3x%dx%d per GPU, eval" % (a.levels, a.batch, a.size, a.size),
+                   "per_gpu_batch": a.batch, "sharding": "batch over ranks, no data-path collective"},
+        "roofline": {"bound": "mfma", "kernel": "plc conv 243->243 3x3 (tree context, 61% of the step's FLOPs)",
+                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "avg_launch_ms": dom_ms / n_launch, "launches": len(dom["events"]),
+                     "algorithmic_flop_per_launch": dom["flops"] / n_launch},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sd, cfg, min(a.size, 256))
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,10 +43,10 @@ SIGNATURES = {
     "lldwt_lift_step_ws_bytes": (_i64, [_i64, _i64, _i64, _i]),
     "lldwt_lift_step": (_i, [View, View, View, _i64, _i64, _i64, _i64, _p, _p, _i, _i, _i, _f, _f, _i, _p, _i64, _p]),
     "lldwt_lifting_ws_bytes": (_i64, [_i64, _i64, _i64, _i]),
-    "lldwt_lifting_forward": (_i, [_p, _p, C.POINTER(_p), _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _f, _i, _p, _p,
-                                   _p, _i64, _p]),
-    "lldwt_lifting_inverse": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _f, _i, _p, _p,
-                                   _p, _i64, _p]),
+    "lldwt_lifting_forward": (_i, [_p, _p, C.POINTER(_p), _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _i, _i, _f, _i,
+                                   _p, _p, _p, _i64, _p]),
+    "lldwt_lifting_inverse": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _i, _f, _i,
+                                   _p, _p, _p, _i64, _p]),
     "lldwt_subband_mlp": (_i, [_p, _p, _i64, _i64, _i, _i64, _i] + [_p] * 8 + [_i, _p]),
     "lldwt_conv2d": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_direct": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),

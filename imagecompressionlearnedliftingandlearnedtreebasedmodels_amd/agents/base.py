@@ -1,0 +1,104 @@
+"""BaseAgent -- device selection, mode dispatch, epoch loop, checkpoint I/O (reference agents/base.py:13-188).
+
+One process per GPU: the device is ``cuda:LOCAL_RANK`` (the reference is single-GPU, agents/base.py:21,28).
+"""
+import logging
+import os
+import shutil
+
+import torch
+
+
+class BaseAgent:
+    def __init__(self, config):
+        self.config = config
+        self.logger = logging.getLogger("Agent")
+        self.best_valid_loss = float("inf")
+        self.current_epoch = 0
+        self.current_iteration = 0
+        if not torch.cuda.is_available():
+            raise RuntimeError("the agent needs a GPU: the product path has no CPU fallback (the reference also "
+                               "requires one, agents/base.py:27-28)")
+        local = int(os.environ.get("LOCAL_RANK", config.get("gpu_device", 0)))
+        torch.cuda.set_device(local)
+        self.device = torch.device("cuda", local)
+        self.cuda = True
+        self.manual_seed = config.seed
+        self.lr = config.learning_rate
+        torch.manual_seed(self.manual_seed + int(os.environ.get("RANK", 0)))   # per-rank noise streams
+        torch.cuda.manual_seed(self.manual_seed + int(os.environ.get("RANK", 0)))
+
+    # the four hooks of agents/base.py:30-61
+    def train_one_epoch(self):
+        raise NotImplementedError
+
+    def validate(self):
+        raise NotImplementedError
+
+    def test(self):
+        raise NotImplementedError
+
+    def load_checkpoint(self, file_name):
+        """Restores model + counters + loggers, NOT optimizer/scheduler (agents/base.py:63-95, :74-75 commented out)."""
+        filename = os.path.join(self.config.checkpoint_dir, file_name)
+        try:
+            ckpt = torch.load(filename, map_location=self.device, weights_only=False)   # files written by save_checkpoint
+        except OSError:
+            self.logger.info("No checkpoint exists from '%s'. Skipping...", self.config.checkpoint_dir)
+            return
+        self.current_epoch = ckpt["epoch"] + 1
+        self.current_iteration = ckpt["iteration"]
+        self.best_valid_loss = ckpt.get("best_valid_loss", self.best_valid_loss)
+        self.model.load_state_dict(ckpt["state_dict"], strict=False)
+        for name in ("train_logger", "trnit_logger", "valid_logger", "test_logger"):
+            if name in ckpt and hasattr(self, name):
+                getattr(self, name).load_state_dict(ckpt[name])
+
+    def save_checkpoint(self, file_name="checkpoint.pth.tar", is_best=0):
+        """agents/base.py:97-128."""
+        state = {"epoch": self.current_epoch, "iteration": self.current_iteration,
+                 "best_valid_loss": self.best_valid_loss, "state_dict": self.model.state_dict(),
+                 "optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict()}
+        for name in ("train_logger", "trnit_logger", "valid_logger", "test_logger"):
+            if hasattr(self, name):
+                state[name] = getattr(self, name).state_dict()
+        os.makedirs(self.config.checkpoint_dir, exist_ok=True)
+        path = os.path.join(self.config.checkpoint_dir, file_name)
+        torch.save(state, path)
+        if is_best:
+            shutil.copyfile(path, os.path.join(self.config.checkpoint_dir, "model_best.pth.tar"))
+
+    def run(self):
+        """Mode dispatch (agents/base.py:130-154): exceptions save a checkpoint and re-raise, Ctrl-C is swallowed."""
+        try:
+            mode = self.config.mode
+            if mode == "test":
+                self.test()
+            elif mode == "validate":
+                self.validate()
+            elif mode in ("train", "debug"):
+                self.train()
+            else:
+                raise NameError("'" + mode + "' is not a valid training mode.")
+        except KeyboardInterrupt:
+            self.logger.info("You have entered CTRL+C.. Wait to finalize")
+        except Exception:
+            if getattr(self, "optimizer", None) is not None and "checkpoint_dir" in self.config:
+                self.save_checkpoint()
+            raise
+
+    def train(self):
+        """Epoch loop (agents/base.py:156-168)."""
+        for _ in range(self.current_epoch, self.config.max_epoch):
+            self.train_one_epoch()
+            valid_loss = self.validate()
+            is_best = valid_loss < self.best_valid_loss
+            if is_best:
+                self.best_valid_loss = valid_loss
+            if "checkpoint_dir" in self.config:
+                self.save_checkpoint(is_best=is_best)
+            self.current_epoch += 1
+
+    def finalize(self):
+        if "checkpoint_dir" in self.config and getattr(self, "optimizer", None) is not None:
+            self.save_checkpoint()

@@ -1,0 +1,112 @@
+"""LiftingBasedDWTAgent -- per-batch maths, validation loop, optimizer set-up (reference agents/liftingDWT_agent.py).
+
+Same class name, constructor signature and method set as the reference agent (:14-366) so the JSON's
+``"agent": "LiftingBasedDWTAgent"`` resolves to it (main.py:30).  ``batch_forward`` is the forward half of
+``train_one_epoch`` (:84-96) / ``validate`` (:171-183): RGB->YCbCr, Y-0.5, model, +0.5, YCbCr->RGB, -0.5, forward3.
+"""
+import os
+
+import torch
+from torch import optim
+
+from .. import ops
+from ..graphs.losses.rate_dist import TrainDLoss, TrainRDLoss
+from ..graphs.models.LiftingBasedDWT_net import LiftingBasedDWTNetWrapper, forward_planes
+from ..loggers import RDLogger
+from .base import BaseAgent
+
+
+class SyntheticLoader:
+    """Stand-in for dataloaders/image_dl.py when no image folder is configured: seeded uniform RGB crops in [0,1]
+    (ToTensor range, dataloaders/image_dl.py:81), generated on the device."""
+
+    def __init__(self, n_batches, batch, size, device, seed):
+        self.n, self.b, self.s, self.dev, self.seed = n_batches, batch, size, device, seed
+
+    def __iter__(self):
+        g = torch.Generator(device=self.dev).manual_seed(self.seed)
+        for _ in range(self.n):
+            yield torch.rand(self.b, 3, self.s, self.s, device=self.dev, generator=g)
+
+    def __len__(self):
+        return self.n
+
+
+class _Loaders:
+    def __init__(self, config, device):
+        n = int(config.get("synthetic_batches", 2))
+        self.train_loader = SyntheticLoader(n, config.batch_size, config.patch_size, device, config.seed)
+        self.valid_loader = SyntheticLoader(n, config.get("val_batch_size", 1), config.get("val_patch_size", config.patch_size),
+                                            device, config.seed + 1)
+        self.test_loader = self.valid_loader
+
+
+class LiftingBasedDWTAgent(BaseAgent):
+    def __init__(self, config):
+        super().__init__(config)
+        self.clrch = config.clrch
+        self.lr = config.learning_rate
+        self.model = LiftingBasedDWTNetWrapper(config).to(self.device)
+        self.optimizer = configure_optimizers(self.model, self.lr)
+        self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, factor=0.5, patience=5, threshold=0.0001,
+                                                              threshold_mode="rel", cooldown=0, min_lr=1e-06, eps=1e-08)
+        self.grad_acc_iters = config.grad_acc_iters
+        self.loss_prnt_iters = config.loss_prnt_iters
+        self.data_loader = _Loaders(config, self.device)
+        self.lambda_ = config.lambda_
+        self.loss_switch_thr = config.loss_switch_thr
+        self.training_loss_switch = config.training_loss_switch
+        self.train_loss = TrainDLoss(config.lambda_) if self.training_loss_switch == 0 else TrainRDLoss(config.lambda_)
+        self.valid_loss = TrainRDLoss(config.lambda_)
+        self.train_logger, self.trnit_logger = RDLogger(), RDLogger()
+        self.aux_logger, self.valid_logger, self.test_logger = RDLogger(), RDLogger(), RDLogger()
+        if config.mode in ("test", "validate") and "checkpoint_dir" in config:
+            self.load_checkpoint("model_best.pth.tar")
+        elif config.get("resume_training") and "checkpoint_dir" in config:
+            self.load_checkpoint(config.checkpoint_file)
+
+    def batch_forward(self, x, loss_fn, clamp=False):
+        """x (B,3,H,W) RGB in [0,1] -> (loss, mse, rate1, rate2, xhat)."""
+        if self.clrch != 1:
+            xs = (x - 0.5).contiguous()
+            xhat, si_xe, si_xo = self.model(xs)
+        else:
+            y = ops.rgb_to_ycc(x.contiguous())                                   # :86-87, plane-major
+            yhat, si_xe, si_xo = forward_planes(self.model.nets(), y, self.model.training)
+            xhat = ops.ycc_to_rgb(yhat, clamp=clamp)                             # :90-94 (+ clamp :181)
+            xs = (x - 0.5).contiguous()
+        loss, mse, r1, r2 = loss_fn.forward3(xs, xhat, si_xe, si_xo)
+        return loss, mse, r1, r2, xhat
+
+    def train_one_epoch(self):
+        raise NotImplementedError(
+            "the backward kernels of the HIP path (lifting / conv data- and weight-gradients) are the next row of the "
+            "hot-path scope (DESIGN.md 'What comes next'); round 1 ships the forward / validation path")
+
+    @torch.no_grad()
+    def validate(self):
+        """agents/liftingDWT_agent.py:155-201."""
+        self.model.eval()
+        psnr, r1s, r2s = [], [], []
+        for x in self.data_loader.valid_loader:
+            x = x.to(self.device)
+            loss, mse, r1, r2, _ = self.batch_forward(x, self.valid_loss, clamp=True)
+            self.valid_logger(loss.item(), mse.item(), r1.item(), r2.item())
+            psnr.append(10.0 * torch.log10(1.0 / torch.tensor(mse.item())))
+            r1s.append(r1.item())
+            r2s.append(r2.item())
+        valid_rd_loss, _, _, _ = self.valid_logger.display(lr=0.0, typ="va")
+        m = lambda v: float(torch.tensor(v).mean())
+        print(" avg_psnr = %.2f, rate_1 = %g, rate_2 = %g, total_rate = %g" % (m(psnr), m(r1s), m(r2s), m(r1s) + m(r2s)))
+        return valid_rd_loss
+
+    def test(self):
+        raise NotImplementedError("real entropy coding (rANS, LiftingBasedDWT_net.py:458-556) is outside the hot path "
+                                  "(SURVEY.md 8f.1)")
+
+
+def configure_optimizers(net, lr):
+    """Adam over all trainable parameters sorted by name (agents/liftingDWT_agent.py:369-389)."""
+    params = dict(net.named_parameters())
+    names = sorted(n for n, p in params.items() if p.requires_grad)
+    return optim.Adam([{"params": [params[n] for n in names], "lr": lr}])

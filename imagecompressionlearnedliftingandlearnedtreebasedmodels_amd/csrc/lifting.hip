@@ -471,9 +471,12 @@ static int lifting_args_ok(const char* who, int64_t planes, int64_t batch, int64
 
 extern "C" int lldwt_lifting_forward(const float* x, float* ll, float* const* yh, int64_t planes, int64_t batch,
                                      int64_t H, int64_t W, int levels, const float* taps, const float* packed,
-                                     int different, int C, int K, float res_weight, int linear, const float* scale_nh,
-                                     const float* scale_nl, void* ws, int64_t ws_bytes, void* stream) {
+                                     int nblocks, int block_offset, int different, int C, int K, float res_weight,
+                                     int linear, const float* scale_nh, const float* scale_nl, void* ws,
+                                     int64_t ws_bytes, void* stream) {
     int r = lifting_args_ok("lifting_forward", planes, batch, H, W, levels);
+    LLDWT_REQUIRE(nblocks >= 2 && block_offset >= 0 && block_offset + (different ? 2 * levels : 2) <= nblocks,
+                  "lifting_forward: block_offset=%d (+%d) exceeds nblocks=%d", block_offset, different ? 2 * levels : 2, nblocks);
     if (r) return r;
     LLDWT_REQUIRE(x && ll && yh && taps && packed && ws, "lifting_forward: null pointer");
     const int64_t Z = planes * batch;
@@ -487,13 +490,12 @@ extern "C" int lldwt_lifting_forward(const float* x, float* ll, float* const* yh
     float* tmpL = Hrow + half;
     float* tmpH = tmpL + half;
     float* llbuf[2] = {tmpH + half, tmpH + half + quarter};
-    const int nblocks = different ? 2 * 2 * levels : 2;
     LiftCtx c{Z, batch, taps, planes * 3, packed, (int64_t)nblocks * 2 * pack_off(C, K).total, pack_off(C, K).total, C, K, linear,
               res_weight, llbuf[1] + quarter, (hipStream_t)stream};
     const float* cur = x;
     for (int lev = 0; lev < levels; ++lev) {
         const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2;
-        const int blk = different ? lev * 2 : 0;
+        const int blk = block_offset + (different ? lev * 2 : 0);
         float* X = const_cast<float*>(cur);
         // rows: L = x[0::2], H = x[1::2]  (wavelet_forward_v2.py:27-29)
         lldwt_view A = mkview(X, h * w, 2 * w, 1), B = mkview(X + w, h * w, 2 * w, 1);
@@ -523,9 +525,12 @@ extern "C" int lldwt_lifting_forward(const float* x, float* ll, float* const* yh
 
 extern "C" int lldwt_lifting_inverse(const float* ll, const float* const* yh, float* x, int64_t planes, int64_t batch,
                                      int64_t H, int64_t W, int levels, const float* taps, const float* packed,
-                                     int different, int C, int K, float res_weight, int linear, const float* scale_nh,
-                                     const float* scale_nl, void* ws, int64_t ws_bytes, void* stream) {
+                                     int nblocks, int block_offset, int C, int K, float res_weight, int linear,
+                                     const float* scale_nh, const float* scale_nl, void* ws, int64_t ws_bytes,
+                                     void* stream) {
     int r = lifting_args_ok("lifting_inverse", planes, batch, H, W, levels);
+    LLDWT_REQUIRE(nblocks >= 2 && block_offset >= 0 && block_offset + 2 <= nblocks,
+                  "lifting_inverse: block_offset=%d exceeds nblocks=%d", block_offset, nblocks);
     if (r) return r;
     LLDWT_REQUIRE(x && ll && yh && taps && packed && ws, "lifting_inverse: null pointer");
     const int64_t Z = planes * batch;
@@ -539,10 +544,9 @@ extern "C" int lldwt_lifting_inverse(const float* ll, const float* const* yh, fl
     float* tmpL = Hrow + half;
     float* tmpH = tmpL + half;
     float* llbuf[2] = {tmpH + half, tmpH + half + quarter};
-    const int nblocks = different ? 2 * 2 * levels : 2;
     LiftCtx c{Z, batch, taps, planes * 3, packed, (int64_t)nblocks * 2 * pack_off(C, K).total, pack_off(C, K).total, C, K, linear,
               res_weight, llbuf[1] + quarter, (hipStream_t)stream};
-    const int blk = different ? levels * 2 : 0;   // lifting_dwt_nets.py:718-722: every inverse level starts there
+    const int blk = block_offset;   // lifting_dwt_nets.py:718-722: every inverse level uses the same pair
     const float* cur = ll;
     for (int lev = levels - 1; lev >= 0; --lev) {
         const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2;

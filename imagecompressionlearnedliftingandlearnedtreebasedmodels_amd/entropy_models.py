@@ -1,0 +1,128 @@
+"""Host-side mirrors of the two compressai==1.2.1 entropy models the reference uses (``EntropyBottleneck``,
+``GaussianConditional``; imported at graphs/models/LiftingBasedDWT_net.py:3), running on the HIP rate kernels.
+
+Parameter / buffer names and shapes follow compressai so reference checkpoints load; the CDF tables used
+only by real entropy coding (``_offset``, ``_quantized_cdf``, ``_cdf_length``, ``scale_table``) are kept as empty
+buffers.  The arithmetic (likelihood + both LowerBounds + -log2) is one fused kernel: lldwt_gauss_rate /
+lldwt_factorized_rate (include/lldwt.h).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .utils.bound_ops import LowerBound
+
+EB_ORDER = ("m0", "b0", "f0", "m1", "b1", "f1", "m2", "b2", "f2", "m3", "b3", "f3", "m4", "b4", "median")
+
+
+def pack_entropy_bottleneck(sd):
+    """{'_matrix0'.., '_bias0'.., '_factor0'.., 'quantiles'} of a C-channel EntropyBottleneck -> (C,59) raw values in
+    the order the kernel expects (include/lldwt.h LLDWT_EB_FLOATS)."""
+    C = sd["_matrix0"].shape[0]
+    parts = []
+    for i in range(5):
+        parts.append(sd["_matrix%d" % i].reshape(C, -1))
+        parts.append(sd["_bias%d" % i].reshape(C, -1))
+        if i < 4:
+            parts.append(sd["_factor%d" % i].reshape(C, -1))
+    parts.append(sd["quantiles"][:, :, 1].reshape(C, 1))
+    out = torch.cat(parts, 1).contiguous()
+    assert out.shape[1] == 59
+    return out
+
+
+class _EntropyModelBase(nn.Module):
+    def __init__(self, likelihood_bound=1e-9):
+        super().__init__()
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+        self.likelihood_bound = float(likelihood_bound)
+        self.likelihood_lower_bound = LowerBound(likelihood_bound)     # state_dict: likelihood_lower_bound.bound
+
+    def quantize(self, inputs, mode, means=None):
+        """compressai EntropyModel.quantize: 'noise' -> x + U(-.5,.5); 'dequantize' -> round(x - mu) + mu."""
+        x = inputs.contiguous()
+        if mode == "noise":
+            noise = torch.empty_like(x).uniform_(-0.5, 0.5)
+            return ops.quantize(x, noise)
+        if mode != "dequantize":
+            raise ValueError("only 'noise' / 'dequantize' are on the hot path (mode=%r)" % mode)
+        if means is None:
+            return ops.quantize(x)
+        return ops.quantize((x - means).contiguous()) + means
+
+
+class GaussianConditional(_EntropyModelBase):
+    """compressai.entropy_models.GaussianConditional(scale_table=None, scale_bound=0.11) (LiftingBasedDWT_net.py:291)."""
+
+    def __init__(self, scale_table=None, scale_bound=0.11, tail_mass=1e-9, **kw):
+        super().__init__(**kw)
+        if abs(float(scale_bound) - 0.11) > 1e-12:
+            raise ValueError("the HIP rate kernel is built for scale_bound=0.11 (LiftingBasedDWT_net.py:291,307,318)")
+        self.register_buffer("scale_table", torch.Tensor())
+        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]))
+        self.lower_bound_scale = LowerBound(scale_bound)                # state_dict: lower_bound_scale.bound
+
+    def bits(self, inputs, params, noise=None, want_q=False, bit_sum=None):
+        """Fused path: inputs (P,B,C,h,w), params (P,B,2C,h,w) -> (-log2 likelihood, quantised)."""
+        return ops.gauss_rate(inputs, params, noise, want_q, bit_sum)
+
+    def forward(self, inputs, scales, means=None, training=None):
+        """API-compatible form: -> (outputs, likelihood).  4-D (B,C,h,w) tensors."""
+        training = self.training if training is None else training
+        B, C, h, w = inputs.shape
+        mu = means if means is not None else torch.zeros_like(scales)
+        params = torch.stack((scales, mu), 2).reshape(1, B, 2 * C, h, w).contiguous()
+        noise = torch.empty_like(inputs).uniform_(-0.5, 0.5)[None].contiguous() if training else None
+        bits, q = ops.gauss_rate(inputs[None].contiguous(), params, noise, want_q=True)
+        return q[0], torch.exp2(-bits[0])
+
+
+class EntropyBottleneck(_EntropyModelBase):
+    """compressai.entropy_models.EntropyBottleneck(channels) with the default filters (3,3,3,3), init_scale 10."""
+
+    def __init__(self, channels, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3), **kw):
+        super().__init__(**kw)
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        if self.filters != (3, 3, 3, 3):
+            raise ValueError("the HIP factorized-rate kernel is built for filters (3,3,3,3)")
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        f = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        C = self.channels
+        for i in range(len(self.filters) + 1):
+            init = float(np.log(np.expm1(1 / scale / f[i + 1])))
+            self.register_parameter("_matrix%d" % i, nn.Parameter(torch.full((C, f[i + 1], f[i]), init)))
+            self.register_parameter("_bias%d" % i, nn.Parameter(torch.empty(C, f[i + 1], 1).uniform_(-0.5, 0.5)))
+            if i < len(self.filters):
+                self.register_parameter("_factor%d" % i, nn.Parameter(torch.zeros(C, f[i + 1], 1)))
+        self.quantiles = nn.Parameter(torch.Tensor([-self.init_scale, 0, self.init_scale]).repeat(C, 1, 1))
+        target = float(np.log(2 / self.tail_mass - 1))
+        self.register_buffer("target", torch.Tensor([-target, 0, target]))
+
+    def packed(self):
+        return pack_entropy_bottleneck({k: v.detach() for k, v in self.named_parameters()})
+
+    def forward(self, x, training=None):
+        """-> (outputs, likelihood) for a (B,C,h,w) tensor."""
+        training = self.training if training is None else training
+        xi = x[None].contiguous()
+        noise = torch.empty_like(xi).uniform_(-0.5, 0.5) if training else None
+        bits, q = ops.factorized_rate(xi, self.packed()[None].contiguous(), noise)
+        return q[0], torch.exp2(-bits[0])
+
+    def loss(self):
+        """Auxiliary quantile loss |logits(quantiles) - target| (compressai EntropyBottleneck.loss): a 3-point host-side
+        evaluation per channel, not on the per-batch hot path."""
+        import torch.nn.functional as F
+        logits = self.quantiles
+        for i in range(5):
+            logits = torch.matmul(F.softplus(getattr(self, "_matrix%d" % i).detach()), logits)
+            logits = logits + getattr(self, "_bias%d" % i).detach()
+            if i < 4:
+                logits = logits + torch.tanh(getattr(self, "_factor%d" % i).detach()) * torch.tanh(logits)
+        return torch.abs(logits - self.target).sum()

@@ -1,0 +1,36 @@
+"""MaskedConv2d type A/B (reference graphs/layers/masked_conv2d.py:5-21) on the HIP conv kernels (dead taps skipped)."""
+import torch.nn as nn
+
+from ... import ops
+
+
+class MaskedConv2d(nn.Conv2d):
+    def __init__(self, mask_type, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert mask_type in ("A", "B")
+        self.mask_type = mask_type
+        self.register_buffer("mask", self.weight.data.clone())
+        _, _, kH, kW = self.weight.size()
+        b = 1 if mask_type == "B" else 0
+        self.mask.fill_(1)
+        if kW > 1 or mask_type == "A":
+            self.mask[:, :, kH // 2, kW // 2 + b:] = 0
+        if kH > 1:
+            self.mask[:, :, kH // 2 + 1:] = 0
+
+    def tap_bits(self):
+        """Bit t = ky*K+kx set for live taps (the mask is identical for every (out,in) pair)."""
+        m = self.mask[0, 0].flatten().tolist()
+        return sum(1 << t for t, v in enumerate(m) if v > 0)
+
+    def apply_mask_(self):
+        # the reference mutates weight.data in place on every forward (masked_conv2d.py:20); keep that contract
+        self.weight.data *= self.mask
+
+    def forward(self, x):
+        self.apply_mask_()
+        K = self.kernel_size[0]
+        y = ops.conv2d(x[None].contiguous(), self.weight.detach()[None].contiguous(),
+                       None if self.bias is None else self.bias.detach()[None].contiguous(), K, groups=self.groups,
+                       tap_mask=self.tap_bits())
+        return y[0]

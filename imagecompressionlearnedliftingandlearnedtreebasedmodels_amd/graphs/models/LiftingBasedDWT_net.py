@@ -1,0 +1,305 @@
+"""Model wrapper + entropy layers on the HIP kernels -- mirrors graphs/models/LiftingBasedDWT_net.py of the reference:
+``LiftingBasedDWTNetWrapper`` (:35-99), ``LiftingBasedDWTNet`` (:100-180), ``DWTFactorizedEntropyLayer`` (:182-231),
+``DWTConditioned2EntropyLayerZTsepSubbands`` (:233-372), ``onlyEZWT`` (:759-840).
+
+Same class names, constructor signature (one ``config`` object), dispatch strings, forward signature and state_dict
+layout.  The three per-plane networks of ``clrch == 1`` are executed TOGETHER: every kernel launch covers the three
+planes and the whole batch (plane-major tensors, per-plane weights stacked), instead of three sequential sub-networks.
+
+Real entropy coding (``compress`` / ``test``, :136-152,374-556) is outside the hot path.
+"""
+import torch
+from torch import nn
+
+from ... import ops
+from ...entropy_models import EntropyBottleneck, GaussianConditional
+from ..layers.lifting_dwt_nets import (DWTPytorchWaveletsLayer, LiftingBasedNeuralWaveletv4, _cache, _stack,
+                                       decode_planes, encode_planes)
+from ..layers.masked_conv2d import MaskedConv2d
+
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _conv_params(mods, tag):
+    """Stacked (weight, bias) of the same conv layer of every plane (cached until a parameter changes)."""
+    for m in mods:
+        if isinstance(m, MaskedConv2d):
+            m.apply_mask_()          # reference: weight.data *= mask on every forward (masked_conv2d.py:20)
+    return _cache.get(("conv", id(mods[0]), tag), [p for m in mods for p in (m.weight, m.bias)],
+                      lambda: (_stack(mods, lambda m: m.weight), _stack(mods, lambda m: m.bias)))
+
+
+def _conv(mods, x, act=ops.ACT_NONE, upsample2=False, **kw):
+    m = mods[0]
+    w, b = _conv_params(mods, "w")
+    mask = m.tap_bits() if isinstance(m, MaskedConv2d) else None
+    return ops.conv2d(x, w, b, m.kernel_size[0], groups=m.groups, act=act, upsample2=upsample2, tap_mask=mask, **kw)
+
+
+def _noise(t, training):
+    return torch.empty_like(t).uniform_(-0.5, 0.5) if training else None
+
+
+def _seq_stack(seqs, x, idxs):
+    """Masked-conv stack with LeakyReLU between layers (LiftingBasedDWT_net.py:299-305,311-317)."""
+    t = x
+    for n in idxs:
+        t = _conv([s[n] for s in seqs], t, act=ops.ACT_NONE if n == idxs[-1] else ops.ACT_LRELU)
+    return t
+
+
+def _eb_packed(ebs):
+    return _cache.get(("eb", id(ebs[0])), [p for e in ebs for p in e.parameters()],
+                      lambda: torch.stack([e.packed() for e in ebs], 0).contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ entropy layers
+class _EntropyLayerBase(nn.Module):
+    def _level_channels(self, config):
+        self.num_lifting_layers = config.dwtlevels
+        assert self.num_lifting_layers > 0
+        self.clrch = config.clrch
+        self.se, self.so = 1, 3
+        self.ses = [self.se * self.clrch] * self.num_lifting_layers
+        self.sos = [self.so * self.clrch] * self.num_lifting_layers
+
+    def forward(self, out_xe, out_xo_list):
+        si_xe, si_xo, xe_q, xo_q = self.forward_planes([self], out_xe[None].contiguous(),
+                                                       [t[None].contiguous() for t in out_xo_list], self.training)
+        return si_xe[0], [t[0] for t in si_xo], xe_q[0], [t[0] for t in xo_q]
+
+
+class DWTFactorizedEntropyLayer(_EntropyLayerBase):
+    """Factorized model, one EntropyBottleneck per level (LiftingBasedDWT_net.py:182-231)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self._level_channels(config)
+        self.ent_out_xo_list = nn.ModuleList()
+        self.scl_out_xo_list = nn.ParameterList()     # present in the reference's state_dict, unused in forward (:205-211)
+        self.scb_out_xo_list = nn.ParameterList()
+        for i in range(self.num_lifting_layers):
+            self.ent_out_xo_list.append(EntropyBottleneck(channels=self.sos[i]))
+            self.scl_out_xo_list.append(nn.Parameter(torch.full((1, self.sos[i], 1, 1), i + 1.0)))
+            self.scb_out_xo_list.append(nn.Parameter(torch.full((1, self.sos[i], 1, 1), 1.0)))
+        se = self.ses[-1]
+        self.ent_out_xe = EntropyBottleneck(channels=se)
+        self.scl_out_xe = nn.Parameter(torch.full((1, se, 1, 1), 5.0))
+        self.scb_out_xe = nn.Parameter(torch.full((1, se, 1, 1), 1.0 / 5.0))
+
+    @staticmethod
+    def forward_planes(layers, out_xe, out_xo_list, training):
+        si_xo, q_xo = [], []
+        for i in range(len(out_xo_list)):
+            ebs = [l.ent_out_xo_list[i] for l in layers]
+            bits, q = ops.factorized_rate(out_xo_list[i], _eb_packed(ebs), _noise(out_xo_list[i], training))
+            si_xo.append(bits)
+            q_xo.append(q)
+        bits, q = ops.factorized_rate(out_xe, _eb_packed([l.ent_out_xe for l in layers]), _noise(out_xe, training))
+        return bits, si_xo, q, q_xo
+
+
+def _plc(so):
+    o = so * 81
+    return nn.Conv2d(so, o, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(), nn.Conv2d(o, o, kernel_size=3, stride=1, padding=1)
+
+
+class onlyEZWT(_EntropyLayerBase):
+    """Inter-subband ("zero-tree") model only (LiftingBasedDWT_net.py:759-840)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self._level_channels(config)
+        self.config = config
+        self.plc_list = nn.ModuleList()
+        self.ent_out_xo_list = nn.ModuleList()
+        for i in range(self.num_lifting_layers - 1):
+            a, r, b = _plc(self.sos[i + 1])
+            self.plc_list.append(nn.Sequential(a, r, b, nn.LeakyReLU(), nn.Conv2d(self.sos[i + 1] * 81, 6, kernel_size=1)))
+            self.ent_out_xo_list.append(GaussianConditional(scale_table=None, scale_bound=0.11))
+        self.ent_out_xe = EntropyBottleneck(channels=1)
+        self.ent_out_xo = EntropyBottleneck(channels=3)
+
+    @staticmethod
+    def forward_planes(layers, out_xe, out_xo_list, training):
+        L = len(out_xo_list)
+        si_list, q_list = [], []
+        si_xe, xe_q = ops.factorized_rate(out_xe, _eb_packed([l.ent_out_xe for l in layers]), _noise(out_xe, training))
+        bits, q = ops.factorized_rate(out_xo_list[L - 1], _eb_packed([l.ent_out_xo for l in layers]),
+                                      _noise(out_xo_list[L - 1], training))
+        si_list.append(bits)
+        q_list.append(q)
+        parent = q
+        for i in range(L - 2, -1, -1):
+            seqs = [l.plc_list[i] for l in layers]
+            t = _conv([s[0] for s in seqs], parent, act=ops.ACT_LRELU, upsample2=True)      # :822,835 + :793
+            t = _conv([s[2] for s in seqs], t, act=ops.ACT_LRELU)
+            ms = _conv([s[4] for s in seqs], t)
+            bits, q = ops.gauss_rate(out_xo_list[i], ms, _noise(out_xo_list[i], training), want_q=True)   # :832
+            si_list.append(bits)
+            q_list.append(q)
+            parent = q
+        q_list.reverse()
+        si_list.reverse()
+        return si_xe, si_list, xe_q, q_list
+
+
+class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
+    """Tree (parent level) + causal intra-subband context model (LiftingBasedDWT_net.py:233-372)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self._level_channels(config)
+        self.config = config
+        L = self.num_lifting_layers
+        self.plc_list = nn.ModuleList()
+        self.csc_list = nn.ModuleList()
+        self.cgp_out_xo_list = nn.ModuleList()
+        self.ent_out_xo_list = nn.ModuleList()
+        self.scl_out_xo_list = nn.ParameterList()
+        self.scb_out_xo_list = nn.ParameterList()
+        for i in range(L - 1):
+            inn1 = self.sos[i + 1]
+            self.plc_list.append(nn.Sequential(*_plc(inn1)))
+            inn2 = self.sos[i]
+            self.csc_list.append(MaskedConv2d("A", inn2, inn2 * 81, 5, 1, 2, groups=inn2))
+            inn = inn1 * 81 + inn2 * 81
+            self.cgp_out_xo_list.append(nn.Sequential(
+                nn.Conv2d(inn, inn, 1, groups=inn1), nn.LeakyReLU(inplace=True),
+                nn.Conv2d(inn, inn // 3, 1, groups=inn1), nn.LeakyReLU(inplace=True),
+                nn.Conv2d(inn // 3, inn // 9, 1, groups=inn1), nn.LeakyReLU(inplace=True),
+                nn.Conv2d(inn // 9, self.sos[i] * 2, 1, groups=inn1)))
+            self.ent_out_xo_list.append(GaussianConditional(scale_table=None, scale_bound=0.11))
+
+        def stack(g):
+            o = g * 81
+            spec = [("A", g, o), ("B", o, o), ("B", o, o // 3), ("B", o // 3, o // 9), ("B", o // 9, g * 2)]
+            mods = []
+            for n, (t, a, b) in enumerate(spec):
+                mods.append(MaskedConv2d(t, a, b, 3, 1, 1, groups=g))
+                if n != 4:
+                    mods.append(nn.LeakyReLU(inplace=True))
+            return nn.Sequential(*mods)
+        self.csc_list.append(stack(self.sos[L - 1]))
+        self.ent_out_xo_list.append(GaussianConditional(scale_table=None, scale_bound=0.11))
+        self.csc_xe = stack(self.ses[L - 1])
+        self.ent_out_xe = GaussianConditional(scale_table=None, scale_bound=0.11)
+
+    @staticmethod
+    def forward_planes(layers, out_xe, out_xo_list, training):
+        L = len(out_xo_list)
+        idx5 = (0, 2, 4, 6, 8)
+        # xe: decoder / context see quantize(x) WITHOUT means (:330); the rate uses an independent noise sample (:334)
+        xe_q = ops.quantize(out_xe, _noise(out_xe, training))
+        ms = _seq_stack([l.csc_xe for l in layers], xe_q, idx5)
+        si_xe, _ = ops.gauss_rate(out_xe, ms, _noise(out_xe, training))
+        q_list, si_list = [], []
+        i = L - 1
+        xo_q = ops.quantize(out_xo_list[i], _noise(out_xo_list[i], training))
+        ms = _seq_stack([l.csc_list[i] for l in layers], xo_q, idx5)
+        bits, _ = ops.gauss_rate(out_xo_list[i], ms, _noise(out_xo_list[i], training))
+        si_list.append(bits)
+        q_list.append(xo_q)
+        parent = xo_q
+        for i in range(L - 2, -1, -1):
+            x = out_xo_list[i]
+            P, B, so, h, w = x.shape
+            xo_q = ops.quantize(x, _noise(x, training))
+            # (plc_g, csc_g) interleaved per subband g, written in place by the two producers (:357-359)
+            cat = torch.empty(P, B, 2 * so * 81, h, w, device=x.device, dtype=torch.float32)
+            _conv([l.csc_list[i] for l in layers], xo_q, out=cat, oc_block=81, oc_stride=162, oc_off=81)      # :353
+            seqs = [l.plc_list[i] for l in layers]
+            t = _conv([s[0] for s in seqs], parent, act=ops.ACT_LRELU, upsample2=True)                       # :348,355
+            _conv([s[2] for s in seqs], t, out=cat, oc_block=81, oc_stride=162, oc_off=0)
+            del t
+            cg = [l.cgp_out_xo_list[i] for l in layers]
+            t = cat
+            for n in (0, 2, 4, 6):                                                                           # :360
+                t = _conv([s[n] for s in cg], t, act=ops.ACT_NONE if n == 6 else ops.ACT_LRELU)
+            bits, _ = ops.gauss_rate(x, t, _noise(x, training))                                              # :364
+            si_list.append(bits)
+            q_list.append(xo_q)
+            parent = xo_q
+        q_list.reverse()
+        si_list.reverse()
+        return si_xe, si_list, xe_q, q_list
+
+
+_ENTROPY = {"factorized": DWTFactorizedEntropyLayer, "onlyEZWT": onlyEZWT,
+            "conditioned2ZTsepSubbands": DWTConditioned2EntropyLayerZTsepSubbands}
+_TRANSFORM = {"CDF97": DWTPytorchWaveletsLayer, "LiftingBasedNeuralWaveletv4": LiftingBasedNeuralWaveletv4}
+
+
+# ------------------------------------------------------------------------------------------------ nets
+def forward_planes(nets, x, training):
+    """encode -> entropymodel -> decode for a list of per-plane nets; x (P,B,C,H,W) plane-major.
+    (LiftingBasedDWTNet.forward, LiftingBasedDWT_net.py:154-170)"""
+    out_xe, out_xo = encode_planes([n.autoencoder for n in nets], x)
+    em = [n.entropymodel for n in nets]
+    si_xe, si_xo, xe_q, xo_q = type(em[0]).forward_planes(em, out_xe, out_xo, training)
+    xhat = decode_planes([n.autoencoder for n in nets], xe_q, xo_q)
+    return xhat, si_xe, si_xo
+
+
+def rate_planes(nets, x, training=False):
+    """The metric's path: lifting DWT encode + entropy-model forward (no decode) -> (si_xe, si_xo_list)."""
+    out_xe, out_xo = encode_planes([n.autoencoder for n in nets], x)
+    em = [n.entropymodel for n in nets]
+    si_xe, si_xo, _, _ = type(em[0]).forward_planes(em, out_xe, out_xo, training)
+    return si_xe, si_xo
+
+
+class LiftingBasedDWTNet(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.clrch = config.clrch
+        if config.netType not in _TRANSFORM:
+            raise ValueError("netType %r is not on the hot path (SURVEY.md 2: BasicWavelet/AttentionWavelet* are dead "
+                             "or out of scope); supported: %s" % (config.netType, sorted(_TRANSFORM)))
+        self.autoencoder = _TRANSFORM[config.netType](config)
+        self.entropy_layer = config.entropy_layer
+        if self.entropy_layer not in _ENTROPY:
+            raise ValueError("entropy_layer %r not built yet; supported: %s" % (self.entropy_layer, sorted(_ENTROPY)))
+        self.entropymodel = _ENTROPY[self.entropy_layer](config)
+
+    def forward(self, x):
+        xhat, si_xe, si_xo = forward_planes([self], x[None].contiguous(), self.training)
+        return xhat[0], si_xe[0], [t[0] for t in si_xo]
+
+    def aux_loss(self):
+        return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
+
+
+class LiftingBasedDWTNetWrapper(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.clrch = config.clrch
+        if self.clrch == 3:
+            self.model = LiftingBasedDWTNet(config)
+        elif self.clrch == 1:
+            self.model0 = LiftingBasedDWTNet(config)
+            self.model1 = LiftingBasedDWTNet(config)
+            self.model2 = LiftingBasedDWTNet(config)
+        else:
+            raise ValueError("clrch must be 1 or 3")
+
+    def nets(self):
+        return [self.model] if self.clrch == 3 else [self.model0, self.model1, self.model2]
+
+    def forward_planes(self, x_pm):
+        """Plane-major entry (P,B,C,H,W) -> plane-major (xhat, si_xe, [si_xo]); no layout copies."""
+        return forward_planes(self.nets(), x_pm, self.training)
+
+    def forward(self, x):
+        """(B,3,H,W) -> (xhat (B,3,H,W), si_xe (B,3,h,w), list[3*L] of (B,3,h_i,w_i)), plane-major list order
+        (LiftingBasedDWT_net.py:48-62)."""
+        if self.clrch == 3:
+            return self.model(x)
+        x_pm = x.permute(1, 0, 2, 3).unsqueeze(2).contiguous()          # (3,B,1,H,W)
+        xhat, si_xe, si_xo = self.forward_planes(x_pm)
+        si_list = [t[p] for p in range(3) for t in si_xo]               # extend(): plane 0 levels, plane 1 ..., :58-61
+        return (xhat[:, :, 0].permute(1, 0, 2, 3).contiguous(), si_xe[:, :, 0].permute(1, 0, 2, 3).contiguous(), si_list)
+
+    def aux_loss(self):
+        return sum(n.aux_loss() for n in self.nets())

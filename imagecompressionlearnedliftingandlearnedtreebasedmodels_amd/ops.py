@@ -94,7 +94,7 @@ def _ptr_array(tensors):
 
 
 def lifting_forward(x, taps, packed, levels, Cc, K, res_weight, linear=False, different=False, scale_nh=None,
-                    scale_nl=None):
+                    scale_nl=None, block_offset=0):
     """x: (P,B,1,H,W) -> (ll (P,B,1,H>>L,W>>L), [yh_i (P,B,3,H>>(i+1),W>>(i+1))])  (lifting_dwt_nets.py:728-732)."""
     lib = _lib.load()
     P, B, _, H, W = x.shape
@@ -104,14 +104,14 @@ def lifting_forward(x, taps, packed, levels, Cc, K, res_weight, linear=False, di
     nb = lib.lldwt_lifting_ws_bytes(P * B, H, W, Cc)
     ws = workspace(nb, dev)
     check(lib.lldwt_lifting_forward(_chk(x, "x"), _chk(ll), _ptr_array(yh), P, B, H, W, levels, _chk(taps, "taps"),
-                                    _chk(packed, "packed"), int(bool(different)), Cc, K, float(res_weight),
-                                    int(bool(linear)), _opt(scale_nh), _opt(scale_nl), C.c_void_p(ws.data_ptr()), nb,
-                                    _stream()), "lifting_forward")
+                                    _chk(packed, "packed"), int(packed.shape[1]), int(block_offset),
+                                    int(bool(different)), Cc, K, float(res_weight), int(bool(linear)), _opt(scale_nh),
+                                    _opt(scale_nl), C.c_void_p(ws.data_ptr()), nb, _stream()), "lifting_forward")
     return ll, yh
 
 
-def lifting_inverse(ll, yh, taps, packed, Cc, K, res_weight, linear=False, different=False, scale_nh=None,
-                    scale_nl=None):
+def lifting_inverse(ll, yh, taps, packed, Cc, K, res_weight, linear=False, scale_nh=None, scale_nl=None,
+                    block_offset=0):
     lib = _lib.load()
     levels = len(yh)
     P, B, _, hl, wl = ll.shape
@@ -123,9 +123,9 @@ def lifting_inverse(ll, yh, taps, packed, Cc, K, res_weight, linear=False, diffe
     nb = lib.lldwt_lifting_ws_bytes(P * B, H, W, Cc)
     ws = workspace(nb, dev)
     check(lib.lldwt_lifting_inverse(_chk(ll, "ll"), _ptr_array(yh), _chk(x), P, B, H, W, levels, _chk(taps, "taps"),
-                                    _chk(packed, "packed"), int(bool(different)), Cc, K, float(res_weight),
-                                    int(bool(linear)), _opt(scale_nh), _opt(scale_nl), C.c_void_p(ws.data_ptr()), nb,
-                                    _stream()), "lifting_inverse")
+                                    _chk(packed, "packed"), int(packed.shape[1]), int(block_offset), Cc, K,
+                                    float(res_weight), int(bool(linear)), _opt(scale_nh), _opt(scale_nl),
+                                    C.c_void_p(ws.data_ptr()), nb, _stream()), "lifting_inverse")
     return x
 
 

@@ -87,19 +87,23 @@ int lldwt_lift_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, int64
 /* Whole multi-level transform of LiftingBasedNeuralWaveletv4.encode (lifting_dwt_nets.py:728-732), all planes
  * and images in one call.  x: (Z,1,H,W) plane-major; ll: (Z,1,H>>L,W>>L); yh[i]: (Z,3,H>>(i+1),W>>(i+1)) with
  * channels (LH,HL,HH), finest first (the layout of out_xo_list before the subband auto-encoder, :739-740).
- * taps: (4,planes,3) = preProcessingList.{j}.weight of every plane, j-major; packed: (planes, nblocks, 2 (P,U), packed_floats) -- nblocks = 2 for
- * block_property=="same", 2*2*levels for "different" (lifting_dwt_nets.py:688-722).
+ * taps: (4,planes,3) = preProcessingList.{j}.weight of every plane, j-major.
+ * packed: (planes, nblocks, 2 (P,U), packed_floats); nblocks = 2 for block_property=="same", 2*2*levels for
+ * "different" (lifting_dwt_nets.py:688-722).  Level `lev` of the forward uses block pairs
+ * block_offset + (different ? 2*lev : 0) + {0,1}; EVERY level of the inverse uses block_offset + {0,1}
+ * (lifting_dwt_nets.py:718-722 slices the inverse blocks from waveletLevel*liftingLevel for every level, so the
+ * caller passes block_offset = 2*levels there when block_property=="different").
  * scale_nh/scale_nl: device (planes) floats = lifting_coeff[4/5] + n*0.1 when config.scale==1, else NULL.  */
 int64_t lldwt_lifting_ws_bytes(int64_t Z, int64_t H, int64_t W, int C);
 int lldwt_lifting_forward(const float* x, float* ll, float* const* yh, int64_t planes, int64_t batch, int64_t H,
-                          int64_t W, int levels, const float* taps, const float* packed, int different, int C,
-                          int K, float res_weight, int linear, const float* scale_nh, const float* scale_nl,
-                          void* ws, int64_t ws_bytes, void* stream);
+                          int64_t W, int levels, const float* taps, const float* packed, int nblocks,
+                          int block_offset, int different, int C, int K, float res_weight, int linear,
+                          const float* scale_nh, const float* scale_nl, void* ws, int64_t ws_bytes, void* stream);
 /* Inverse (LiftingBasedNeuralWaveletv4.decode, lifting_dwt_nets.py:762-781; wavelet_inverse_v2.py:20-92).  */
 int lldwt_lifting_inverse(const float* ll, const float* const* yh, float* x, int64_t planes, int64_t batch,
-                          int64_t H, int64_t W, int levels, const float* taps, const float* packed, int different,
-                          int C, int K, float res_weight, int linear, const float* scale_nh, const float* scale_nl,
-                          void* ws, int64_t ws_bytes, void* stream);
+                          int64_t H, int64_t W, int levels, const float* taps, const float* packed, int nblocks,
+                          int block_offset, int C, int K, float res_weight, int linear, const float* scale_nh,
+                          const float* scale_nl, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * SubbandAutoEncoder (lifting_dwt_nets.py:99-110): per-coefficient scalar MLP 1 -> Hd -> Hd -> Hd -> 1, tanh

@@ -98,7 +98,7 @@ def test_lifting_vs_reference_golden(name):
         assert maxdiff(yh[i][0].cpu(), oYh[i][:, 0]) < TOL
     if L == 1:
         assert maxdiff(ll[0].cpu(), g["LL"]) < TOL
-    xr = ops.lifting_inverse(ll, yh, taps, packed, 16, K, 0.1, linear, different, nh, nl)
+    xr = ops.lifting_inverse(ll, yh, taps, packed, 16, K, 0.1, linear, nh, nl, block_offset=2 * L if different else 0)
     oxr = lifting.lifting_inverse(oLL, oYh, sd, cfg)
     assert maxdiff(xr[0].cpu(), oxr) < TOL
     if not different:       # perfect reconstruction
