@@ -48,7 +48,9 @@ SIGNATURES = {
     "lldwt_lifting_inverse": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _i, _f, _i,
                                    _p, _p, _p, _i64, _p]),
     "lldwt_subband_mlp": (_i, [_p, _p, _i64, _i64, _i, _i64, _i] + [_p] * 8 + [_i, _p]),
-    "lldwt_conv2d": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
+    "lldwt_conv_packed_floats": (_i64, [C.POINTER(ConvDesc)]),
+    "lldwt_conv_pack": (_i, [_p, _p, C.POINTER(ConvDesc), _i64, _p]),
+    "lldwt_conv2d": (_i, [_p, _p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_direct": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
     "lldwt_gdn": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i64, _i, _f, _p]),
     "lldwt_lower_bound_fwd": (_i, [_p, _p, _i64, _f, _p]),

@@ -510,7 +510,3 @@ extern "C" int lldwt_sum(const float* x, int64_t n, double* out, void* stream) {
     return check_launch("sum");
 }
 
-extern "C" int lldwt_conv2d(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
-                            int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream) {
-    return lldwt_conv2d_direct(x, y, w, bias, d, planes, batch, h, w_, stream);
-}

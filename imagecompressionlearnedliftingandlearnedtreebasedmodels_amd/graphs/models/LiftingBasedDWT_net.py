@@ -26,15 +26,20 @@ def _conv_params(mods, tag):
     for m in mods:
         if isinstance(m, MaskedConv2d):
             m.apply_mask_()          # reference: weight.data *= mask on every forward (masked_conv2d.py:20)
-    return _cache.get(("conv", id(mods[0]), tag), [p for m in mods for p in (m.weight, m.bias)],
-                      lambda: (_stack(mods, lambda m: m.weight), _stack(mods, lambda m: m.bias)))
+    m0 = mods[0]
+    mask = m0.tap_bits() if isinstance(m0, MaskedConv2d) else None
+
+    def build():
+        w = _stack(mods, lambda m: m.weight)
+        return w, _stack(mods, lambda m: m.bias), ops.conv_pack(w, m0.kernel_size[0], m0.groups, tap_mask=mask), mask
+    return _cache.get(("conv", id(m0), tag), [p for m in mods for p in (m.weight, m.bias)], build)
 
 
 def _conv(mods, x, act=ops.ACT_NONE, upsample2=False, **kw):
     m = mods[0]
-    w, b = _conv_params(mods, "w")
-    mask = m.tap_bits() if isinstance(m, MaskedConv2d) else None
-    return ops.conv2d(x, w, b, m.kernel_size[0], groups=m.groups, act=act, upsample2=upsample2, tap_mask=mask, **kw)
+    w, b, packed, mask = _conv_params(mods, "w")
+    return ops.conv2d(x, w, b, m.kernel_size[0], groups=m.groups, act=act, upsample2=upsample2, tap_mask=mask,
+                      packed=packed, **kw)
 
 
 def _noise(t, training):

@@ -170,23 +170,47 @@ def subband_mlp(x, w0, b0, w1, b1, w2, b2, w3, b3, transposed=False, hidden=32):
     return y
 
 
+def conv_desc(cin, cout, K, groups=1, act=ACT_NONE, upsample2=False, transposed=False, tap_mask=None, oc_block=None,
+              oc_stride=0, oc_off=0, ytot=None):
+    return ConvDesc(cin, cout, K, groups, act, int(bool(upsample2)), int(bool(transposed)),
+                    (1 << (K * K)) - 1 if tap_mask is None else int(tap_mask), cout if oc_block is None else oc_block,
+                    oc_stride, oc_off, cout if ytot is None else ytot)
+
+
+def conv_pack(w, K, groups=1, transposed=False, tap_mask=None):
+    """(P,cout,cin/groups,K,K) (transposed: (P,cin,cout,K,K)) -> packed (P, floats) in MFMA A-operand order."""
+    lib = _lib.load()
+    P = w.shape[0]
+    cout = w.shape[2] if transposed else w.shape[1]
+    cin = w.shape[1] if transposed else w.shape[2] * groups
+    d = conv_desc(cin, cout, K, groups, transposed=transposed, tap_mask=tap_mask)
+    n = lib.lldwt_conv_packed_floats(C.byref(d))
+    packed = torch.empty(P, n, device=w.device, dtype=torch.float32)
+    check(lib.lldwt_conv_pack(_chk(w, "w"), _chk(packed), C.byref(d), P, _stream()), "conv_pack")
+    return packed
+
+
 def conv2d(x, w, bias, K, groups=1, act=ACT_NONE, upsample2=False, transposed=False, tap_mask=None, out=None,
-           oc_block=None, oc_stride=0, oc_off=0, direct=False):
+           oc_block=None, oc_stride=0, oc_off=0, direct=False, packed=None, residual=None):
     """General conv layer (include/lldwt.h lldwt_conv2d).  x: (P,B,cin,h,w); w: (P,cout,cin/groups,K,K)
-    (transposed: (P,cin,cout,K,K)).  ``out``: optional pre-allocated (P,B,ytot,h,w) tensor for channel placement."""
+    (transposed: (P,cin,cout,K,K)).  ``out``: optional pre-allocated (P,B,ytot,h,w) tensor for channel placement.
+    ``packed``: result of conv_pack(w, ...) to skip re-packing; ``direct``: reference-order VALU kernel."""
     lib = _lib.load()
     P, B, cin, hi, wi = x.shape
     cout = w.shape[2] if transposed else w.shape[1]
     h, wd = (hi * 2, wi * 2) if upsample2 else (hi, wi)
     if out is None:
         out = torch.empty(P, B, cout, h, wd, device=x.device, dtype=torch.float32)
-    ytot = out.shape[2]
-    d = ConvDesc(cin, cout, K, groups, act, int(bool(upsample2)), int(bool(transposed)),
-                 (1 << (K * K)) - 1 if tap_mask is None else int(tap_mask),
-                 cout if oc_block is None else oc_block, oc_stride, oc_off, ytot)
-    fn = lib.lldwt_conv2d_direct if direct else lib.lldwt_conv2d
-    check(fn(_chk(x, "x"), _chk(out, "out"), _chk(w, "w"), _opt(bias, "bias"), C.byref(d), P, B, h, wd, _stream()),
-          "conv2d")
+    d = conv_desc(cin, cout, K, groups, act, upsample2, transposed, tap_mask, oc_block, oc_stride, oc_off, out.shape[2])
+    if direct:
+        assert residual is None
+        check(lib.lldwt_conv2d_direct(_chk(x, "x"), _chk(out, "out"), _chk(w, "w"), _opt(bias, "bias"), C.byref(d), P, B,
+                                      h, wd, _stream()), "conv2d_direct")
+        return out
+    if packed is None:
+        packed = conv_pack(w, K, groups, transposed, tap_mask)
+    check(lib.lldwt_conv2d(_chk(x, "x"), _chk(out, "out"), _chk(packed, "packed"), _opt(bias, "bias"),
+                           _opt(residual, "residual"), C.byref(d), P, B, h, wd, _stream()), "conv2d")
     return out
 
 

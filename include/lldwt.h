@@ -134,9 +134,14 @@ typedef struct lldwt_conv_desc {
     uint32_t tap_mask;
     int oc_block, oc_stride, oc_off, ytot;
 } lldwt_conv_desc;
-int lldwt_conv2d(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
-                 int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
-/* Same contract, always the reference-order direct kernel (VALU); used to cross-check the MFMA engine on the GPU. */
+/* Weights are pre-packed once per update into the MFMA A-operand lane order (csrc/conv_mfma.hip):
+ * packed holds lldwt_conv_packed_floats(d) floats PER PLANE.  residual (optional): tensor laid out like y, added before
+ * the activation (P_block_v2.py:53 "tmp + out_res").                                                       */
+int64_t lldwt_conv_packed_floats(const lldwt_conv_desc* d);
+int lldwt_conv_pack(const float* w, float* packed, const lldwt_conv_desc* d, int64_t planes, void* stream);
+int lldwt_conv2d(const float* x, float* y, const float* packed, const float* bias, const float* residual,
+                 const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+/* Same maths from the raw PyTorch-layout weights w, reference-order direct kernel (VALU); cross-checks the MFMA engine. */
 int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
                         int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
 

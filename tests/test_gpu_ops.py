@@ -54,12 +54,19 @@ CONV_CASES = [
     (486, 162, 1, 3, 2, False, False, None),   # cgp 1x1 grouped
     (18, 6, 1, 3, 0, False, False, None),
     (12, 20, 3, 1, 0, False, True, None),      # ConvTranspose2d (Berk decoder)
-    (16, 16, 5, 1, 1, False, False, None),     # tanh
+    (16, 16, 5, 1, 1, False, False, None),     # tanh (lifting P-block conv2)
+    (243, 243, 3, 1, 0, False, False, None),   # plc second conv: the dominant layer
+    (3, 6, 3, 3, 0, False, False, "A"),        # tiny grouped masked (cout/groups = 2)
+    (27, 9, 3, 1, 2, False, False, "B"),       # csc_xe tail
+    (96, 192, 3, 1, 0, False, False, None),    # Berk auto-encoder middle layer
+    (1, 32, 1, 1, 1, False, False, None),      # cin = 1, 1x1
 ]
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_direct(case):
+def test_conv2d(case, direct):
+    """direct=False: the MFMA implicit-GEMM engine; direct=True: the reference-order VALU kernel."""
     ops, gu = _ops()
     cin, cout, K, groups, act, up, tr, mt = case
     P, B, h, w = 2, 2, 10, 14
@@ -76,7 +83,7 @@ def test_conv2d_direct(case):
         wt = wt * m
         mask_bits = int(sum(1 << t for t in range(K * K) if m[0, 0].flatten()[t] > 0))
     y = ops.conv2d(gu.dev(x), gu.dev(wt), gu.dev(bias), K, groups=groups, act=act, upsample2=up, transposed=tr,
-                   tap_mask=mask_bits, direct=True)
+                   tap_mask=mask_bits, direct=direct)
     for p in range(P):
         xi = entropy.upsample2(x[p]) if up else x[p]
         if tr:
@@ -96,14 +103,32 @@ def test_conv2d_channel_placement():
     wa = torch.rand(P, 243, 3, 3, 3, generator=g) - 0.5
     wb = (torch.rand(P, 243, 1, 5, 5, generator=g) - 0.5) * entropy.conv_mask((243, 1, 5, 5), "A")
     out = torch.zeros(P, B, 486, h, w, device=gu.DEV)
-    ops.conv2d(gu.dev(xa), gu.dev(wa), None, 3, out=out, oc_block=81, oc_stride=162, oc_off=0, direct=True)
-    ops.conv2d(gu.dev(xa), gu.dev(wb), None, 5, groups=3, out=out, oc_block=81, oc_stride=162, oc_off=81, direct=True)
+    ops.conv2d(gu.dev(xa), gu.dev(wa), None, 3, out=out, oc_block=81, oc_stride=162, oc_off=0)
+    ops.conv2d(gu.dev(xa), gu.dev(wb), None, 5, groups=3, out=out, oc_block=81, oc_stride=162, oc_off=81,
+               tap_mask=sum(1 << t for t in range(12)))
     plc = F.conv2d(xa[0], wa[0], None, padding=1)
     csc = F.conv2d(xa[0], wb[0], None, padding=2, groups=3)
     p0, p1, p2 = plc.chunk(3, 1)
     c0, c1, c2 = csc.chunk(3, 1)
     ref = torch.cat((p0, c0, p1, c1, p2, c2), 1)
     assert maxdiff(out[0].cpu(), ref) < 2e-5
+
+
+def test_conv2d_mfma_ragged_and_residual():
+    """Image sizes that are not multiples of any tile, plus the residual epilogue (P_block_v2.py:53)."""
+    ops, gu = _ops()
+    g = torch.Generator().manual_seed(11)
+    for (cin, cout, K, h, w) in [(16, 16, 5, 37, 53), (243, 243, 3, 9, 19), (20, 100, 1, 5, 70)]:
+        x = torch.rand(1, 2, cin, h, w, generator=g) - 0.5
+        wt = (torch.rand(1, cout, cin, K, K, generator=g) - 0.5) * 0.2
+        b = torch.rand(1, cout, generator=g) - 0.5
+        res = torch.rand(1, 2, cout, h, w, generator=g) - 0.5
+        y = ops.conv2d(gu.dev(x), gu.dev(wt), gu.dev(b), K, act=1, residual=gu.dev(res))
+        ref = torch.tanh(F.conv2d(x[0], wt[0], b[0], padding=K // 2) + res[0])
+        assert maxdiff(y[0].cpu(), ref) < 2e-5, (cin, cout, K)
+        yd = ops.conv2d(gu.dev(x), gu.dev(wt), gu.dev(b), K, direct=True)
+        ym = ops.conv2d(gu.dev(x), gu.dev(wt), gu.dev(b), K)
+        assert maxdiff(yd, ym) < 2e-5
 
 
 def test_gdn_and_bound_ops():
