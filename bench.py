@@ -42,7 +42,8 @@ def cpu_baseline(sd, cfg, size, seconds_budget=25.0):
     """Oracle (CPU port of the reference path) on a bounded sample of the same workload: 1 x 3 x size x size."""
     from oracle import model as omodel
     from oracle.entropy import ENTROPY_LAYERS
-    torch.set_num_threads(os.cpu_count())
+    cores = min(16, len(os.sched_getaffinity(0)))     # the GPU box grants a 16-core share per GPU
+    torch.set_num_threads(cores)
     x = torch.rand(1, 3, size, size, generator=torch.Generator().manual_seed(1337))
 
     def run():
@@ -64,8 +65,15 @@ def cpu_baseline(sd, cfg, size, seconds_budget=25.0):
             if time.perf_counter() - t0 > seconds_budget / 2 or n >= 5:
                 break
         dt = (time.perf_counter() - t0) / n
-    return {"value": size * size / dt / 1e6, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": size * size / dt / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": "oracle (torch-CPU restatement of the reference path), 1x3x%dx%d, %d timed runs after 1 warm-up" % (size, size, n)}
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
 
 
 def main():
@@ -91,7 +99,9 @@ def main():
 
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import rate_planes
+    log("building model")
     net, sd, cfg = build_model(a.levels, dev)
+    log("model ready")
     nets = net.nets()
     x = torch.rand(a.batch, 3, a.size, a.size, device=dev, generator=torch.Generator(device=dev).manual_seed(1337 + rank))
     bit_acc = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -125,9 +135,10 @@ def main():
             for t in si_xo:
                 ops.sum_into(t, bit_acc)
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         step()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        log("warmup %d done" % i)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -141,6 +152,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dom["on"] = False
+    log("timed region done: %.3f s for %d steps" % (dt, a.steps))
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
