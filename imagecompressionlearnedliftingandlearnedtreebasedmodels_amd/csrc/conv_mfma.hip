@@ -53,7 +53,7 @@ static inline ConvPlan make_plan(const lldwt_conv_desc& d) {
     }
     p.cfg = best;
     p.oct = kOct[best];
-    p.ck = d.K == 1 ? 32 : 8;
+    p.ck = d.K == 1 ? 32 : (cin_g <= 4 ? 4 : 8);   // must match the dispatch in lldwt_conv2d
     p.ntaps = popc(d.tap_mask & ((1u << (d.K * d.K)) - 1u));
     p.nchunk = (int)cdiv(cin_g, p.ck);
     p.nocb = (int)cdiv(cout_g, p.oct * 16);
@@ -118,9 +118,13 @@ struct Geo {
     static constexpr int PS = ((IH * IW + 15) / 32) * 32 + 16;     // plane stride, == 16 mod 32, >= IH*IW
     static constexpr int S = CK / 4;
     static constexpr int IN_FLOATS = CK * PS;
+    static constexpr int NIN = (CK * IH * IW + NT - 1) / NT;             // input floats staged per thread
+    static constexpr int NWV = (KS * KS * S * OCT * 16 + NT - 1) / NT;   // weight float4s staged per thread (dense)
 };
 
-template <int KS, int WM, int WN, int WVM, int WVN, int TWS, int CK>
+// Software-pipelined main loop (guide T14, "issue early / write late"): the global loads of chunk c+1 are issued into
+// registers before the MFMAs of chunk c and written to LDS after them, so HBM/L2 latency hides under the matrix work.
+template <int KS, int WM, int WN, int WVM, int WVN, int TWS, int CK, bool DENSE>
 __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     using G = Geo<KS, WM, WN, WVM, WVN, TWS, CK>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     const float* xg = a.x + (z * d.cin + (int64_t)g * cin_g) * hwi;
     const float* pk = a.packed + (int64_t)plane * a.p.plane_floats +
                       ((int64_t)(g * a.p.nocb + ocb) * a.p.nchunk) * a.p.chunk_floats;
-    const int ntaps = a.p.ntaps;
-    const int wfloats = (int)a.p.chunk_floats;
+    const int wvec = (int)(a.p.chunk_floats / 4);
+    const uint32_t mask = d.tap_mask;
 
     floatx4 acc[WM][WN];
 #pragma unroll
@@ -151,40 +155,67 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < WN; ++n) acc[m][n] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane LDS bases
+    // per-thread staging coordinates (chunk independent)
+    int in_off[G::NIN];      // global offset inside a channel plane, or -1 (zero padding / outside the tile list)
+    int in_lds[G::NIN];      // LDS offset, or -1
+    int in_c[G::NIN];
+#pragma unroll
+    for (int r = 0; r < G::NIN; ++r) {
+        const int i = tid + r * G::NT;
+        const int c = i / (G::IH * G::IW);
+        const int rem = i - c * (G::IH * G::IW);
+        const int ly = rem / G::IW, lx = rem - ly * G::IW;
+        const int gy = y0 - G::R + ly, gx = x0 - G::R + lx;
+        const bool live = i < CK * G::IH * G::IW;
+        const bool inimg = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const int sy = d.upsample2 ? gy >> 1 : gy, sx = d.upsample2 ? gx >> 1 : gx;
+        in_c[r] = c;
+        in_lds[r] = live ? c * G::PS + ly * G::IW + lx : -1;
+        in_off[r] = (live && inimg) ? sy * wi + sx : -1;
+    }
+    float xin[G::NIN];
+    float4 wv[G::NWV];
+
+    // (macros, not lambdas: by-reference captures of the register arrays end up in scratch)
+#define LLDWT_STAGE_LOAD(CHUNK)                                                                             \
+    {                                                                                                       \
+        _Pragma("unroll") for (int r = 0; r < G::NIN; ++r) {                                                \
+            const int ic = (CHUNK) * CK + in_c[r];                                                          \
+            xin[r] = (in_off[r] >= 0 && ic < cin_g) ? xg[ic * hwi + in_off[r]] : 0.f;                       \
+        }                                                                                                   \
+        const float4* src = reinterpret_cast<const float4*>(pk + (int64_t)(CHUNK) * a.p.chunk_floats);     \
+        _Pragma("unroll") for (int r = 0; r < G::NWV; ++r) {                                                \
+            const int i = tid + r * G::NT;                                                                  \
+            wv[r] = (i < wvec) ? src[i] : float4{0.f, 0.f, 0.f, 0.f};                                       \
+        }                                                                                                   \
+    }
+#define LLDWT_STAGE_STORE()                                                                                 \
+    {                                                                                                       \
+        _Pragma("unroll") for (int r = 0; r < G::NIN; ++r)                                                  \
+            if (in_lds[r] >= 0) lin[in_lds[r]] = xin[r];                                                    \
+        float4* dst = reinterpret_cast<float4*>(lw);                                                        \
+        _Pragma("unroll") for (int r = 0; r < G::NWV; ++r) {                                                \
+            const int i = tid + r * G::NT;                                                                  \
+            if (i < wvec) dst[i] = wv[r];                                                                   \
+        }                                                                                                   \
+    }
+
     const float* bbase = lin + kk * G::PS + px;                         // + (4s)*PS + row/seg/tap offsets
     const float* abase = lw + (wm * WM) * 64 + lane;                    // + ((tl*S+s)*OCT + m)*64
 
+    LLDWT_STAGE_LOAD(0)
     for (int chunk = 0; chunk < a.p.nchunk; ++chunk) {
+        __syncthreads();          // all waves are done reading the previous chunk
+        LLDWT_STAGE_STORE()
         __syncthreads();
-        // ---- stage the input patch: CK channels x IH x IW, zero outside the image / beyond cin_g
-        for (int i = tid; i < CK * G::IH * G::IW; i += G::NT) {
-            const int c = i / (G::IH * G::IW);
-            const int rem = i - c * (G::IH * G::IW);
-            const int ly = rem / G::IW, lx = rem - ly * G::IW;
-            const int gy = y0 - G::R + ly, gx = x0 - G::R + lx;
-            const int ic = chunk * CK + c;
-            float v = 0.f;
-            if (ic < cin_g && gy >= 0 && gy < h && gx >= 0 && gx < w) {
-                const int sy = d.upsample2 ? gy >> 1 : gy, sx = d.upsample2 ? gx >> 1 : gx;
-                v = xg[ic * hwi + (int64_t)sy * wi + sx];
-            }
-            lin[c * G::PS + ly * G::IW + lx] = v;
-        }
-        // ---- stage the weight slab (already in lane order): straight 16-byte copies
-        {
-            const float4* src = reinterpret_cast<const float4*>(pk + (int64_t)chunk * wfloats);
-            float4* dst = reinterpret_cast<float4*>(lw);
-            for (int i = tid; i < wfloats / 4; i += G::NT) dst[i] = src[i];
-        }
-        __syncthreads();
+        if (chunk + 1 < a.p.nchunk) LLDWT_STAGE_LOAD(chunk + 1)
         int tl = 0;
 #pragma unroll
         for (int t = 0; t < KS * KS; ++t) {
-            if (!((d.tap_mask >> t) & 1u)) continue;
+            if (!DENSE && !((mask >> t) & 1u)) continue;
             const int dy = t / KS, dx = t % KS;
             const float* bt = bbase + dy * G::IW + dx;
-            const float* at = abase + (tl * G::S) * G::OCT * 64;
+            const float* at = abase + ((DENSE ? t : tl) * G::S) * G::OCT * 64;
 #pragma unroll
             for (int s = 0; s < G::S; ++s) {
                 float A[WM], B[WN];
@@ -205,7 +236,8 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
             ++tl;
         }
     }
-    (void)ntaps;
+#undef LLDWT_STAGE_LOAD
+#undef LLDWT_STAGE_STORE
     // ---- epilogue: bias, residual, activation, channel placement
     const int64_t hw = (int64_t)h * w;
 #pragma unroll
@@ -233,14 +265,14 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     }
 }
 
-template <int KS, int WM, int WN, int WVM, int WVN, int TWS, int CK>
+template <int KS, int WM, int WN, int WVM, int WVN, int TWS, int CK, bool DENSE>
 static int launch_cfg(const ConvArgs& a0, int64_t Z, hipStream_t st) {
     using G = Geo<KS, WM, WN, WVM, WVN, TWS, CK>;
     ConvArgs a = a0;
     a.tiles_x = (int)cdiv(a.w, G::TW);
     const int tiles_y = (int)cdiv(a.h, G::TH);
     const size_t shmem = sizeof(float) * (G::IN_FLOATS + (size_t)a.p.chunk_floats);
-    auto kern = k_conv_mfma<KS, WM, WN, WVM, WVN, TWS, CK>;
+    auto kern = k_conv_mfma<KS, WM, WN, WVM, WVN, TWS, CK, DENSE>;
     if (shmem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
             set_error("conv2d: cannot reserve %zu bytes of LDS", shmem);
@@ -252,14 +284,14 @@ static int launch_cfg(const ConvArgs& a0, int64_t Z, hipStream_t st) {
     return check_launch("conv2d(mfma)");
 }
 
-template <int KS, int CK>
+template <int KS, int CK, bool DENSE>
 static int launch_ks(const ConvArgs& a, int64_t Z, hipStream_t st) {
     switch (a.p.cfg) {
-        case 0: return launch_cfg<KS, 1, 8, 1, 4, 2, CK>(a, Z, st);
-        case 1: return launch_cfg<KS, 2, 4, 1, 4, 2, CK>(a, Z, st);
-        case 2: return launch_cfg<KS, 4, 4, 1, 4, 2, CK>(a, Z, st);
-        case 3: return launch_cfg<KS, 3, 4, 2, 2, 1, CK>(a, Z, st);
-        default: return launch_cfg<KS, 4, 4, 2, 2, 1, CK>(a, Z, st);
+        case 0: return launch_cfg<KS, 1, 8, 1, 4, 2, CK, DENSE>(a, Z, st);
+        case 1: return launch_cfg<KS, 2, 4, 1, 4, 2, CK, DENSE>(a, Z, st);
+        case 2: return launch_cfg<KS, 4, 4, 1, 4, 2, CK, DENSE>(a, Z, st);
+        case 3: return launch_cfg<KS, 3, 4, 2, 2, 1, CK, DENSE>(a, Z, st);
+        default: return launch_cfg<KS, 4, 4, 2, 2, 1, CK, DENSE>(a, Z, st);
     }
 }
 
@@ -309,7 +341,12 @@ extern "C" int lldwt_conv2d(const float* x, float* y, const float* packed, const
     a.batch = (int)batch; a.h = (int)h; a.w = (int)w_; a.tiles_x = 0;
     const int64_t Z = planes * batch;
     hipStream_t st = (hipStream_t)stream;
-    if (d->K == 1) return launch_ks<1, 32>(a, Z, st);
-    if (d->K == 3) return launch_ks<3, 8>(a, Z, st);
-    return launch_ks<5, 8>(a, Z, st);
+    const bool dense = a.p.ntaps == d->K * d->K;
+    if (d->K == 1) return launch_ks<1, 32, true>(a, Z, st);
+    if (d->K == 3) {
+        if (a.p.ck == 4) return dense ? launch_ks<3, 4, true>(a, Z, st) : launch_ks<3, 4, false>(a, Z, st);
+        return dense ? launch_ks<3, 8, true>(a, Z, st) : launch_ks<3, 8, false>(a, Z, st);
+    }
+    if (a.p.ck == 4) return dense ? launch_ks<5, 4, true>(a, Z, st) : launch_ks<5, 4, false>(a, Z, st);
+    return dense ? launch_ks<5, 8, true>(a, Z, st) : launch_ks<5, 8, false>(a, Z, st);
 }
