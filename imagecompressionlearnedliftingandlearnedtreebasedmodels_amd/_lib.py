@@ -58,6 +58,9 @@ SIGNATURES = {
     "lldwt_nonneg_param_fwd": (_i, [_p, _p, _i64, _f, _p]),
     "lldwt_nonneg_param_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
     "lldwt_gauss_rate": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i64, _p]),
+    "lldwt_cgp_packed_floats": (_i64, [_i, _i, _i, _i, _i]),
+    "lldwt_cgp_pack": (_i, [_p] * 9 + [_i64, _i, _i, _i, _i, _i, _p]),
+    "lldwt_cgp_rate": (_i, [_p] * 7 + [_i64, _i64, _i64, _i, _i, _i, _i, _i, _p]),
     "lldwt_quantize": (_i, [_p, _p, _p, _i64, _p]),
     "lldwt_factorized_rate": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
     "lldwt_sq_err_sum": (_i, [_p, _p, _i64, _p, _p]),

@@ -1,0 +1,316 @@
+// cgp_fused.hip -- the "cgp" parameter network of DWTConditioned2EntropyLayerZTsepSubbands fused with the Gaussian rate.
+//
+// Reference (LiftingBasedDWT_net.py:282-289,357-365): per subband g the concatenated contexts (plc_g, csc_g) go through
+// grouped 1x1 convs C0 -> C1 -> C2 -> C3 -> 2 (162 -> 162 -> 54 -> 18 -> 2) with LeakyReLU between, the two outputs are
+// (sigma, mu) of the conditional Gaussian whose likelihood gives the bits of the coefficient.  Unfused this moves
+// ~6 KB per pixel through HBM for 36 kMAC; here one workgroup keeps a 64-pixel column of activations in LDS, runs the
+// four layers on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) and writes only the bits (4 B / coefficient).
+//   * waves split OUTPUT CHANNELS: each wave streams the A operands (weights, pre-packed in lane order) of its own
+//     16-channel tiles straight from L2 -- no LDS staging of weights, no duplication across waves;
+//   * all waves share the B operand (activations) in one LDS buffer, overwritten IN PLACE after each layer (the
+//     accumulators stay in registers until every wave has finished reading the layer's input).
+#include "common.h"
+
+namespace lldwt {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int CGP_PX = 64;          // pixels per workgroup
+constexpr int CGP_PS = CGP_PX + 16; // LDS row stride (dwords), == 16 mod 32 -> conflict-free B reads
+constexpr int CGP_MAXT = 3;         // 16-channel tiles per wave (layer 1: 11 tiles over 4 waves)
+constexpr int CGP_NPT = CGP_PX / 16;
+
+struct CgpDims {
+    int c[5];        // channels per group: C0 (in), C1, C2, C3, C4 (=2)
+    int woff[4];     // float offset of layer l's packed weights inside a (plane, group) block
+    int boff[4];     // float offset of layer l's bias
+    int group_floats;
+};
+
+// 16-channel tiles of a layer, padded to a multiple of the 4 waves (zero weights): every wave owns the same number
+static inline __host__ __device__ int cgp_tiles(int M) { return ((((M + 15) / 16) + 3) / 4) * 4; }
+
+static inline CgpDims cgp_dims(int c0, int c1, int c2, int c3) {
+    CgpDims d;
+    d.c[0] = c0; d.c[1] = c1; d.c[2] = c2; d.c[3] = c3; d.c[4] = 2;
+    int off = 0;
+    for (int l = 0; l < 4; ++l) {
+        d.woff[l] = off;
+        off += cgp_tiles(d.c[l + 1]) * (int)cdiv(d.c[l], 4) * 64;
+    }
+    for (int l = 0; l < 4; ++l) {
+        d.boff[l] = off;
+        off += (int)round_up(d.c[l + 1], 16);
+    }
+    d.group_floats = off;
+    return d;
+}
+
+// packed[plane][group] = { for each layer: [oc tile][k step][lane] weights, then biases }
+__global__ void k_cgp_pack(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1,
+                           const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                           const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ packed,
+                           CgpDims d, int groups) {
+    const int plane = blockIdx.z, g = blockIdx.y;
+    const float* ws[4] = {w0, w1, w2, w3};
+    const float* bs[4] = {b0, b1, b2, b3};
+    float* dst = packed + ((int64_t)plane * groups + g) * d.group_floats;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.group_floats; i += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int l = 0; l < 4; ++l) {
+            const int K = d.c[l], M = d.c[l + 1];
+            const int ks = (K + 3) / 4, mt = cgp_tiles(M);
+            if (i >= d.woff[l] && i < d.woff[l] + mt * ks * 64) {
+                const int j = i - d.woff[l];
+                const int lane = j % 64, kstep = (j / 64) % ks, t = j / (64 * ks);
+                const int oc = t * 16 + (lane & 15), k = 4 * kstep + (lane >> 4);
+                if (oc < M && k < K) v = ws[l][((int64_t)plane * groups * M + (int64_t)g * M + oc) * K + k];
+            }
+            const int bpad = ((M + 15) / 16) * 16;
+            if (i >= d.boff[l] && i < d.boff[l] + bpad) {
+                const int oc = i - d.boff[l];
+                if (oc < M) v = bs[l][(int64_t)plane * groups * M + g * M + oc];
+            }
+        }
+        dst[i] = v;
+    }
+}
+
+// one dense layer on the LDS column: acc = W . buf ; result kept in registers.  Wave w owns tiles [w*MT, (w+1)*MT).
+// Branch-free hot loop: A operands stream from L2 through a double-buffered register ring (the loads of k-steps
+// [s0+U, s0+2U) are in flight while the MFMAs of [s0, s0+U) issue; addresses are clamped instead of predicated).
+template <int MT>
+__device__ __forceinline__ void cgp_layer(const float* __restrict__ buf, const float* __restrict__ pk, int K, int wave,
+                                          int lane, floatx4 (&acc)[MT][CGP_NPT]) {
+    const int ks = (K + 3) / 4;
+    const int px = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int n = 0; n < CGP_NPT; ++n) acc[j][n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const float* bb = buf + kk * CGP_PS + px;
+    const float* pa = pk + (int64_t)(wave * MT) * ks * 64 + lane;
+    constexpr int U = 4;
+    float An[U][MT];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) An[u][j] = pa[(j * ks + min(u, ks - 1)) * 64];
+    int s0 = 0;
+    for (; s0 + U <= ks; s0 += U) {
+        float Ac[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                Ac[u][j] = An[u][j];
+                An[u][j] = pa[(j * ks + min(s0 + U + u, ks - 1)) * 64];
+            }
+        // keep the prefetch loads ABOVE the MFMAs: without this fence hipcc sinks each load next to its use and
+        // waits vmcnt(0) per k-step (seen in the .s), which serialises the loop on L2 latency
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float B[CGP_NPT];
+#pragma unroll
+            for (int n = 0; n < CGP_NPT; ++n) B[n] = bb[(4 * (s0 + u)) * CGP_PS + n * 16];
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int n = 0; n < CGP_NPT; ++n)
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ac[u][j], B[n], acc[j][n], 0, 0, 0);
+        }
+    }
+#pragma unroll 1
+    for (int s = s0; s < ks; ++s) {      // tail: ks % U steps
+        float B[CGP_NPT], A[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) A[j] = pa[(j * ks + s) * 64];
+#pragma unroll
+        for (int n = 0; n < CGP_NPT; ++n) B[n] = bb[(4 * s) * CGP_PS + n * 16];
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int n = 0; n < CGP_NPT; ++n)
+                acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j], B[n], acc[j][n], 0, 0, 0);
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float* __restrict__ bias, int M, int wave,
+                                          int lane, const floatx4 (&acc)[MT][CGP_NPT]) {
+    const int px = lane & 15, kk = lane >> 4;
+    const int mpad = (M + 3) & ~3;     // rows M..mpad-1 are the zero padding of the next layer's K dimension
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = (wave * MT + j) * 16 + 4 * kk + r;
+            if (oc < mpad) {
+                const float b = oc < M ? bias[oc] : 0.f;
+#pragma unroll
+                for (int n = 0; n < CGP_NPT; ++n) {
+                    float v = oc < M ? acc[j][n][r] + b : 0.f;
+                    v = v >= 0.f ? v : 0.01f * v;             // LeakyReLU(0.01)
+                    buf[oc * CGP_PS + n * 16 + px] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void cgp_hidden(float* __restrict__ buf, const float* __restrict__ pk, const CgpDims& d, int l,
+                                           int wave, int lane) {
+    floatx4 acc[MT][CGP_NPT];
+    cgp_layer<MT>(buf, pk + d.woff[l], d.c[l], wave, lane, acc);
+    __syncthreads();                       // every wave has read this layer's input
+    cgp_store<MT>(buf, pk + d.boff[l], d.c[l + 1], wave, lane, acc);
+    __syncthreads();
+}
+
+constexpr int CGP_ROWS_MAX = 164;                         // input channels per group supported by the register prefetch
+constexpr int CGP_NIN = CGP_ROWS_MAX * CGP_PX / 256;      // input floats staged per thread
+constexpr int CGP_TILES_PER_WG = 8;                       // consecutive 64-pixel columns per workgroup
+
+// Persistent over CGP_TILES_PER_WG consecutive pixel columns: the next column's input is prefetched into registers
+// while the matrix work of the current one runs (issue early / write late), so HBM latency never parks the waves.
+__global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ cat, const float* __restrict__ x,
+                                                  const float* __restrict__ noise, const float* __restrict__ packed,
+                                                  float* __restrict__ bits, float* __restrict__ params_out,
+                                                  double* __restrict__ bit_sum, CgpDims d, int groups, int batch,
+                                                  int64_t hw) {
+    extern __shared__ __attribute__((aligned(16))) float buf[];     // [roundup(C0,4)][CGP_PS] + sigma/mu [2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const float* pk = packed + ((int64_t)plane * groups + g) * d.group_floats;
+    const int C0 = d.c[0];
+    const int rows0 = (C0 + 3) & ~3;
+    float* sm = buf + rows0 * CGP_PS;                               // sigma[64], mu[64]
+    const float* src = cat + (z * (int64_t)groups * C0 + (int64_t)g * C0) * hw;
+    const int64_t ntiles = (hw + CGP_PX - 1) / CGP_PX;
+    const int64_t t0 = (int64_t)blockIdx.x * CGP_TILES_PER_WG;
+    // this thread stages channels c0, c0+4, ...: c0 = wave id is wave-uniform -> row bases live in SGPRs
+    const int p = tid & (CGP_PX - 1), c0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    float xin[CGP_NIN];
+#define LLDWT_CGP_LOAD(TILE)                                                                         \
+    {                                                                                                \
+        const int pp = (int)((TILE) * CGP_PX) + p;                                                   \
+        _Pragma("unroll") for (int r = 0; r < CGP_NIN; ++r) {                                        \
+            const int c = c0 + 4 * r;                                                                \
+            const float* row = src + (int64_t)c * hw;          /* scalar */                          \
+            xin[r] = (c < C0 && pp < hw) ? row[pp] : 0.f;                                            \
+        }                                                                                            \
+    }
+    if (t0 < ntiles) LLDWT_CGP_LOAD(t0)
+    double local = 0;
+    for (int64_t t = t0; t < t0 + CGP_TILES_PER_WG && t < ntiles; ++t) {
+        const int64_t p0 = t * CGP_PX;
+        __syncthreads();                       // previous column fully consumed
+#pragma unroll
+        for (int r = 0; r < CGP_NIN; ++r) {
+            const int c = c0 + 4 * r;
+            if (c < rows0) buf[c * CGP_PS + p] = xin[r];
+        }
+        __syncthreads();
+        if (t + 1 < t0 + CGP_TILES_PER_WG && t + 1 < ntiles) LLDWT_CGP_LOAD(t + 1)
+        cgp_hidden<CGP_MAXT>(buf, pk, d, 0, wave, lane);
+        cgp_hidden<1>(buf, pk, d, 1, wave, lane);
+        cgp_hidden<1>(buf, pk, d, 2, wave, lane);
+        // ---- last layer (-> sigma, mu) on wave 0 (LiftingBasedDWT_net.py:360-362)
+        if (wave == 0) {
+            floatx4 acc[1][CGP_NPT];
+            cgp_layer<1>(buf, pk + d.woff[3], d.c[3], 0, lane, acc);
+            if (lane < 16) {
+                const float bs = pk[d.boff[3] + 0], bm = pk[d.boff[3] + 1];
+#pragma unroll
+                for (int n = 0; n < CGP_NPT; ++n) {
+                    sm[n * 16 + lane] = acc[0][n][0] + bs;
+                    sm[CGP_PX + n * 16 + lane] = acc[0][n][1] + bm;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Gaussian rate, one pixel per lane, on wave 1 (:364-365)
+        if (wave == 1) {
+            const int64_t pp = p0 + lane;
+            if (pp < hw) {
+                const float sg = sm[lane], mu = sm[CGP_PX + lane];
+                const int64_t idx = (z * groups + g) * hw + pp;
+                const float xv = x[idx];
+                const float v = noise ? xv + noise[idx] : rintf(xv - mu) + mu;
+                const float a = fabsf(v - mu);
+                const float sc = fmaxf(sg, 0.11f);
+                const float cst = -0.70710678118654752440f;
+                const float up = 0.5f * erfcf(cst * ((0.5f - a) / sc));
+                const float lo = 0.5f * erfcf(cst * ((-0.5f - a) / sc));
+                const float b = -log2f(fmaxf(up - lo, 1e-9f));
+                bits[idx] = b;
+                local += (double)b;
+                if (params_out) {
+                    params_out[(z * 2 * groups + 2 * g) * hw + pp] = sg;
+                    params_out[(z * 2 * groups + 2 * g + 1) * hw + pp] = mu;
+                }
+            }
+        }
+    }
+#undef LLDWT_CGP_LOAD
+    if (bit_sum && wave == 1) {
+        local = wave_sum(local);
+        if (lane == 0) atomicAdd(bit_sum, local);
+    }
+}
+
+}  // namespace lldwt
+using namespace lldwt;
+
+static int cgp_dims_ok(const char* who, int c0, int c1, int c2, int c3, int groups) {
+    LLDWT_REQUIRE(groups > 0 && c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0, "%s: bad channel counts", who);
+    LLDWT_REQUIRE(c1 <= 64 * CGP_MAXT && c2 <= 64 && c3 <= 64,
+                  "%s: hidden widths (%d,%d,%d) exceed the built tile plan (%d,64,64)", who, c1, c2, c3, 64 * CGP_MAXT);
+    LLDWT_REQUIRE(c1 <= round_up(c0, 4) && c2 <= round_up(c0, 4) && c3 <= round_up(c0, 4),
+                  "%s: hidden widths must not exceed the input width (in-place LDS column)", who);
+    LLDWT_REQUIRE(round_up(c0, 4) <= CGP_ROWS_MAX, "%s: input width %d exceeds %d", who, c0, CGP_ROWS_MAX);
+    return 0;
+}
+
+extern "C" int64_t lldwt_cgp_packed_floats(int c0, int c1, int c2, int c3, int groups) {
+    if (c0 <= 0 || c1 <= 0 || c2 <= 0 || c3 <= 0 || groups <= 0) return -1;
+    return (int64_t)cgp_dims(c0, c1, c2, c3).group_floats * groups;
+}
+
+extern "C" int lldwt_cgp_pack(const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                              const float* b2, const float* w3, const float* b3, float* packed, int64_t planes,
+                              int c0, int c1, int c2, int c3, int groups, void* stream) {
+    int r = cgp_dims_ok("cgp_pack", c0, c1, c2, c3, groups);
+    if (r) return r;
+    LLDWT_REQUIRE(w0 && b0 && w1 && b1 && w2 && b2 && w3 && b3 && packed && planes > 0, "cgp_pack: null pointer");
+    const CgpDims d = cgp_dims(c0, c1, c2, c3);
+    dim3 grid((unsigned)cdiv(d.group_floats, 256), (unsigned)groups, (unsigned)planes);
+    hipLaunchKernelGGL(k_cgp_pack, grid, dim3(256), 0, (hipStream_t)stream, w0, b0, w1, b1, w2, b2, w3, b3, packed, d, groups);
+    return check_launch("cgp_pack");
+}
+
+extern "C" int lldwt_cgp_rate(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
+                              float* params_out, double* bit_sum, int64_t planes, int64_t batch, int64_t hw, int c0,
+                              int c1, int c2, int c3, int groups, void* stream) {
+    int r = cgp_dims_ok("cgp_rate", c0, c1, c2, c3, groups);
+    if (r) return r;
+    LLDWT_REQUIRE(cat && x && packed && bits && planes > 0 && batch > 0 && hw > 0 && planes * batch <= 65535,
+                  "cgp_rate: bad arguments");
+    const CgpDims d = cgp_dims(c0, c1, c2, c3);
+    const size_t shmem = ((size_t)round_up(c0, 4) * CGP_PS + 2 * CGP_PX) * sizeof(float);
+    if (shmem > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k_cgp_rate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
+            set_error("cgp_rate: cannot reserve %zu bytes of LDS", shmem);
+            return LLDWT_EHIP;
+        }
+    }
+    dim3 grid((unsigned)cdiv(cdiv(hw, CGP_PX), CGP_TILES_PER_WG), (unsigned)groups, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_cgp_rate, grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits, params_out,
+                       bit_sum, d, groups, (int)batch, hw);
+    return check_launch("cgp_rate");
+}

@@ -24,8 +24,11 @@ class MaskedConv2d(nn.Conv2d):
         return sum(1 << t for t, v in enumerate(m) if v > 0)
 
     def apply_mask_(self):
-        # the reference mutates weight.data in place on every forward (masked_conv2d.py:20); keep that contract
-        self.weight.data *= self.mask
+        # the reference mutates weight.data in place on every forward (masked_conv2d.py:20).  Masking is idempotent, so
+        # it is re-applied only when the weight tensor changed since the last masking (keeps the packed-weight cache hot)
+        if getattr(self, "_masked_version", None) != (self.weight.data_ptr(), self.weight._version):
+            self.weight.data *= self.mask
+            self._masked_version = (self.weight.data_ptr(), self.weight._version)
 
     def forward(self, x):
         self.apply_mask_()

@@ -219,10 +219,11 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
             _conv([s[2] for s in seqs], t, out=cat, oc_block=81, oc_stride=162, oc_off=0)
             del t
             cg = [l.cgp_out_xo_list[i] for l in layers]
-            t = cat
-            for n in (0, 2, 4, 6):                                                                           # :360
-                t = _conv([s[n] for s in cg], t, act=ops.ACT_NONE if n == 6 else ops.ACT_LRELU)
-            bits, _ = ops.gauss_rate(x, t, _noise(x, training))                                              # :364
+            convs = [[s[n] for s in cg] for n in (0, 2, 4, 6)]
+            packed, dims = _cache.get(("cgp", id(cg[0])), [p for layer in convs for m in layer for p in (m.weight, m.bias)],
+                                      lambda: ops.cgp_pack([_stack(layer, lambda m: m.weight) for layer in convs],
+                                                           [_stack(layer, lambda m: m.bias) for layer in convs], so))
+            bits, _ = ops.cgp_rate(cat, x, packed, dims, _noise(x, training))                                # :360-365
             si_list.append(bits)
             q_list.append(xo_q)
             parent = xo_q

@@ -267,6 +267,34 @@ def gauss_rate(x, params, noise=None, want_q=False, bit_sum=None):
     return bits, q
 
 
+def cgp_pack(ws, bs, groups):
+    """ws: 4 stacked 1x1 conv weights (P, groups*c_{l+1}, c_l, 1, 1); bs: 4 biases (P, groups*c_{l+1})."""
+    lib = _lib.load()
+    P = ws[0].shape[0]
+    c = [ws[0].shape[2]] + [w.shape[1] // groups for w in ws]
+    assert c[4] == 2
+    n = lib.lldwt_cgp_packed_floats(c[0], c[1], c[2], c[3], groups)
+    packed = torch.empty(P, n, device=ws[0].device, dtype=torch.float32)
+    args = []
+    for w, b in zip(ws, bs):
+        args += [_chk(w, "w"), _chk(b, "b")]
+    check(lib.lldwt_cgp_pack(*args, _chk(packed), P, c[0], c[1], c[2], c[3], groups, _stream()), "cgp_pack")
+    return packed, tuple(c[:4])
+
+
+def cgp_rate(cat, x, packed, dims, noise=None, want_params=False, bit_sum=None):
+    """cat (P,B,groups*c0,h,w), x (P,B,groups,h,w) -> bits (and (sigma,mu) params if asked)."""
+    P, B, G, h, w = x.shape
+    assert cat.shape == (P, B, G * dims[0], h, w)
+    bits = torch.empty_like(x)
+    params = torch.empty(P, B, 2 * G, h, w, device=x.device, dtype=torch.float32) if want_params else None
+    bs = C.c_void_p(0) if bit_sum is None else C.c_void_p(bit_sum.data_ptr())
+    check(_lib.load().lldwt_cgp_rate(_chk(cat, "cat"), _chk(x, "x"), _opt(noise), _chk(packed, "packed"), _chk(bits),
+                                     _opt(params), bs, P, B, h * w, dims[0], dims[1], dims[2], dims[3], G, _stream()),
+          "cgp_rate")
+    return bits, params
+
+
 def factorized_rate(x, eb, noise=None, bit_sum=None):
     """x: (P,B,C,h,w); eb: (P,C,59) packed EntropyBottleneck parameters -> (bits, q)."""
     P, B, Cc, h, w = x.shape

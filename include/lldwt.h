@@ -169,6 +169,20 @@ int lldwt_gauss_rate(const float* x, const float* params, const float* noise, fl
 /* quantize(x, mode, means=None): round(x) or x + noise (LiftingBasedDWT_net.py:330,341,352). */
 int lldwt_quantize(const float* x, const float* noise, float* q, int64_t n, void* stream);
 
+/* Fused "cgp" parameter network + Gaussian rate of DWTConditioned2EntropyLayerZTsepSubbands
+ * (LiftingBasedDWT_net.py:282-289 grouped 1x1 convs c0 -> c1 -> c2 -> c3 -> 2 with LeakyReLU, :361-365 rate).
+ * cat: (Z, groups*c0, hw) = the interleaved (plc_g, csc_g) tensor of :357-359; x, noise, bits: (Z, groups, hw);
+ * params_out (optional): (Z, 2*groups, hw) receives (sigma, mu) as the reference's out_xo_qnt_mu_sigma.
+ * lldwt_cgp_pack: the four conv weights (planes, groups*c_{l+1}, c_l) / biases (planes, groups*c_{l+1}) in PyTorch
+ * layout -> packed (planes, lldwt_cgp_packed_floats) in MFMA A-operand lane order.                       */
+int64_t lldwt_cgp_packed_floats(int c0, int c1, int c2, int c3, int groups);
+int lldwt_cgp_pack(const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                   const float* b2, const float* w3, const float* b3, float* packed, int64_t planes, int c0, int c1,
+                   int c2, int c3, int groups, void* stream);
+int lldwt_cgp_rate(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
+                   float* params_out, double* bit_sum, int64_t planes, int64_t batch, int64_t hw, int c0, int c1,
+                   int c2, int c3, int groups, void* stream);
+
 /* Factorized (compressai EntropyBottleneck.forward, call sites LiftingBasedDWT_net.py:225,229,815,818):
  * per channel c of plane p: 5 tiny matrices softplus(_matrix{i}) (1x3,3x3,3x3,3x3,3x1), biases, tanh(_factor).
  * eb: packed per (plane,channel) block of LLDWT_EB_FLOATS floats =

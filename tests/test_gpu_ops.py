@@ -174,6 +174,35 @@ def test_gauss_rate_eval_and_noise():
     assert torch.equal(ops.quantize(gu.dev(x)).cpu(), torch.round(x))
 
 
+def test_cgp_fused_rate():
+    """Fused cgp MLP + Gaussian rate vs the oracle's grouped 1x1 conv stack (LiftingBasedDWT_net.py:357-365)."""
+    ops, gu = _ops()
+    g = torch.Generator().manual_seed(12)
+    P, B, G, h, w = 2, 2, 3, 9, 13          # 117 pixels: ragged 64-pixel columns
+    dims = [162, 162, 54, 18, 2]
+    cat = torch.rand(P, B, G * 162, h, w, generator=g) - 0.5
+    x = (torch.rand(P, B, G, h, w, generator=g) - 0.5) * 8
+    ws = [(torch.rand(P, G * dims[l + 1], dims[l], 1, 1, generator=g) - 0.5) * (3.0 / dims[l]) ** 0.5 * 2 for l in range(4)]
+    bs = [(torch.rand(P, G * dims[l + 1], generator=g) - 0.5) * 0.4 for l in range(4)]
+    packed, d = ops.cgp_pack([gu.dev(t) for t in ws], [gu.dev(t) for t in bs], G)
+    bsum = torch.zeros(1, dtype=torch.float64, device=gu.DEV)
+    bits, params = ops.cgp_rate(gu.dev(cat), gu.dev(x), packed, d, want_params=True, bit_sum=bsum)
+    noise = torch.rand(P, B, G, h, w, generator=g) - 0.5
+    bits_n, _ = ops.cgp_rate(gu.dev(cat), gu.dev(x), packed, d, noise=gu.dev(noise))
+    for p in range(P):
+        t = cat[p]
+        for l in range(4):
+            t = F.conv2d(t, ws[l][p], bs[l][p], groups=G)
+            if l < 3:
+                t = F.leaky_relu(t, 0.01)
+        assert maxdiff(params[p].cpu(), t) < 2e-5
+        _, lik = entropy.gaussian_conditional_forward(x[p], t[:, 0::2], t[:, 1::2], False)
+        assert maxdiff(bits[p].cpu(), -torch.log2(lik)) < 2e-4
+        _, lik = entropy.gaussian_conditional_forward(x[p], t[:, 0::2], t[:, 1::2], True, noise[p])
+        assert maxdiff(bits_n[p].cpu(), -torch.log2(lik)) < 2e-4
+    assert abs(float(bsum) - float(bits.double().sum())) < 1e-6 * float(bits.double().sum())
+
+
 def test_factorized_rate():
     ops, gu = _ops()
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.entropy_models import pack_entropy_bottleneck
