@@ -87,15 +87,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
+    rank, world, local = parallel.env_rank()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+    parallel.init("nccl", dev)                               # backend "nccl" == RCCL over xGMI; no-op for N == 1
 
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import rate_planes
@@ -103,7 +99,7 @@ def main():
     net, sd, cfg = build_model(a.levels, dev)
     log("model ready")
     nets = net.nets()
-    x = torch.rand(a.batch, 3, a.size, a.size, device=dev, generator=torch.Generator(device=dev).manual_seed(1337 + rank))
+    x = torch.rand(a.batch, 3, a.size, a.size, device=dev, generator=torch.Generator(device=dev).manual_seed(parallel.rank_seed(1337, rank)))
     bit_acc = torch.zeros(1, dtype=torch.float64, device=dev)
 
     # HIP events around the dominant kernel (plc second conv, 243 -> 243 3x3, LiftingBasedDWT_net.py:271-272): the
@@ -147,16 +143,12 @@ def main():
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dom["on"] = False
     log("timed region done: %.3f s for %d steps" % (dt, a.steps))
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    dt = parallel.max_over_ranks(dt, dev)                    # the slowest rank defines the step time
 
     dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom["events"])
     n_launch = max(len(dom["events"]), 1)
@@ -182,8 +174,8 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if dist:
-        dist.destroy_process_group()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
