@@ -135,8 +135,7 @@ def main():
         step()
         torch.cuda.synchronize()
         log("warmup %d done" % i)
-    if dist:
-        dist.barrier()
+    parallel.barrier()
     torch.cuda.synchronize()
     dom["on"] = True
     t0 = time.perf_counter()
