@@ -23,10 +23,12 @@ class ConvDesc(C.Structure):
     """lldwt_conv_desc (include/lldwt.h)."""
     _fields_ = [("cin", C.c_int), ("cout", C.c_int), ("K", C.c_int), ("groups", C.c_int), ("act", C.c_int),
                 ("upsample2", C.c_int), ("transposed", C.c_int), ("tap_mask", C.c_uint32), ("oc_block", C.c_int),
-                ("oc_stride", C.c_int), ("oc_off", C.c_int), ("ytot", C.c_int)]
+                ("oc_stride", C.c_int), ("oc_off", C.c_int), ("ytot", C.c_int), ("ic_block", C.c_int),
+                ("ic_stride", C.c_int), ("ic_off", C.c_int), ("xtot", C.c_int), ("epi", C.c_int)]
 
 
 ACT_NONE, ACT_TANH, ACT_LRELU = 0, 1, 2
+EPI_NONE, EPI_TANH_BWD, EPI_LRELU_BWD = 0, 1, 2
 EB_FLOATS = 59
 
 _p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -50,7 +52,10 @@ SIGNATURES = {
     "lldwt_subband_mlp": (_i, [_p, _p, _i64, _i64, _i, _i64, _i] + [_p] * 8 + [_i, _p]),
     "lldwt_conv_packed_floats": (_i64, [C.POINTER(ConvDesc)]),
     "lldwt_conv_pack": (_i, [_p, _p, C.POINTER(ConvDesc), _i64, _p]),
-    "lldwt_conv2d": (_i, [_p, _p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
+    "lldwt_conv2d": (_i, [_p, _p, _p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
+    "lldwt_conv2d_wgrad": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
+    "lldwt_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "lldwt_downsum2": (_i, [_p, _p, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_direct": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
     "lldwt_gdn": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i64, _i, _f, _p]),
     "lldwt_lower_bound_fwd": (_i, [_p, _p, _i64, _f, _p]),

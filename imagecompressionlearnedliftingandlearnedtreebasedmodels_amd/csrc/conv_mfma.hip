@@ -90,7 +90,7 @@ __global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ pac
         float v = 0.f;
         if (ocl < cout_g && ic < cin_g && tap >= 0) {
             const int oc = g * cout_g + ocl;
-            v = d.transposed ? wp[((int64_t)(g * cin_g + ic) * d.cout + oc) * KK + (KK - 1 - tap)]   // groups == 1
+            v = d.transposed ? wp[((int64_t)(g * cin_g + ic) * cout_g + ocl) * KK + (KK - 1 - tap)]   // (cin, cout/groups, K, K)
                              : wp[((int64_t)oc * cin_g + ic) * KK + tap];
         }
         dst[i] = v;
@@ -103,6 +103,7 @@ struct ConvArgs {
     const float* packed;
     const float* bias;
     const float* residual;   // same layout as y (ytot channels) or null
+    const float* aux;        // same layout as y: forward output for the gradient epilogue, or null
     lldwt_conv_desc d;
     ConvPlan p;
     int batch, h, w, tiles_x;
@@ -143,7 +144,9 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     const int h = a.h, w = a.w;
     const int hi = d.upsample2 ? h >> 1 : h, wi = d.upsample2 ? w >> 1 : w;
     const int64_t hwi = (int64_t)hi * wi;
-    const float* xg = a.x + (z * d.cin + (int64_t)g * cin_g) * hwi;
+    const int xtot = d.ic_block > 0 ? d.xtot : d.cin;
+    const float* xg = a.x + (z * xtot) * hwi;               // + mapped channel * hwi
+    const int icb = d.ic_block > 0 ? d.ic_block : d.cin, ics = d.ic_block > 0 ? d.ic_stride : 0, ico = d.ic_block > 0 ? d.ic_off : 0;
     const float* pk = a.packed + (int64_t)plane * a.p.plane_floats +
                       ((int64_t)(g * a.p.nocb + ocb) * a.p.nchunk) * a.p.chunk_floats;
     const int wvec = (int)(a.p.chunk_floats / 4);
@@ -181,7 +184,9 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     {                                                                                                       \
         _Pragma("unroll") for (int r = 0; r < G::NIN; ++r) {                                                \
             const int ic = (CHUNK) * CK + in_c[r];                                                          \
-            xin[r] = (in_off[r] >= 0 && ic < cin_g) ? xg[ic * hwi + in_off[r]] : 0.f;                       \
+            const int icg = g * cin_g + ic;                                                                 \
+            const int icm = (icg / icb) * ics + ico + icg % icb;                                            \
+            xin[r] = (in_off[r] >= 0 && ic < cin_g) ? xg[icm * hwi + in_off[r]] : 0.f;                      \
         }                                                                                                   \
         const float4* src = reinterpret_cast<const float4*>(pk + (int64_t)(CHUNK) * a.p.chunk_floats);     \
         _Pragma("unroll") for (int r = 0; r < G::NWV; ++r) {                                                \
@@ -251,12 +256,17 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
             const float bv = a.bias ? a.bias[plane * d.cout + oc] : 0.f;
             float* yp = a.y + (z * d.ytot + ocp) * hw;
             const float* rp = a.residual ? a.residual + (z * d.ytot + ocp) * hw : nullptr;
+            const float* ap = (a.aux && d.epi) ? a.aux + (z * d.ytot + ocp) * hw : nullptr;
 #pragma unroll
             for (int n = 0; n < WN; ++n) {
                 const int j = wn * WN + n;
                 const int gy = y0 + j / TWS, gx = x0 + (j % TWS) * 16 + px;
                 if (gy < h && gx < w) {
                     float v = acc[m][n][r] + bv;
+                    if (ap) {
+                        const float av = ap[(int64_t)gy * w + gx];
+                        v *= d.epi == LLDWT_EPI_TANH_BWD ? (1.f - av * av) : (av > 0.f ? 1.f : 0.01f);
+                    }
                     if (rp) v += rp[(int64_t)gy * w + gx];
                     yp[(int64_t)gy * w + gx] = act_apply(v, d.act);
                 }
@@ -300,7 +310,7 @@ static int conv_desc_ok(const char* who, const lldwt_conv_desc* d, int64_t plane
     LLDWT_REQUIRE(d->K == 1 || d->K == 3 || d->K == 5, "%s: K=%d unsupported", who, d->K);
     LLDWT_REQUIRE(d->groups > 0 && d->cin > 0 && d->cout > 0 && d->cin % d->groups == 0 && d->cout % d->groups == 0,
                   "%s: bad channels/groups (%d,%d,%d)", who, d->cin, d->cout, d->groups);
-    LLDWT_REQUIRE(!d->transposed || d->groups == 1, "%s: transposed needs groups==1", who);
+    LLDWT_REQUIRE(d->ic_block == 0 || (d->ic_block > 0 && d->xtot >= d->cin), "%s: bad input placement", who);
     LLDWT_REQUIRE(planes > 0 && batch > 0 && h > 0 && w > 0 && planes * batch <= 65535, "%s: bad planes/batch/h/w", who);
     LLDWT_REQUIRE(!d->upsample2 || (h % 2 == 0 && w % 2 == 0), "%s: upsample2 needs even output dims", who);
     LLDWT_REQUIRE(d->oc_block > 0 && d->ytot >= d->cout, "%s: bad output placement", who);
@@ -328,13 +338,13 @@ extern "C" int lldwt_conv_pack(const float* w, float* packed, const lldwt_conv_d
 }
 
 extern "C" int lldwt_conv2d(const float* x, float* y, const float* packed, const float* bias, const float* residual,
-                            const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_,
-                            void* stream) {
+                            const float* aux, const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h,
+                            int64_t w_, void* stream) {
     int r = conv_desc_ok("conv2d", d, planes, batch, h, w_);
     if (r) return r;
     LLDWT_REQUIRE(x && y && packed, "conv2d: null pointer");
     ConvArgs a;
-    a.x = x; a.y = y; a.packed = packed; a.bias = bias; a.residual = residual;
+    a.x = x; a.y = y; a.packed = packed; a.bias = bias; a.residual = residual; a.aux = aux;
     a.d = *d;
     a.d.tap_mask &= (1u << (d->K * d->K)) - 1u;
     a.p = make_plan(a.d);

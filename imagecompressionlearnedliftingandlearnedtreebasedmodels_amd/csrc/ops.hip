@@ -149,8 +149,9 @@ __global__ __launch_bounds__(256) void k_conv_direct(const float* __restrict__ x
                 for (int o = 0; o < OCB; ++o) {
                     const int oc = oc0 + o;
                     if (ocl0 + o < cout_g) {
-                        const float wv = d.transposed ? wp[((int64_t)ic * d.cout + oc) * KK + (KK - 1 - t)]
-                                                      : wp[((int64_t)oc * cin_g + ic) * KK + t];
+                        const float wv = d.transposed
+                                             ? wp[((int64_t)(g * cin_g + ic) * cout_g + (ocl0 + o)) * KK + (KK - 1 - t)]
+                                             : wp[((int64_t)oc * cin_g + ic) * KK + t];
                         acc[o] = fmaf(wv, v, acc[o]);
                     }
                 }
@@ -415,7 +416,7 @@ extern "C" int lldwt_conv2d_direct(const float* x, float* y, const float* w, con
     LLDWT_REQUIRE(x && y && w && d, "conv2d: null pointer");
     LLDWT_REQUIRE(d->K == 1 || d->K == 3 || d->K == 5, "conv2d: K=%d unsupported", d->K);
     LLDWT_REQUIRE(d->groups > 0 && d->cin % d->groups == 0 && d->cout % d->groups == 0, "conv2d: bad groups");
-    LLDWT_REQUIRE(!d->transposed || d->groups == 1, "conv2d: transposed needs groups==1");
+    LLDWT_REQUIRE(d->ic_block == 0, "conv2d_direct: input placement not supported by the cross-check kernel");
     LLDWT_REQUIRE(!d->upsample2 || (h % 2 == 0 && w_ % 2 == 0), "conv2d: upsample2 needs even output dims");
     LLDWT_REQUIRE(d->oc_block > 0 && d->ytot >= d->cout, "conv2d: bad output placement");
     LLDWT_REQUIRE(planes * batch <= 65535, "conv2d: planes*batch exceeds grid.z");

@@ -8,7 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_TANH, ConvDesc, View, check  # noqa: F401
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_TANH, EPI_LRELU_BWD, EPI_NONE, EPI_TANH_BWD, ConvDesc, View,  # noqa: F401
+                   check)
 
 _ws = {}
 
@@ -171,18 +172,30 @@ def subband_mlp(x, w0, b0, w1, b1, w2, b2, w3, b3, transposed=False, hidden=32):
 
 
 def conv_desc(cin, cout, K, groups=1, act=ACT_NONE, upsample2=False, transposed=False, tap_mask=None, oc_block=None,
-              oc_stride=0, oc_off=0, ytot=None):
+              oc_stride=0, oc_off=0, ytot=None, ic_block=0, ic_stride=0, ic_off=0, xtot=0, epi=0):
     return ConvDesc(cin, cout, K, groups, act, int(bool(upsample2)), int(bool(transposed)),
                     (1 << (K * K)) - 1 if tap_mask is None else int(tap_mask), cout if oc_block is None else oc_block,
-                    oc_stride, oc_off, cout if ytot is None else ytot)
+                    oc_stride, oc_off, cout if ytot is None else ytot, ic_block, ic_stride, ic_off, xtot, epi)
+
+
+def flip_mask(mask, K):
+    """Tap mask of the 180-degree rotated kernel (backward-data of a masked conv)."""
+    if mask is None:
+        return None
+    KK = K * K
+    return sum(1 << (KK - 1 - t) for t in range(KK) if (mask >> t) & 1)
 
 
 def conv_pack(w, K, groups=1, transposed=False, tap_mask=None):
-    """(P,cout,cin/groups,K,K) (transposed: (P,cin,cout,K,K)) -> packed (P, floats) in MFMA A-operand order."""
+    """(P,cout,cin/groups,K,K) -> packed (P, floats) in MFMA A-operand order.  transposed: the weight is in
+    ConvTranspose2d layout (P,cin,cout/groups,K,K) (or a forward Conv2d weight used for its backward-data pass:
+    then `cin` is the forward cout) and the taps are flipped; tap_mask refers to the effective (flipped) taps."""
     lib = _lib.load()
     P = w.shape[0]
-    cout = w.shape[2] if transposed else w.shape[1]
-    cin = w.shape[1] if transposed else w.shape[2] * groups
+    if transposed:
+        cin, cout = w.shape[1], w.shape[2] * groups
+    else:
+        cout, cin = w.shape[1], w.shape[2] * groups
     d = conv_desc(cin, cout, K, groups, transposed=transposed, tap_mask=tap_mask)
     n = lib.lldwt_conv_packed_floats(C.byref(d))
     packed = torch.empty(P, n, device=w.device, dtype=torch.float32)
@@ -191,26 +204,62 @@ def conv_pack(w, K, groups=1, transposed=False, tap_mask=None):
 
 
 def conv2d(x, w, bias, K, groups=1, act=ACT_NONE, upsample2=False, transposed=False, tap_mask=None, out=None,
-           oc_block=None, oc_stride=0, oc_off=0, direct=False, packed=None, residual=None):
-    """General conv layer (include/lldwt.h lldwt_conv2d).  x: (P,B,cin,h,w); w: (P,cout,cin/groups,K,K)
-    (transposed: (P,cin,cout,K,K)).  ``out``: optional pre-allocated (P,B,ytot,h,w) tensor for channel placement.
+           oc_block=None, oc_stride=0, oc_off=0, direct=False, packed=None, residual=None, aux=None, epi=0,
+           ic_block=0, ic_stride=0, ic_off=0, cin=None):
+    """General conv layer (include/lldwt.h lldwt_conv2d).  x: (P,B,xtot,h,w); w: (P,cout,cin/groups,K,K)
+    (transposed: (P,cin,cout/groups,K,K)).  ``out``: optional pre-allocated (P,B,ytot,h,w) tensor for channel placement.
     ``packed``: result of conv_pack(w, ...) to skip re-packing; ``direct``: reference-order VALU kernel."""
     lib = _lib.load()
-    P, B, cin, hi, wi = x.shape
-    cout = w.shape[2] if transposed else w.shape[1]
+    P, B, xtot, hi, wi = x.shape
+    if transposed:
+        cin_w, cout = w.shape[1], w.shape[2] * groups
+    else:
+        cout, cin_w = w.shape[1], w.shape[2] * groups
+    cin = cin_w if cin is None else cin
     h, wd = (hi * 2, wi * 2) if upsample2 else (hi, wi)
     if out is None:
         out = torch.empty(P, B, cout, h, wd, device=x.device, dtype=torch.float32)
-    d = conv_desc(cin, cout, K, groups, act, upsample2, transposed, tap_mask, oc_block, oc_stride, oc_off, out.shape[2])
+    d = conv_desc(cin, cout, K, groups, act, upsample2, transposed, tap_mask, oc_block, oc_stride, oc_off, out.shape[2],
+                  ic_block, ic_stride, ic_off, xtot if ic_block else 0, epi)
+    if not ic_block and xtot != cin:
+        raise _lib.LLDWTError("conv2d: input has %d channels, weight expects %d" % (xtot, cin))
     if direct:
-        assert residual is None
+        assert residual is None and aux is None and not ic_block
         check(lib.lldwt_conv2d_direct(_chk(x, "x"), _chk(out, "out"), _chk(w, "w"), _opt(bias, "bias"), C.byref(d), P, B,
                                       h, wd, _stream()), "conv2d_direct")
         return out
     if packed is None:
         packed = conv_pack(w, K, groups, transposed, tap_mask)
     check(lib.lldwt_conv2d(_chk(x, "x"), _chk(out, "out"), _chk(packed, "packed"), _opt(bias, "bias"),
-                           _opt(residual, "residual"), C.byref(d), P, B, h, wd, _stream()), "conv2d")
+                           _opt(residual, "residual"), _opt(aux, "aux"), C.byref(d), P, B, h, wd, _stream()), "conv2d")
+    return out
+
+
+def conv2d_wgrad(x, dy, wshape, K, groups=1, upsample2=False, tap_mask=None, want_bias=True, oc_block=None, oc_stride=0,
+                 oc_off=0, ic_block=0, ic_stride=0, ic_off=0):
+    """-> (dw (P,cout,cin/groups,K,K), dbias (P,cout) or None); dy: (P,B,ytot,h,w) read through the output placement."""
+    lib = _lib.load()
+    P, B, ytot, h, wd = dy.shape
+    cout, cin = wshape[1], wshape[2] * groups
+    dw = torch.zeros(wshape, device=x.device, dtype=torch.float32)
+    db = torch.zeros(P, cout, device=x.device, dtype=torch.float32) if want_bias else None
+    d = conv_desc(cin, cout, K, groups, 0, upsample2, False, tap_mask, oc_block, oc_stride, oc_off, ytot, ic_block,
+                  ic_stride, ic_off, x.shape[2] if ic_block else 0, 0)
+    check(lib.lldwt_conv2d_wgrad(_chk(x, "x"), _chk(dy, "dy"), _chk(dw), _opt(db), C.byref(d), P, B, h, wd, _stream()),
+          "conv2d_wgrad")
+    return dw, db
+
+
+def act_bwd(dy, y, act):
+    dx = torch.empty_like(dy)
+    check(_lib.load().lldwt_act_bwd(_chk(dy), _chk(y), _chk(dx), dy.numel(), act, _stream()), "act_bwd")
+    return dx
+
+
+def downsum2(g):
+    P, B, Cc, h, w = g.shape
+    out = torch.empty(P, B, Cc, h // 2, w // 2, device=g.device, dtype=torch.float32)
+    check(_lib.load().lldwt_downsum2(_chk(g), _chk(out), P * B * Cc, h, w, _stream()), "downsum2")
     return out
 
 

@@ -133,14 +133,37 @@ typedef struct lldwt_conv_desc {
     int transposed;
     uint32_t tap_mask;
     int oc_block, oc_stride, oc_off, ytot;
+    /* input channel placement (mirror of the output placement; used by the backward-data pass, whose input is the
+     * gradient of a tensor written with oc_* placement): channel c is read at (c / ic_block)*ic_stride + ic_off +
+     * c % ic_block of a tensor with xtot channels; ic_block == 0 means dense (xtot = cin).                    */
+    int ic_block, ic_stride, ic_off, xtot;
+    /* gradient epilogue: LLDWT_EPI_NONE, or multiply the result by act'(aux) with aux = the forward OUTPUT of the
+     * layer whose pre-activation gradient is being formed (tanh: 1-aux^2, LeakyReLU: aux>0 ? 1 : 0.01).       */
+    int epi;
 } lldwt_conv_desc;
+#define LLDWT_EPI_NONE 0
+#define LLDWT_EPI_TANH_BWD 1
+#define LLDWT_EPI_LRELU_BWD 2
 /* Weights are pre-packed once per update into the MFMA A-operand lane order (csrc/conv_mfma.hip):
  * packed holds lldwt_conv_packed_floats(d) floats PER PLANE.  residual (optional): tensor laid out like y, added before
  * the activation (P_block_v2.py:53 "tmp + out_res").                                                       */
 int64_t lldwt_conv_packed_floats(const lldwt_conv_desc* d);
 int lldwt_conv_pack(const float* w, float* packed, const lldwt_conv_desc* d, int64_t planes, void* stream);
+/* y = act( (conv(x) + bias) * epi(aux) + residual ).  transposed != 0 builds the operator from a weight in
+ * ConvTranspose2d layout (planes, cin, cout/groups, K, K) with the taps flipped: that is ConvTranspose2d (stride 1)
+ * itself and, applied to a forward Conv2d weight with cin/cout swapped, the BACKWARD-DATA pass of that conv.      */
 int lldwt_conv2d(const float* x, float* y, const float* packed, const float* bias, const float* residual,
-                 const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+                 const float* aux, const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_,
+                 void* stream);
+/* Backward-weights: dw (planes,cout,cin/groups,K,K) += sum over batch and pixels of dy[.,oc,p] * x[.,ic,p+tap]
+ * (dead taps of tap_mask are skipped), dbias (planes,cout) += sum dy (optional).  dy is read through the OUTPUT
+ * placement (oc_*), x through upsample2 / the input placement.  Accumulates with float atomics: zero dw/dbias first. */
+int lldwt_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const lldwt_conv_desc* d,
+                       int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+/* dx = dy * act'(y) elementwise (y = forward output); act as in lldwt_conv_desc. */
+int lldwt_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, void* stream);
+/* backward of the nearest-neighbour 2x upsampling: out (Z,C,h/2,w/2) = sum over each 2x2 block of g (Z,C,h,w). */
+int lldwt_downsum2(const float* g, float* out, int64_t zc, int64_t h, int64_t w_, void* stream);
 /* Same maths from the raw PyTorch-layout weights w, reference-order direct kernel (VALU); cross-checks the MFMA engine. */
 int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
                         int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
