@@ -19,6 +19,16 @@ class View(C.Structure):
     _fields_ = [("p", C.c_void_p), ("sz", C.c_int64), ("sy", C.c_int64), ("sx", C.c_int64)]
 
 
+class LiftOp(C.Structure):
+    """lldwt_lift_op (include/lldwt.h)."""
+    _fields_ = [("kind", C.c_int32), ("buf_src", C.c_int32), ("buf_din", C.c_int32), ("buf_dout", C.c_int32),
+                ("off_src", C.c_int64), ("sz_src", C.c_int64), ("sy_src", C.c_int64), ("sx_src", C.c_int64),
+                ("off_din", C.c_int64), ("sz_din", C.c_int64), ("sy_din", C.c_int64), ("sx_din", C.c_int64),
+                ("off_dout", C.c_int64), ("sz_dout", C.c_int64), ("sy_dout", C.c_int64), ("sx_dout", C.c_int64),
+                ("h", C.c_int32), ("w", C.c_int32), ("vertical", C.c_int32), ("tap", C.c_int32), ("block", C.c_int32),
+                ("is_u", C.c_int32), ("sign", C.c_float), ("pad_", C.c_int32), ("saved_off", C.c_int64)]
+
+
 class ConvDesc(C.Structure):
     """lldwt_conv_desc (include/lldwt.h)."""
     _fields_ = [("cin", C.c_int), ("cout", C.c_int), ("K", C.c_int), ("groups", C.c_int), ("act", C.c_int),
@@ -49,11 +59,20 @@ SIGNATURES = {
                                    _p, _p, _p, _i64, _p]),
     "lldwt_lifting_inverse": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _i, _f, _i,
                                    _p, _p, _p, _i64, _p]),
+    "lldwt_lifting_program": (_i, [C.POINTER(LiftOp), _i, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, C.POINTER(_i64)]),
+    "lldwt_lifting_forward_train": (_i, [_p, _p, C.POINTER(_p), _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _i, _i, _f,
+                                         _i, _p, _i64, _p, _p]),
+    "lldwt_lifting_inverse_train": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _i, _f, _i,
+                                         _p, _i64, _p, _p]),
+    "lldwt_lift_bwd_pre": (_i, [View, View, _p, _i64, _i64, _i64, _p]),
+    "lldwt_lift_bwd_fin": (_i, [_p, _p, _p, View, _i64, _i64, _i64, _i64, _p, _p, _i, _f, _f, _p]),
     "lldwt_subband_mlp": (_i, [_p, _p, _i64, _i64, _i, _i64, _i] + [_p] * 8 + [_i, _p]),
     "lldwt_conv_packed_floats": (_i64, [C.POINTER(ConvDesc)]),
     "lldwt_conv_pack": (_i, [_p, _p, C.POINTER(ConvDesc), _i64, _p]),
+    "lldwt_conv_pack_ex": (_i, [_p, _p, C.POINTER(ConvDesc), _i64, _i, _p]),
     "lldwt_conv2d": (_i, [_p, _p, _p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_wgrad": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
+    "lldwt_conv2d_wgrad_ex": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _f, _i, _p]),
     "lldwt_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
     "lldwt_downsum2": (_i, [_p, _p, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_direct": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
@@ -66,6 +85,9 @@ SIGNATURES = {
     "lldwt_cgp_packed_floats": (_i64, [_i, _i, _i, _i, _i]),
     "lldwt_cgp_pack": (_i, [_p] * 9 + [_i64, _i, _i, _i, _i, _i, _p]),
     "lldwt_cgp_rate": (_i, [_p] * 7 + [_i64, _i64, _i64, _i, _i, _i, _i, _i, _p]),
+    "lldwt_gauss_rate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i64, _p]),
+    "lldwt_axpby": (_i, [_p, _p, _p, _i64, _f, _f, _p]),
+    "lldwt_ycc_to_rgb_bwd": (_i, [_p, _p, _i64, _i64, _i64, _p]),
     "lldwt_quantize": (_i, [_p, _p, _p, _i64, _p]),
     "lldwt_factorized_rate": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
     "lldwt_sq_err_sum": (_i, [_p, _p, _i64, _p, _p]),

@@ -41,3 +41,231 @@ class ConvFn(torch.autograd.Function):
 
 def conv(x, w, b, K, groups=1, act=ops.ACT_NONE, upsample2=False, tap_mask=None, residual=None):
     return ConvFn.apply(x, w, b, residual, K, groups, act, upsample2, tap_mask)
+
+
+# ------------------------------------------------------------------------------------------------ rate / quantise / colour
+class GaussRateFn(torch.autograd.Function):
+    """bits = -log2 p(x + noise | sigma, mu) (lldwt_gauss_rate); backward closed form (lldwt_gauss_rate_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, params, noise):
+        bits, _ = ops.gauss_rate(x, params, noise)
+        ctx.save_for_backward(x, params, noise)
+        return bits
+
+    @staticmethod
+    def backward(ctx, gbits):
+        x, params, noise = ctx.saved_tensors
+        dx, dparams = ops.gauss_rate_bwd(x, params, noise, gbits.contiguous())
+        return dx, dparams, None
+
+
+class QuantNoiseFn(torch.autograd.Function):
+    """quantize(x, 'noise') = x + U(-.5,.5): identity gradient."""
+
+    @staticmethod
+    def forward(ctx, x, noise):
+        return ops.quantize(x, noise)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class YccToRgbFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ycc):
+        return ops.ycc_to_rgb(ycc, clamp=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.ycc_to_rgb_bwd(g.contiguous())
+
+
+class SumFn(torch.autograd.Function):
+    """float64 device sum of a tensor (lldwt_sum); gradient = broadcast."""
+
+    @staticmethod
+    def forward(ctx, t):
+        acc = torch.zeros(1, dtype=torch.float64, device=t.device)
+        ops.sum_into(t.contiguous(), acc)
+        ctx.shape = t.shape
+        return acc
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.float32).expand(ctx.shape).contiguous()
+
+
+class SqErrSumFn(torch.autograd.Function):
+    """sum((a-b)^2) in float64 (lldwt_sq_err_sum); d/db = 2 (b - a) g (a is the target, no gradient)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        acc = torch.zeros(1, dtype=torch.float64, device=a.device)
+        ops.sq_err_sum(a.contiguous(), b.contiguous(), acc)
+        ctx.save_for_backward(a, b)
+        return acc
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        s = 2.0 * float(g)
+        return None, ops.axpby(b.contiguous(), a.contiguous(), s, -s)
+
+
+# ------------------------------------------------------------------------------------------------ lifting transform
+_BUF_X, _BUF_LROW, _BUF_HROW, _BUF_TMPL, _BUF_TMPH, _BUF_LL0, _BUF_LL1, _BUF_LL, _BUF_YH0 = range(9)
+
+
+def _pack_forward(W, nblocks):
+    """W: dict of 8 stacked tensors (nblocks,2,P,...) -> packed (P,nblocks,2,total) for the lifting step kernels."""
+    blocks = []
+    for b in range(nblocks):
+        pu = [ops.pack_pblock(*[W[k][b, u] for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")]) for u in range(2)]
+        blocks.append(torch.stack(pu, 1))
+    return torch.stack(blocks, 1).contiguous()
+
+
+class _LiftBackward:
+    """Executes the step program in reverse over gradient buffers of the forward layout (include/lldwt.h)."""
+
+    def __init__(self, meta, taps, W, saved, P, B, H, W_):
+        self.m, self.taps, self.W, self.saved = meta, taps, W, saved
+        self.P, self.B, self.H, self.Wd = P, B, H, W_
+        self.Z = P * B
+        self.dtaps = torch.zeros_like(taps)
+        self.dW = {k: torch.zeros_like(v) for k, v in W.items()}
+        self.packs = {}
+
+    def _pack(self, name, blk, u, vertical):
+        key = (name, blk, u, vertical)
+        if key not in self.packs:
+            self.packs[key] = ops.conv_pack(self.W[name][blk, u], self.m["K"], transposed=True, swap_hw=not vertical)
+        return self.packs[key]
+
+    def run(self, program, G):
+        m, Z, B = self.m, self.Z, self.B
+        C_, K, rw = m["C"], m["K"], m["rw"]
+        epi = ops.EPI_NONE if m["linear"] else ops.EPI_TANH_BWD
+        for op in reversed(program):
+            if op.kind != 0:
+                raise RuntimeError("training with config.scale == 1 is not supported on the HIP path")
+            h, w = op.h, op.w
+            n = Z * h * w
+            base = self.saved[op.saved_off:op.saved_off + n * (2 + 3 * C_)]
+            srcv = base[:n]
+            skip = base[n:2 * n].view(self.P, B, 1, h, w)
+            t1 = base[2 * n:(2 + C_) * n].view(self.P, B, C_, h, w)
+            t2 = base[(2 + C_) * n:(2 + 2 * C_) * n].view(self.P, B, C_, h, w)
+            t3 = base[(2 + 2 * C_) * n:(2 + 3 * C_) * n].view(self.P, B, C_, h, w)
+            view = lambda buf, off, sz, sy, sx: ops.View(G[buf].data_ptr() + 4 * off, sz, sy, sx)
+            g = torch.empty(self.P, B, 1, h, w, device=srcv.device, dtype=torch.float32)
+            ops.lift_bwd_pre(view(op.buf_dout, op.off_dout, op.sz_dout, op.sy_dout, op.sx_dout),
+                             view(op.buf_din, op.off_din, op.sz_din, op.sy_din, op.sx_din), g, Z, h, w)
+            blk, u, vert = op.block, op.is_u, bool(op.vertical)
+            Wb = {k: v[blk, u] for k, v in self.W.items()}
+            dWb = {k: v[blk, u] for k, v in self.dW.items()}
+            alpha = op.sign * rw
+            swap = not vert
+            # conv4: net = conv4(t3)
+            dt3 = ops.conv2d(g, Wb["w4"], None, K, transposed=True, packed=self._pack("w4", blk, u, vert))
+            ops.conv2d_wgrad(t3, g, tuple(Wb["w4"].shape), K, dw=dWb["w4"], db=dWb["b4"], alpha=alpha, swap_hw=swap)
+            # conv3 (+ residual r): t3 = conv3(t2) + r
+            dpre2 = ops.conv2d(dt3, Wb["w3"], None, K, transposed=True, packed=self._pack("w3", blk, u, vert), aux=t2,
+                               epi=epi)
+            ops.conv2d_wgrad(t2, dt3, tuple(Wb["w3"].shape), K, dw=dWb["w3"], db=dWb["b3"], alpha=alpha, swap_hw=swap)
+            # conv2: t2 = tanh(conv2(t1)); dr = dt1 * tanh'(r) + dt3
+            dr = ops.conv2d(dpre2, Wb["w2"], None, K, transposed=True, packed=self._pack("w2", blk, u, vert), aux=t1,
+                            epi=epi, residual=dt3)
+            ops.conv2d_wgrad(t1, dpre2, tuple(Wb["w2"].shape), K, dw=dWb["w2"], db=dWb["b2"], alpha=alpha, swap_hw=swap)
+            # conv1: r = conv1(skip)
+            dsk = ops.conv2d(dr, Wb["w1"], None, K, transposed=True, packed=self._pack("w1", blk, u, vert))
+            ops.conv2d_wgrad(skip, dr, tuple(Wb["w1"].shape), K, dw=dWb["w1"], db=dWb["b1"], alpha=alpha, swap_hw=swap)
+            ops.lift_bwd_fin(g, dsk, srcv, view(op.buf_src, op.off_src, op.sz_src, op.sy_src, op.sx_src), Z, B, h, w,
+                             self.taps[op.tap], self.dtaps[op.tap],
+                             vert, op.sign, rw)
+
+
+_W_KEYS = ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")
+
+
+def _grad_buffers(P, B, H, W, levels, dev):
+    Z = P * B
+    half, quarter = Z * (H // 2) * W, Z * (H // 2) * (W // 2)
+    G = {}
+    for b in (_BUF_LROW, _BUF_HROW, _BUF_TMPL, _BUF_TMPH):
+        G[b] = torch.empty(half, device=dev, dtype=torch.float32)
+    for b in (_BUF_LL0, _BUF_LL1):
+        G[b] = torch.empty(quarter, device=dev, dtype=torch.float32)
+    return G
+
+
+class LiftingFn(torch.autograd.Function):
+    """x (P,B,1,H,W) -> (ll, yh_0..yh_{L-1}); parameters: taps (4,P,3) and the 8 stacked P/U-block tensors
+    (nblocks,2,P,...).  Forward = lldwt_lifting_forward_train; backward = reversed step program."""
+
+    @staticmethod
+    def forward(ctx, x, taps, meta, *Wt):
+        W = dict(zip(_W_KEYS, Wt))
+        P, B, _, H, Wd = x.shape
+        nblocks = Wt[0].shape[0]
+        prog, nsaved = ops.lifting_program(P * B, H, Wd, meta["levels"], meta["different"], 0, False, meta["C"])
+        saved = torch.empty(nsaved, device=x.device, dtype=torch.float32)
+        packed = _pack_forward(W, nblocks)
+        ll, yh = ops.lifting_forward_train(x, taps, packed, meta["levels"], meta["C"], meta["K"], meta["rw"], meta["linear"],
+                                           meta["different"], 0, saved)
+        ctx.save_for_backward(taps, saved, *Wt)
+        ctx.meta, ctx.prog, ctx.shape = meta, prog, (P, B, H, Wd)
+        return (ll, *yh)
+
+    @staticmethod
+    def backward(ctx, g_ll, *g_yh):
+        taps, saved, *Wt = ctx.saved_tensors
+        W = dict(zip(_W_KEYS, Wt))
+        P, B, H, Wd = ctx.shape
+        L = ctx.meta["levels"]
+        G = _grad_buffers(P, B, H, Wd, L, taps.device)
+        G[_BUF_X] = torch.empty(P, B, 1, H, Wd, device=taps.device, dtype=torch.float32)
+        G[_BUF_LL] = g_ll.contiguous().clone()
+        for i in range(L):
+            G[_BUF_YH0 + i] = g_yh[i].contiguous().clone()
+        bw = _LiftBackward(ctx.meta, taps, W, saved, P, B, H, Wd)
+        bw.run(ctx.prog, G)
+        return (G[_BUF_X], bw.dtaps, None, *[bw.dW[k] for k in _W_KEYS])
+
+
+class LiftingInvFn(torch.autograd.Function):
+    """(ll, yh_0..yh_{L-1}) -> x (inverse transform); same parameters as LiftingFn."""
+
+    @staticmethod
+    def forward(ctx, taps, meta, nlev, *rest):
+        ll, yh, Wt = rest[0], list(rest[1:1 + nlev]), rest[1 + nlev:]
+        W = dict(zip(_W_KEYS, Wt))
+        P, B, _, hl, wl = ll.shape
+        H, Wd = hl << nlev, wl << nlev
+        nblocks = Wt[0].shape[0]
+        off = 2 * nlev if meta["different"] else 0     # lifting_dwt_nets.py:718-722
+        prog, nsaved = ops.lifting_program(P * B, H, Wd, nlev, False, off, True, meta["C"])
+        saved = torch.empty(nsaved, device=ll.device, dtype=torch.float32)
+        packed = _pack_forward(W, nblocks)
+        x = ops.lifting_inverse_train(ll.contiguous(), [t.contiguous() for t in yh], taps, packed, meta["C"], meta["K"],
+                                      meta["rw"], meta["linear"], off, saved)
+        ctx.save_for_backward(taps, saved, *Wt)
+        ctx.meta, ctx.prog, ctx.shape, ctx.nlev = meta, prog, (P, B, H, Wd), nlev
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        taps, saved, *Wt = ctx.saved_tensors
+        W = dict(zip(_W_KEYS, Wt))
+        P, B, H, Wd = ctx.shape
+        L = ctx.nlev
+        G = _grad_buffers(P, B, H, Wd, L, taps.device)
+        G[_BUF_X] = gx.contiguous().clone()
+        G[_BUF_LL] = torch.empty(P, B, 1, H >> L, Wd >> L, device=taps.device, dtype=torch.float32)
+        for i in range(L):
+            G[_BUF_YH0 + i] = torch.empty(P, B, 3, H >> (i + 1), Wd >> (i + 1), device=taps.device, dtype=torch.float32)
+        bw = _LiftBackward(ctx.meta, taps, W, saved, P, B, H, Wd)
+        bw.run(ctx.prog, G)
+        return (bw.dtaps, None, None, G[_BUF_LL], *[G[_BUF_YH0 + i] for i in range(L)], *[bw.dW[k] for k in _W_KEYS])

@@ -26,6 +26,7 @@ struct WgradArgs {
     lldwt_conv_desc d;
     int batch, h, w, ntaps, zsplit;
     int n_total;       // cin_g * ntaps
+    float alpha;
     int8_t tdy[25], tdx[25];
     int8_t tap_of[25];
 };
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
                 const int ocl = oc0 + m * 16 + 4 * kk + r;
                 if (ocl < cout_g) {
                     const int oc = g * cout_g + ocl;
-                    atomicAdd(dwp + ((int64_t)oc * cin_g + icl) * KK + tap, acc[m][j][r]);
+                    atomicAdd(dwp + ((int64_t)oc * cin_g + icl) * KK + tap, a.alpha * acc[m][j][r]);
                 }
             }
     }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
 
 // dbias[plane][oc] += sum over batch, pixels of dy (read through the output placement)
 __global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dy, float* __restrict__ db, lldwt_conv_desc d,
-                                                   int batch, int64_t hw) {
+                                                   int batch, int64_t hw, float alpha) {
     __shared__ float part[4];
     const int oc = blockIdx.x, plane = blockIdx.z, b = blockIdx.y;
     const int ocp = (oc / d.oc_block) * d.oc_stride + d.oc_off + oc % d.oc_block;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dy,
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(db + plane * d.cout + oc, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) atomicAdd(db + plane * d.cout + oc, alpha * (part[0] + part[1] + part[2] + part[3]));
 }
 
 __global__ void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, int64_t n,
@@ -228,6 +229,12 @@ using namespace lldwt;
 
 extern "C" int lldwt_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const lldwt_conv_desc* d,
                                   int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream) {
+    return lldwt_conv2d_wgrad_ex(x, dy, dw, dbias, d, planes, batch, h, w_, 1.0f, 0, stream);
+}
+
+extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, float* dbias, const lldwt_conv_desc* d,
+                                     int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw,
+                                     void* stream) {
     LLDWT_REQUIRE(x && dy && dw && d, "conv2d_wgrad: null pointer");
     LLDWT_REQUIRE(d->K == 1 || d->K == 3 || d->K == 5, "conv2d_wgrad: K=%d unsupported", d->K);
     LLDWT_REQUIRE(d->groups > 0 && d->cin % d->groups == 0 && d->cout % d->groups == 0, "conv2d_wgrad: bad groups");
@@ -238,14 +245,14 @@ extern "C" int lldwt_conv2d_wgrad(const float* x, const float* dy, float* dw, fl
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw; a.d = *d;
-    a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
+    a.batch = (int)batch; a.h = (int)h; a.w = (int)w_; a.alpha = alpha;
     const int KK = d->K * d->K, P = d->K / 2;
     int nt = 0;
     for (int t = 0; t < KK; ++t)
         if ((d->tap_mask >> t) & 1u) {
             a.tdy[nt] = (int8_t)(t / d->K);        // offset inside the halo patch (patch origin = tile origin - R)
             a.tdx[nt] = (int8_t)(t % d->K);
-            a.tap_of[nt] = (int8_t)t;
+            a.tap_of[nt] = (int8_t)(swap_hw ? (t % d->K) * d->K + t / d->K : t);
             ++nt;
         }
     (void)P;
@@ -266,7 +273,7 @@ extern "C" int lldwt_conv2d_wgrad(const float* x, const float* dy, float* dw, fl
     if (r) return r;
     if (dbias) {
         dim3 grid((unsigned)d->cout, (unsigned)batch, (unsigned)planes);
-        hipLaunchKernelGGL(k_bias_grad, grid, dim3(256), 0, st, dy, dbias, *d, (int)batch, h * w_);
+        hipLaunchKernelGGL(k_bias_grad, grid, dim3(256), 0, st, dy, dbias, *d, (int)batch, h * w_, alpha);
         return check_launch("bias_grad");
     }
     return 0;

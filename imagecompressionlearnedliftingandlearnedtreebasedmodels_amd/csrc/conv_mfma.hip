@@ -63,7 +63,8 @@ static inline ConvPlan make_plan(const lldwt_conv_desc& d) {
 }
 
 // packed[plane][group][ocb][chunk][live tap][s][m][lane]; lane = kk*16 + ocl
-__global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ packed, lldwt_conv_desc d, ConvPlan p) {
+__global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ packed, lldwt_conv_desc d, ConvPlan p,
+                            int swap_hw) {
     const int plane = blockIdx.y;
     const int cin_g = d.cin / d.groups, cout_g = d.cout / d.groups, KK = d.K * d.K;
     const float* wp = w + (int64_t)plane * d.cout * cin_g * KK;
@@ -90,6 +91,7 @@ __global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ pac
         float v = 0.f;
         if (ocl < cout_g && ic < cin_g && tap >= 0) {
             const int oc = g * cout_g + ocl;
+            if (swap_hw) tap = (tap % d.K) * d.K + tap / d.K;      // effective tap (dy,dx) reads W[..][dx][dy]
             v = d.transposed ? wp[((int64_t)(g * cin_g + ic) * cout_g + ocl) * KK + (KK - 1 - tap)]   // (cin, cout/groups, K, K)
                              : wp[((int64_t)oc * cin_g + ic) * KK + tap];
         }
@@ -327,13 +329,19 @@ extern "C" int64_t lldwt_conv_packed_floats(const lldwt_conv_desc* d) {
 }
 
 extern "C" int lldwt_conv_pack(const float* w, float* packed, const lldwt_conv_desc* d, int64_t planes, void* stream) {
+    return lldwt_conv_pack_ex(w, packed, d, planes, 0, stream);
+}
+
+extern "C" int lldwt_conv_pack_ex(const float* w, float* packed, const lldwt_conv_desc* d, int64_t planes, int swap_hw,
+                                  void* stream) {
     int r = conv_desc_ok("conv_pack", d, planes, 1, 2, 2);
     if (r) return r;
     LLDWT_REQUIRE(w && packed, "conv_pack: null pointer");
     const ConvPlan p = make_plan(*d);
     int64_t gx = cdiv(p.plane_floats, 256);
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)gx, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, w, packed, *d, p);
+    hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)gx, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, w, packed, *d, p,
+                       swap_hw);
     return check_launch("conv_pack");
 }
 

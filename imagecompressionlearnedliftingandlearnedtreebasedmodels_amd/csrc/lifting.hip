@@ -121,6 +121,7 @@ __device__ __forceinline__ void conv_cc(const float (*__restrict__ t)[ROWS][PITC
 // ---- kernel A: skip filter, conv1+act (LDS), conv2+act -> t2; also stores skip --------------------------------
 template <int C, int K>
 __global__ __launch_bounds__(NT) void k_lift_a(CView src, float* __restrict__ skip_out, float* __restrict__ t2_out,
+                                               float* __restrict__ t1_out, float* __restrict__ src_out,
                                                int batch, int h, int w, const float* __restrict__ taps,
                                                const float* __restrict__ packed, int64_t packed_plane_stride,
                                                int vertical, int linear) {
@@ -148,7 +149,10 @@ __global__ __launch_bounds__(NT) void k_lift_a(CView src, float* __restrict__ sk
             const float b = ld_view(src, z, gy, gx, h, w);
             const float c = ld_view(src, z, gy + ddy, gx + ddx, h, w);
             v = tp0 * a + tp1 * b + tp2 * c;
-            if (ly >= R2 && ly < R2 + TH && lx >= R2 && lx < R2 + TW) skip_out[(z * h + gy) * (int64_t)w + gx] = v;
+            if (ly >= R2 && ly < R2 + TH && lx >= R2 && lx < R2 + TW) {
+                skip_out[(z * h + gy) * (int64_t)w + gx] = v;
+                if (src_out) src_out[(z * h + gy) * (int64_t)w + gx] = b;     // training: kept for d(taps)
+            }
         }
         s_lds[ly][lx] = v;
     }
@@ -172,8 +176,13 @@ __global__ __launch_bounds__(NT) void k_lift_a(CView src, float* __restrict__ sk
                     for (int oc = 0; oc < C; ++oc) acc[oc] = fmaf(wt[oc], v, acc[oc]);
                 }
         }
+        const bool centre = t1_out && in && ly >= R && ly < R + TH && lx >= R && lx < R + TW;
 #pragma unroll
-        for (int oc = 0; oc < C; ++oc) t1[oc][ly][lx] = in ? act_apply(acc[oc], act) : 0.f;
+        for (int oc = 0; oc < C; ++oc) {
+            const float tv = in ? act_apply(acc[oc], act) : 0.f;
+            t1[oc][ly][lx] = tv;
+            if (centre) t1_out[(z * C + oc) * ((int64_t)h * w) + (int64_t)gy * w + gx] = tv;   // training: kept for backward
+        }
     }
     __syncthreads();
     const int ly = tid / TW, lx = tid % TW;
@@ -321,30 +330,93 @@ __global__ void k_scale_view(CView in, lldwt_view out, int batch, int h, int w, 
 
 static inline CView cv(lldwt_view v) { return CView{v.p, v.sz, v.sy, v.sx}; }
 
+// ---- backward helpers of one lifting step -------------------------------------------------------------------
+// g = G[dst_out] (view) copied to a dense (Z,h,w) tensor; G[dst_in] = g ("set": the step passes dst through unchanged)
+__global__ void k_lift_bwd_pre(CView gout, lldwt_view gdin, float* __restrict__ g, int h, int w) {
+    const int64_t z = blockIdx.z;
+    for (int y = blockIdx.y; y < h; y += gridDim.y)
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+            const float v = gout.p[z * gout.sz + (int64_t)y * gout.sy + (int64_t)x * gout.sx];
+            g[(z * h + y) * (int64_t)w + x] = v;
+            gdin.p[z * gdin.sz + (int64_t)y * gdin.sy + (int64_t)x * gdin.sx] = v;
+        }
+}
+
+// dskip = sign*(g + rw*dsk);  G[src] += taps^T (x) dskip  (transpose of the zero-padded 3-tap filter);
+// dtaps[k] += sum dskip[p] * src[p + k - 1]
+__global__ __launch_bounds__(256) void k_lift_bwd_fin(const float* __restrict__ g, const float* __restrict__ dsk,
+                                                      const float* __restrict__ srcv, lldwt_view gsrc, int batch, int h,
+                                                      int w, const float* __restrict__ taps, float* __restrict__ dtaps,
+                                                      int vertical, float sign, float rw) {
+    __shared__ float part[3][4];
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const float t0 = taps[plane * 3 + 0], t1 = taps[plane * 3 + 1], t2 = taps[plane * 3 + 2];
+    const int ddy = vertical ? 1 : 0, ddx = vertical ? 0 : 1;
+    const int64_t base = z * (int64_t)h * w;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int y = blockIdx.y; y < h; y += gridDim.y)
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+            auto dskip = [&](int yy, int xx) -> float {
+                if (yy < 0 || yy >= h || xx < 0 || xx >= w) return 0.f;
+                const int64_t i = base + (int64_t)yy * w + xx;
+                return sign * (g[i] + rw * dsk[i]);
+            };
+            auto sv = [&](int yy, int xx) -> float {
+                return (yy < 0 || yy >= h || xx < 0 || xx >= w) ? 0.f : srcv[base + (int64_t)yy * w + xx];
+            };
+            const float dm = dskip(y - ddy, x - ddx), d0 = dskip(y, x), dp = dskip(y + ddy, x + ddx);
+            // skip[p] = t0*src[p-1] + t1*src[p] + t2*src[p+1]  =>  dsrc[p] = t0*dskip[p+1] + t1*dskip[p] + t2*dskip[p-1]
+            gsrc.p[z * gsrc.sz + (int64_t)y * gsrc.sy + (int64_t)x * gsrc.sx] += t0 * dp + t1 * d0 + t2 * dm;
+            a0 += d0 * sv(y - ddy, x - ddx);
+            a1 += d0 * sv(y, x);
+            a2 += d0 * sv(y + ddy, x + ddx);
+        }
+    float acc[3] = {a0, a1, a2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicAdd(dtaps + plane * 3 + threadIdx.x,
+                  part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3]);
+}
+
+
+// where one step keeps its intermediates (training: a per-step slice of the caller's `saved` buffer)
+struct StepBufs {
+    float* skip;   // (Z,h,w)
+    float* t2;     // (Z,C,h,w)
+    float* t3;     // (Z,C,h,w)
+    float* t1;     // (Z,C,h,w) or null
+    float* srcv;   // (Z,h,w)   or null
+};
+
 template <int C, int K>
 static int launch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, int64_t Z, int64_t batch, int64_t h,
                        int64_t w, const float* taps, const float* packed, int64_t pstride, int vertical, float sign,
-                       float rw, int linear, float* ws, hipStream_t st) {
-    float* skip = ws;
-    float* t2 = skip + Z * h * w;
-    float* t3 = t2 + Z * C * h * w;
+                       float rw, int linear, const StepBufs& b, hipStream_t st) {
     dim3 grid((unsigned)cdiv(w, TW), (unsigned)cdiv(h, TH), (unsigned)Z), block(NT);
-    hipLaunchKernelGGL((k_lift_a<C, K>), grid, block, 0, st, cv(src), skip, t2, (int)batch, (int)h, (int)w, taps, packed,
-                       pstride, vertical, linear);
-    hipLaunchKernelGGL((k_lift_b<C, K>), grid, block, 0, st, skip, t2, t3, (int)batch, (int)h, (int)w, packed, pstride,
-                       vertical);
-    hipLaunchKernelGGL((k_lift_c<C, K>), grid, block, 0, st, skip, t3, cv(dst_in), dst_out, (int)batch, (int)h, (int)w,
-                       packed, pstride, vertical, sign, rw);
+    hipLaunchKernelGGL((k_lift_a<C, K>), grid, block, 0, st, cv(src), b.skip, b.t2, b.t1, b.srcv, (int)batch, (int)h,
+                       (int)w, taps, packed, pstride, vertical, linear);
+    hipLaunchKernelGGL((k_lift_b<C, K>), grid, block, 0, st, b.skip, b.t2, b.t3, (int)batch, (int)h, (int)w, packed,
+                       pstride, vertical);
+    hipLaunchKernelGGL((k_lift_c<C, K>), grid, block, 0, st, b.skip, b.t3, cv(dst_in), dst_out, (int)batch, (int)h,
+                       (int)w, packed, pstride, vertical, sign, rw);
     return check_launch("lift_step");
 }
 
 static int dispatch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, int64_t Z, int64_t batch, int64_t h,
                          int64_t w, const float* taps, const float* packed, int64_t pstride, int C, int K, int vertical,
-                         float sign, float rw, int linear, float* ws, hipStream_t st) {
+                         float sign, float rw, int linear, const StepBufs& b, hipStream_t st) {
 #define LLDWT_CASE(CC, KK_)                                                                                         \
     if (C == CC && K == KK_)                                                                                        \
         return launch_step<CC, KK_>(src, dst_in, dst_out, Z, batch, h, w, taps, packed, pstride, vertical, sign, rw, \
-                                    linear, ws, st);
+                                    linear, b, st);
     LLDWT_CASE(16, 5)
     LLDWT_CASE(16, 3)
     LLDWT_CASE(8, 5)
@@ -354,67 +426,171 @@ static int dispatch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, 
     return LLDWT_EINVAL;
 }
 
-static inline lldwt_view mkview(float* p, int64_t sz, int64_t sy, int64_t sx) { return lldwt_view{p, sz, sy, sx}; }
+static inline StepBufs ws_bufs(float* ws, int64_t Z, int64_t h, int64_t w, int C) {
+    StepBufs b;
+    b.skip = ws;
+    b.t2 = ws + Z * h * w;
+    b.t3 = b.t2 + Z * C * h * w;
+    b.t1 = nullptr;
+    b.srcv = nullptr;
+    return b;
+}
 
-struct LiftCtx {
-    int64_t Z, batch;
+// per-step slice of the training `saved` buffer: [srcv | skip | t1 | t2 | t3]
+static inline int64_t saved_step_floats(int64_t Z, int64_t h, int64_t w, int C) { return Z * h * w * (2 + 3 * (int64_t)C); }
+static inline StepBufs saved_bufs(float* base, int64_t Z, int64_t h, int64_t w, int C) {
+    StepBufs b;
+    const int64_t n = Z * h * w;
+    b.srcv = base;
+    b.skip = base + n;
+    b.t1 = b.skip + n;
+    b.t2 = b.t1 + n * C;
+    b.t3 = b.t2 + n * C;
+    return b;
+}
+
+// ---- the transform as a program of lifting steps over symbolic buffers ------------------------------------------------
+enum { B_X = 0, B_LROW, B_HROW, B_TMPL, B_TMPH, B_LL0, B_LL1, B_LL, B_YH0 };
+
+struct SymView {
+    int buf;
+    int64_t off, sz, sy, sx;
+};
+static inline SymView sv(int buf, int64_t off, int64_t sz, int64_t sy, int64_t sx) { return SymView{buf, off, sz, sy, sx}; }
+
+static void push_op(lldwt_lift_op* ops, int& n, int max_ops, int kind, SymView src, SymView din, SymView dout, int64_t h,
+                    int64_t w, int vertical, int tap, int block, int is_u, float sign, int64_t& saved_off, int64_t Z,
+                    int C) {
+    if (n < max_ops) {
+        lldwt_lift_op& o = ops[n];
+        o.kind = kind;
+        o.buf_src = src.buf; o.off_src = src.off; o.sz_src = src.sz; o.sy_src = src.sy; o.sx_src = src.sx;
+        o.buf_din = din.buf; o.off_din = din.off; o.sz_din = din.sz; o.sy_din = din.sy; o.sx_din = din.sx;
+        o.buf_dout = dout.buf; o.off_dout = dout.off; o.sz_dout = dout.sz; o.sy_dout = dout.sy; o.sx_dout = dout.sx;
+        o.h = (int32_t)h; o.w = (int32_t)w; o.vertical = vertical; o.tap = tap; o.block = block; o.is_u = is_u;
+        o.sign = sign; o.saved_off = saved_off;
+    }
+    if (kind == 0) saved_off += saved_step_floats(Z, h, w, C);
+    ++n;
+}
+
+// 2-stage lifting on symbolic (L,H) -> (Lout,Hout) (wavelet_forward_v2.py:58-74 / wavelet_inverse_v2.py:76-90)
+static void two_stage(lldwt_lift_op* ops, int& n, int max_ops, bool inverse, SymView L, SymView H, SymView Lout,
+                      SymView Hout, SymView tL, SymView tH, int64_t hh, int64_t ww, int vertical, int blk,
+                      int64_t& so, int64_t Z, int C) {
+    if (!inverse) {
+        push_op(ops, n, max_ops, 0, L, H, tH, hh, ww, vertical, 0, blk + 0, 0, 1.f, so, Z, C);        // :60-62
+        push_op(ops, n, max_ops, 0, tH, L, tL, hh, ww, vertical, 1, blk + 0, 1, 1.f, so, Z, C);       // :64-66
+        push_op(ops, n, max_ops, 0, tL, tH, Hout, hh, ww, vertical, 2, blk + 1, 0, 1.f, so, Z, C);    // :68-70
+        push_op(ops, n, max_ops, 0, Hout, tL, Lout, hh, ww, vertical, 3, blk + 1, 1, 1.f, so, Z, C);  // :72-74
+    } else {
+        push_op(ops, n, max_ops, 0, H, L, tL, hh, ww, vertical, 3, blk + 1, 1, -1.f, so, Z, C);       // :76-78
+        push_op(ops, n, max_ops, 0, tL, H, tH, hh, ww, vertical, 2, blk + 1, 0, -1.f, so, Z, C);      // :80-82
+        push_op(ops, n, max_ops, 0, tH, tL, Lout, hh, ww, vertical, 1, blk + 0, 1, -1.f, so, Z, C);   // :84-86
+        push_op(ops, n, max_ops, 0, Lout, tH, Hout, hh, ww, vertical, 0, blk + 0, 0, -1.f, so, Z, C); // :88-90
+    }
+}
+
+// scale ops (config.scale == 1): kind 1 = dout = src * nh, 2 = * nl, 3 = / nh, 4 = / nl (per plane)
+static void push_scale(lldwt_lift_op* ops, int& n, int max_ops, int kind, SymView src, SymView dout, int64_t h, int64_t w) {
+    int64_t dummy = 0;
+    push_op(ops, n, max_ops, kind, src, src, dout, h, w, 0, 0, 0, 0, 1.f, dummy, 0, 0);
+}
+
+static int build_program(lldwt_lift_op* ops, int max_ops, int64_t Z, int64_t H, int64_t W, int levels, int different,
+                         int block_offset, int inverse, int scale, int C, int64_t* saved_total) {
+    int n = 0;
+    int64_t so = 0;
+    if (!inverse) {
+        for (int lev = 0; lev < levels; ++lev) {
+            const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2, sub = hh * wh;
+            const int blk = block_offset + (different ? lev * 2 : 0);
+            const int bin = lev == 0 ? B_X : (((lev - 1) & 1) ? B_LL1 : B_LL0);
+            const int bll = lev == levels - 1 ? B_LL : ((lev & 1) ? B_LL1 : B_LL0);
+            const int byh = B_YH0 + lev;
+            SymView A = sv(bin, 0, h * w, 2 * w, 1), Bv = sv(bin, w, h * w, 2 * w, 1);         // rows (wavelet_forward_v2.py:27-29)
+            SymView vL = sv(B_LROW, 0, hh * w, w, 1), vH = sv(B_HROW, 0, hh * w, w, 1);
+            SymView tL = sv(B_TMPL, 0, hh * w, w, 1), tH = sv(B_TMPH, 0, hh * w, w, 1);
+            two_stage(ops, n, max_ops, false, A, Bv, vL, vH, tL, tH, hh, w, 1, blk, so, Z, C);
+            if (scale) { push_scale(ops, n, max_ops, 1, vH, vH, hh, w); push_scale(ops, n, max_ops, 2, vL, vL, hh, w); }
+            SymView vLL = sv(bll, 0, sub, wh, 1);
+            SymView vLH = sv(byh, 0, 3 * sub, wh, 1), vHL = sv(byh, sub, 3 * sub, wh, 1), vHH = sv(byh, 2 * sub, 3 * sub, wh, 1);
+            SymView t2L = sv(B_TMPL, 0, sub, wh, 1), t2H = sv(B_TMPH, 0, sub, wh, 1);
+            SymView Le = sv(B_LROW, 0, hh * w, w, 2), Lo = sv(B_LROW, 1, hh * w, w, 2);          // columns of L (:32-39)
+            two_stage(ops, n, max_ops, false, Le, Lo, vLL, vHL, t2L, t2H, hh, wh, 0, blk, so, Z, C);
+            if (scale) { push_scale(ops, n, max_ops, 1, vHL, vHL, hh, wh); push_scale(ops, n, max_ops, 2, vLL, vLL, hh, wh); }
+            SymView He = sv(B_HROW, 0, hh * w, w, 2), Ho = sv(B_HROW, 1, hh * w, w, 2);          // columns of H (:43-51)
+            two_stage(ops, n, max_ops, false, He, Ho, vLH, vHH, t2L, t2H, hh, wh, 0, blk, so, Z, C);
+            if (scale) { push_scale(ops, n, max_ops, 1, vHH, vHH, hh, wh); push_scale(ops, n, max_ops, 2, vLH, vLH, hh, wh); }
+        }
+    } else {
+        const int blk = block_offset;       // lifting_dwt_nets.py:718-722: every inverse level uses the same pair
+        for (int lev = levels - 1; lev >= 0; --lev) {
+            const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2, sub = hh * wh;
+            const int bin = lev == levels - 1 ? B_LL : ((lev & 1) ? B_LL0 : B_LL1);   // written by level lev+1 into llbuf[(lev+1)&1]
+            const int bout = lev == 0 ? B_X : ((lev & 1) ? B_LL1 : B_LL0);
+            const int byh = B_YH0 + lev;
+            SymView vLL = sv(bin, 0, sub, wh, 1);
+            SymView vLH = sv(byh, 0, 3 * sub, wh, 1), vHL = sv(byh, sub, 3 * sub, wh, 1), vHH = sv(byh, 2 * sub, 3 * sub, wh, 1);
+            SymView t2L = sv(B_TMPL, 0, sub, wh, 1), t2H = sv(B_TMPH, 0, sub, wh, 1);
+            SymView inL = vLL, inH = vHL;
+            // scratch for the scaled copies (config.scale == 1, wavelet_inverse_v2.py:70-74): second halves of tmpL/tmpH
+            SymView sL = sv(B_TMPL, Z * (H / 2) * W / 2, sub, wh, 1), sH = sv(B_TMPH, Z * (H / 2) * W / 2, sub, wh, 1);
+            if (scale) { push_scale(ops, n, max_ops, 4, vLL, sL, hh, wh); push_scale(ops, n, max_ops, 3, vHL, sH, hh, wh); inL = sL; inH = sH; }
+            SymView Le = sv(B_LROW, 0, hh * w, w, 2), Lo = sv(B_LROW, 1, hh * w, w, 2);          // (LL,HL) -> L (:21-26)
+            two_stage(ops, n, max_ops, true, inL, inH, Le, Lo, t2L, t2H, hh, wh, 0, blk, so, Z, C);
+            inL = vLH; inH = vHH;
+            if (scale) { push_scale(ops, n, max_ops, 4, vLH, sL, hh, wh); push_scale(ops, n, max_ops, 3, vHH, sH, hh, wh); inL = sL; inH = sH; }
+            SymView He = sv(B_HROW, 0, hh * w, w, 2), Ho = sv(B_HROW, 1, hh * w, w, 2);          // (LH,HH) -> H (:28-33)
+            two_stage(ops, n, max_ops, true, inL, inH, He, Ho, t2L, t2H, hh, wh, 0, blk, so, Z, C);
+            SymView vL = sv(B_LROW, 0, hh * w, w, 1), vH = sv(B_HROW, 0, hh * w, w, 1);
+            SymView tL = sv(B_TMPL, 0, hh * w, w, 1), tH = sv(B_TMPH, 0, hh * w, w, 1);
+            SymView A = sv(bout, 0, h * w, 2 * w, 1), Bv = sv(bout, w, h * w, 2 * w, 1);        // (L,H) -> rows (:35-37)
+            if (scale) { push_scale(ops, n, max_ops, 4, vL, vL, hh, w); push_scale(ops, n, max_ops, 3, vH, vH, hh, w); }
+            two_stage(ops, n, max_ops, true, vL, vH, A, Bv, tL, tH, hh, w, 1, blk, so, Z, C);
+        }
+    }
+    if (saved_total) *saved_total = so;
+    return n;
+}
+
+static inline lldwt_view resolve(float* const* bases, int buf, int64_t off, int64_t sz, int64_t sy, int64_t sx) {
+    return lldwt_view{bases[buf] + off, sz, sy, sx};
+}
+
+struct RunCtx {
+    int64_t Z, batch, planes;
     const float* taps;     // (4,planes,3)
-    int64_t tstride;       // planes*3
     const float* packed;   // (planes,nblocks,2,total)
-    int64_t pstride;       // floats per plane
-    int64_t total;         // floats per block
+    int64_t pstride, total;
     int C, K, linear;
     float rw;
+    const float* nh;
+    const float* nl;
     float* step_ws;
+    float* saved;          // training: per-step intermediates, or null
     hipStream_t st;
 };
 
-// 2-stage lifting on (L,H) half arrays given as views; writes final L to Lout, final H to Hout; tmpL/tmpH scratch
-// views (contiguous, hh x ww).  blk = index of the first of the two (P,U) block pairs.
-static int two_stage_forward(const LiftCtx& c, lldwt_view L, lldwt_view H, lldwt_view Lout, lldwt_view Hout,
-                             lldwt_view tmpL, lldwt_view tmpH, int64_t hh, int64_t ww, int vertical, int blk) {
-    auto P = [&](int s) { return c.packed + (int64_t)(blk + s) * 2 * c.total; };
-    auto U = [&](int s) { return c.packed + (int64_t)(blk + s) * 2 * c.total + c.total; };
-    int r;
-    // wavelet_forward_v2.py:60-62  H = H + skip(L) + P0(skip)*rw
-    if ((r = dispatch_step(L, H, tmpH, c.Z, c.batch, hh, ww, c.taps + 0 * c.tstride, P(0), c.pstride, c.C, c.K, vertical, 1.f, c.rw,
-                           c.linear, c.step_ws, c.st)))
-        return r;
-    // :64-66  L = L + skip(H) + U0(skip)*rw
-    if ((r = dispatch_step(tmpH, L, tmpL, c.Z, c.batch, hh, ww, c.taps + 1 * c.tstride, U(0), c.pstride, c.C, c.K, vertical, 1.f,
-                           c.rw, c.linear, c.step_ws, c.st)))
-        return r;
-    // :68-70
-    if ((r = dispatch_step(tmpL, tmpH, Hout, c.Z, c.batch, hh, ww, c.taps + 2 * c.tstride, P(1), c.pstride, c.C, c.K, vertical, 1.f,
-                           c.rw, c.linear, c.step_ws, c.st)))
-        return r;
-    // :72-74
-    return dispatch_step(Hout, tmpL, Lout, c.Z, c.batch, hh, ww, c.taps + 3 * c.tstride, U(1), c.pstride, c.C, c.K, vertical, 1.f,
-                         c.rw, c.linear, c.step_ws, c.st);
-}
-
-// inverse (wavelet_inverse_v2.py:76-90): inputs L,H (hh x ww); final L' -> Lout, final H' -> Hout
-static int two_stage_inverse(const LiftCtx& c, lldwt_view L, lldwt_view H, lldwt_view Lout, lldwt_view Hout,
-                             lldwt_view tmpL, lldwt_view tmpH, int64_t hh, int64_t ww, int vertical, int blk) {
-    auto P = [&](int s) { return c.packed + (int64_t)(blk + s) * 2 * c.total; };
-    auto U = [&](int s) { return c.packed + (int64_t)(blk + s) * 2 * c.total + c.total; };
-    int r;
-    if ((r = dispatch_step(H, L, tmpL, c.Z, c.batch, hh, ww, c.taps + 3 * c.tstride, U(1), c.pstride, c.C, c.K, vertical, -1.f, c.rw,
-                           c.linear, c.step_ws, c.st)))
-        return r;
-    if ((r = dispatch_step(tmpL, H, tmpH, c.Z, c.batch, hh, ww, c.taps + 2 * c.tstride, P(1), c.pstride, c.C, c.K, vertical, -1.f,
-                           c.rw, c.linear, c.step_ws, c.st)))
-        return r;
-    if ((r = dispatch_step(tmpH, tmpL, Lout, c.Z, c.batch, hh, ww, c.taps + 1 * c.tstride, U(0), c.pstride, c.C, c.K, vertical, -1.f,
-                           c.rw, c.linear, c.step_ws, c.st)))
-        return r;
-    return dispatch_step(Lout, tmpH, Hout, c.Z, c.batch, hh, ww, c.taps + 0 * c.tstride, P(0), c.pstride, c.C, c.K, vertical, -1.f,
-                         c.rw, c.linear, c.step_ws, c.st);
-}
-
-static void scale_view(const LiftCtx& c, lldwt_view v, int64_t hh, int64_t ww, const float* s, int divide) {
-    dim3 grid((unsigned)cdiv(ww, 256), (unsigned)(hh < 1024 ? hh : 1024), (unsigned)c.Z);
-    hipLaunchKernelGGL(k_scale_view, grid, dim3(256), 0, c.st, cv(v), v, (int)c.batch, (int)hh, (int)ww, s, divide);
+static int run_program(const lldwt_lift_op* ops, int n, float* const* bases, const RunCtx& c) {
+    for (int i = 0; i < n; ++i) {
+        const lldwt_lift_op& o = ops[i];
+        lldwt_view src = resolve(bases, o.buf_src, o.off_src, o.sz_src, o.sy_src, o.sx_src);
+        lldwt_view dout = resolve(bases, o.buf_dout, o.off_dout, o.sz_dout, o.sy_dout, o.sx_dout);
+        if (o.kind != 0) {
+            const float* f = (o.kind == 1 || o.kind == 3) ? c.nh : c.nl;
+            dim3 grid((unsigned)cdiv(o.w, 256), (unsigned)(o.h < 1024 ? o.h : 1024), (unsigned)c.Z);
+            hipLaunchKernelGGL(k_scale_view, grid, dim3(256), 0, c.st, cv(src), dout, (int)c.batch, o.h, o.w, f, o.kind >= 3);
+            continue;
+        }
+        lldwt_view din = resolve(bases, o.buf_din, o.off_din, o.sz_din, o.sy_din, o.sx_din);
+        const float* pk = c.packed + ((int64_t)o.block * 2 + o.is_u) * c.total;
+        const StepBufs b = c.saved ? saved_bufs(c.saved + o.saved_off, c.Z, o.h, o.w, c.C) : ws_bufs(c.step_ws, c.Z, o.h, o.w, c.C);
+        int r = dispatch_step(src, din, dout, c.Z, c.batch, o.h, o.w, c.taps + (int64_t)o.tap * c.planes * 3, pk, c.pstride,
+                              c.C, c.K, o.vertical, o.sign, c.rw, c.linear, b, c.st);
+        if (r) return r;
+    }
+    return check_launch("lifting program");
 }
 
 }  // namespace lldwt
@@ -451,7 +627,27 @@ extern "C" int lldwt_lift_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst
         return LLDWT_EWS;
     }
     return dispatch_step(src, dst_in, dst_out, Z, batch, h, w, taps, packed, pack_off(C, K).total, C, K, vertical, sign,
-                         res_weight, linear, (float*)ws, (hipStream_t)stream);
+                         res_weight, linear, ws_bufs((float*)ws, Z, h, w, C), (hipStream_t)stream);
+}
+
+// backward pieces of one step, exposed so that the host can chain them with the conv engine (see autograd.py)
+extern "C" int lldwt_lift_bwd_pre(lldwt_view g_dst_out, lldwt_view g_dst_in, float* g, int64_t Z, int64_t h, int64_t w,
+                                  void* stream) {
+    LLDWT_REQUIRE(g_dst_out.p && g_dst_in.p && g && Z > 0 && Z <= 65535 && h > 0 && w > 0, "lift_bwd_pre: bad arguments");
+    dim3 grid((unsigned)cdiv(w, 256), (unsigned)(h < 1024 ? h : 1024), (unsigned)Z);
+    hipLaunchKernelGGL(k_lift_bwd_pre, grid, dim3(256), 0, (hipStream_t)stream, cv(g_dst_out), g_dst_in, g, (int)h, (int)w);
+    return check_launch("lift_bwd_pre");
+}
+
+extern "C" int lldwt_lift_bwd_fin(const float* g, const float* dsk, const float* srcv, lldwt_view g_src, int64_t Z,
+                                  int64_t batch, int64_t h, int64_t w, const float* taps, float* dtaps, int vertical,
+                                  float sign, float res_weight, void* stream) {
+    LLDWT_REQUIRE(g && dsk && srcv && g_src.p && taps && dtaps && Z > 0 && Z <= 65535 && batch > 0 && h > 0 && w > 0,
+                  "lift_bwd_fin: bad arguments");
+    dim3 grid((unsigned)cdiv(w, 256), (unsigned)(h < 64 ? h : 64), (unsigned)Z);
+    hipLaunchKernelGGL(k_lift_bwd_fin, grid, dim3(256), 0, (hipStream_t)stream, g, dsk, srcv, g_src, (int)batch, (int)h,
+                       (int)w, taps, dtaps, vertical, sign, res_weight);
+    return check_launch("lift_bwd_fin");
 }
 
 // workspace: [Lrow | Hrow | tmpL | tmpH] (each Z*(H/2)*W) + 2 LL ping-pong (Z*(H/2)*(W/2)) + step ws
@@ -469,58 +665,56 @@ static int lifting_args_ok(const char* who, int64_t planes, int64_t batch, int64
     return 0;
 }
 
+extern "C" int lldwt_lifting_program(lldwt_lift_op* ops, int max_ops, int64_t Z, int64_t H, int64_t W, int levels,
+                                     int different, int block_offset, int inverse, int scale, int C,
+                                     int64_t* saved_floats) {
+    LLDWT_REQUIRE(levels > 0 && levels < 16 && Z > 0 && H > 0 && W > 0, "lifting_program: bad arguments");
+    return build_program(ops, ops ? max_ops : 0, Z, H, W, levels, different, block_offset, inverse, scale, C, saved_floats);
+}
+
+static int lifting_run(const char* who, int inverse, float* x, float* ll, float* const* yh, int64_t planes, int64_t batch,
+                       int64_t H, int64_t W, int levels, const float* taps, const float* packed, int nblocks,
+                       int block_offset, int different, int C, int K, float res_weight, int linear, const float* scale_nh,
+                       const float* scale_nl, void* ws, int64_t ws_bytes, float* saved, void* stream) {
+    int r = lifting_args_ok(who, planes, batch, H, W, levels);
+    if (r) return r;
+    LLDWT_REQUIRE(x && ll && yh && taps && packed && ws, "%s: null pointer", who);
+    LLDWT_REQUIRE(nblocks >= 2 && block_offset >= 0 && block_offset + ((different && !inverse) ? 2 * levels : 2) <= nblocks,
+                  "%s: block_offset=%d exceeds nblocks=%d", who, block_offset, nblocks);
+    LLDWT_REQUIRE(!(saved && scale_nh), "%s: training with config.scale == 1 is not supported", who);
+    const int64_t Z = planes * batch;
+    if (ws_bytes < lldwt_lifting_ws_bytes(Z, H, W, C)) {
+        set_error("%s: workspace %ld < %ld bytes", who, (long)ws_bytes, (long)lldwt_lifting_ws_bytes(Z, H, W, C));
+        return LLDWT_EWS;
+    }
+    const int64_t half = Z * (H / 2) * W, quarter = Z * (H / 2) * (W / 2);
+    float* bases[B_YH0 + 16];
+    float* base = (float*)ws;
+    bases[B_X] = x;
+    bases[B_LROW] = base;
+    bases[B_HROW] = base + half;
+    bases[B_TMPL] = base + 2 * half;
+    bases[B_TMPH] = base + 3 * half;
+    bases[B_LL0] = base + 4 * half;
+    bases[B_LL1] = base + 4 * half + quarter;
+    bases[B_LL] = ll;
+    for (int i = 0; i < levels; ++i) bases[B_YH0 + i] = yh[i];
+    lldwt_lift_op ops[16 * 3 * 8 + 8];
+    const int n = build_program(ops, (int)(sizeof(ops) / sizeof(ops[0])), Z, H, W, levels, different, block_offset, inverse,
+                                scale_nh != nullptr, C, nullptr);
+    RunCtx c{Z, batch, planes, taps, packed, (int64_t)nblocks * 2 * pack_off(C, K).total, pack_off(C, K).total, C, K,
+             linear, res_weight, scale_nh, scale_nl, base + 4 * half + 2 * quarter, saved, (hipStream_t)stream};
+    return run_program(ops, n, bases, c);
+}
+
 extern "C" int lldwt_lifting_forward(const float* x, float* ll, float* const* yh, int64_t planes, int64_t batch,
                                      int64_t H, int64_t W, int levels, const float* taps, const float* packed,
                                      int nblocks, int block_offset, int different, int C, int K, float res_weight,
                                      int linear, const float* scale_nh, const float* scale_nl, void* ws,
                                      int64_t ws_bytes, void* stream) {
-    int r = lifting_args_ok("lifting_forward", planes, batch, H, W, levels);
-    LLDWT_REQUIRE(nblocks >= 2 && block_offset >= 0 && block_offset + (different ? 2 * levels : 2) <= nblocks,
-                  "lifting_forward: block_offset=%d (+%d) exceeds nblocks=%d", block_offset, different ? 2 * levels : 2, nblocks);
-    if (r) return r;
-    LLDWT_REQUIRE(x && ll && yh && taps && packed && ws, "lifting_forward: null pointer");
-    const int64_t Z = planes * batch;
-    if (ws_bytes < lldwt_lifting_ws_bytes(Z, H, W, C)) {
-        set_error("lifting_forward: workspace %ld < %ld bytes", (long)ws_bytes, (long)lldwt_lifting_ws_bytes(Z, H, W, C));
-        return LLDWT_EWS;
-    }
-    const int64_t half = Z * (H / 2) * W, quarter = Z * (H / 2) * (W / 2);
-    float* Lrow = (float*)ws;
-    float* Hrow = Lrow + half;
-    float* tmpL = Hrow + half;
-    float* tmpH = tmpL + half;
-    float* llbuf[2] = {tmpH + half, tmpH + half + quarter};
-    LiftCtx c{Z, batch, taps, planes * 3, packed, (int64_t)nblocks * 2 * pack_off(C, K).total, pack_off(C, K).total, C, K, linear,
-              res_weight, llbuf[1] + quarter, (hipStream_t)stream};
-    const float* cur = x;
-    for (int lev = 0; lev < levels; ++lev) {
-        const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2;
-        const int blk = block_offset + (different ? lev * 2 : 0);
-        float* X = const_cast<float*>(cur);
-        // rows: L = x[0::2], H = x[1::2]  (wavelet_forward_v2.py:27-29)
-        lldwt_view A = mkview(X, h * w, 2 * w, 1), B = mkview(X + w, h * w, 2 * w, 1);
-        lldwt_view vL = mkview(Lrow, hh * w, w, 1), vH = mkview(Hrow, hh * w, w, 1);
-        lldwt_view tL = mkview(tmpL, hh * w, w, 1), tH = mkview(tmpH, hh * w, w, 1);
-        if ((r = two_stage_forward(c, A, B, vL, vH, tL, tH, hh, w, 1, blk))) return r;
-        if (scale_nh) { scale_view(c, vH, hh, w, scale_nh, 0); scale_view(c, vL, hh, w, scale_nl, 0); }
-        // columns of L: LL = L[:, 0::2], HL = L[:, 1::2]  (:32-39)
-        float* llout = (lev == levels - 1) ? ll : llbuf[lev & 1];
-        float* y = yh[lev];
-        const int64_t sub = hh * wh;
-        lldwt_view vLL = mkview(llout, sub, wh, 1);
-        lldwt_view vLH = mkview(y, 3 * sub, wh, 1), vHL = mkview(y + sub, 3 * sub, wh, 1),
-                   vHH = mkview(y + 2 * sub, 3 * sub, wh, 1);
-        lldwt_view t2L = mkview(tmpL, sub, wh, 1), t2H = mkview(tmpH, sub, wh, 1);
-        lldwt_view Le = mkview(Lrow, hh * w, w, 2), Lo = mkview(Lrow + 1, hh * w, w, 2);
-        if ((r = two_stage_forward(c, Le, Lo, vLL, vHL, t2L, t2H, hh, wh, 0, blk))) return r;
-        if (scale_nh) { scale_view(c, vHL, hh, wh, scale_nh, 0); scale_view(c, vLL, hh, wh, scale_nl, 0); }
-        // columns of H: LH = H[:, 0::2], HH = H[:, 1::2]  (:43-51)
-        lldwt_view He = mkview(Hrow, hh * w, w, 2), Ho = mkview(Hrow + 1, hh * w, w, 2);
-        if ((r = two_stage_forward(c, He, Ho, vLH, vHH, t2L, t2H, hh, wh, 0, blk))) return r;
-        if (scale_nh) { scale_view(c, vHH, hh, wh, scale_nh, 0); scale_view(c, vLH, hh, wh, scale_nl, 0); }
-        cur = llout;
-    }
-    return check_launch("lifting_forward");
+    return lifting_run("lifting_forward", 0, const_cast<float*>(x), ll, yh, planes, batch, H, W, levels, taps, packed,
+                       nblocks, block_offset, different, C, K, res_weight, linear, scale_nh, scale_nl, ws, ws_bytes,
+                       nullptr, stream);
 }
 
 extern "C" int lldwt_lifting_inverse(const float* ll, const float* const* yh, float* x, int64_t planes, int64_t batch,
@@ -528,68 +722,30 @@ extern "C" int lldwt_lifting_inverse(const float* ll, const float* const* yh, fl
                                      int nblocks, int block_offset, int C, int K, float res_weight, int linear,
                                      const float* scale_nh, const float* scale_nl, void* ws, int64_t ws_bytes,
                                      void* stream) {
-    int r = lifting_args_ok("lifting_inverse", planes, batch, H, W, levels);
-    LLDWT_REQUIRE(nblocks >= 2 && block_offset >= 0 && block_offset + 2 <= nblocks,
-                  "lifting_inverse: block_offset=%d exceeds nblocks=%d", block_offset, nblocks);
-    if (r) return r;
-    LLDWT_REQUIRE(x && ll && yh && taps && packed && ws, "lifting_inverse: null pointer");
-    const int64_t Z = planes * batch;
-    if (ws_bytes < lldwt_lifting_ws_bytes(Z, H, W, C)) {
-        set_error("lifting_inverse: workspace %ld < %ld bytes", (long)ws_bytes, (long)lldwt_lifting_ws_bytes(Z, H, W, C));
-        return LLDWT_EWS;
-    }
-    const int64_t half = Z * (H / 2) * W, quarter = Z * (H / 2) * (W / 2);
-    float* Lrow = (float*)ws;
-    float* Hrow = Lrow + half;
-    float* tmpL = Hrow + half;
-    float* tmpH = tmpL + half;
-    float* llbuf[2] = {tmpH + half, tmpH + half + quarter};
-    LiftCtx c{Z, batch, taps, planes * 3, packed, (int64_t)nblocks * 2 * pack_off(C, K).total, pack_off(C, K).total, C, K, linear,
-              res_weight, llbuf[1] + quarter, (hipStream_t)stream};
-    const int blk = block_offset;   // lifting_dwt_nets.py:718-722: every inverse level uses the same pair
-    const float* cur = ll;
-    for (int lev = levels - 1; lev >= 0; --lev) {
-        const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2;
-        const int64_t sub = hh * wh;
-        float* y = const_cast<float*>(yh[lev]);
-        lldwt_view vLL = mkview(const_cast<float*>(cur), sub, wh, 1);
-        lldwt_view vLH = mkview(y, 3 * sub, wh, 1), vHL = mkview(y + sub, 3 * sub, wh, 1),
-                   vHH = mkview(y + 2 * sub, 3 * sub, wh, 1);
-        lldwt_view t2L = mkview(tmpL, sub, wh, 1), t2H = mkview(tmpH, sub, wh, 1);
-        float* out = (lev == 0) ? x : llbuf[lev & 1];
-        // scaled copies when config.scale == 1 (wavelet_inverse_v2.py:70-74): use the tail of Lrow/Hrow as scratch
-        lldwt_view inL = vLL, inH = vHL;
-        float* sc0 = llbuf[(lev & 1) ^ 1];     // free ping-pong buffer (>= sub floats per z)
-        if (scale_nh) {
-            lldwt_view sL = mkview(sc0, sub, wh, 1), sH = mkview(tmpH + half - Z * sub, sub, wh, 1);
-            hipLaunchKernelGGL(k_scale_view, dim3((unsigned)cdiv(wh, 256), (unsigned)(hh < 1024 ? hh : 1024), (unsigned)Z),
-                               dim3(256), 0, c.st, cv(vLL), sL, (int)batch, (int)hh, (int)wh, scale_nl, 1);
-            hipLaunchKernelGGL(k_scale_view, dim3((unsigned)cdiv(wh, 256), (unsigned)(hh < 1024 ? hh : 1024), (unsigned)Z),
-                               dim3(256), 0, c.st, cv(vHL), sH, (int)batch, (int)hh, (int)wh, scale_nh, 1);
-            inL = sL; inH = sH;
-        }
-        // (LL,HL) -> L : even/odd columns of Lrow  (wavelet_inverse_v2.py:21-26)
-        lldwt_view Le = mkview(Lrow, hh * w, w, 2), Lo = mkview(Lrow + 1, hh * w, w, 2);
-        if ((r = two_stage_inverse(c, inL, inH, Le, Lo, t2L, t2H, hh, wh, 0, blk))) return r;
-        inL = vLH; inH = vHH;
-        if (scale_nh) {
-            lldwt_view sL = mkview(sc0, sub, wh, 1), sH = mkview(tmpH + half - Z * sub, sub, wh, 1);
-            hipLaunchKernelGGL(k_scale_view, dim3((unsigned)cdiv(wh, 256), (unsigned)(hh < 1024 ? hh : 1024), (unsigned)Z),
-                               dim3(256), 0, c.st, cv(vLH), sL, (int)batch, (int)hh, (int)wh, scale_nl, 1);
-            hipLaunchKernelGGL(k_scale_view, dim3((unsigned)cdiv(wh, 256), (unsigned)(hh < 1024 ? hh : 1024), (unsigned)Z),
-                               dim3(256), 0, c.st, cv(vHH), sH, (int)batch, (int)hh, (int)wh, scale_nh, 1);
-            inL = sL; inH = sH;
-        }
-        // (LH,HH) -> H  (:28-33)
-        lldwt_view He = mkview(Hrow, hh * w, w, 2), Ho = mkview(Hrow + 1, hh * w, w, 2);
-        if ((r = two_stage_inverse(c, inL, inH, He, Ho, t2L, t2H, hh, wh, 0, blk))) return r;
-        // (L,H) -> rows of the output (:35-37)
-        lldwt_view vL = mkview(Lrow, hh * w, w, 1), vH = mkview(Hrow, hh * w, w, 1);
-        lldwt_view tL = mkview(tmpL, hh * w, w, 1), tH = mkview(tmpH, hh * w, w, 1);
-        lldwt_view A = mkview(out, h * w, 2 * w, 1), B = mkview(out + w, h * w, 2 * w, 1);
-        if (scale_nh) { scale_view(c, vL, hh, w, scale_nl, 1); scale_view(c, vH, hh, w, scale_nh, 1); }
-        if ((r = two_stage_inverse(c, vL, vH, A, B, tL, tH, hh, w, 1, blk))) return r;
-        cur = out;
-    }
-    return check_launch("lifting_inverse");
+    return lifting_run("lifting_inverse", 1, x, const_cast<float*>(ll), const_cast<float* const*>(yh), planes, batch, H, W,
+                       levels, taps, packed, nblocks, block_offset, 0, C, K, res_weight, linear, scale_nh, scale_nl, ws,
+                       ws_bytes, nullptr, stream);
+}
+
+// training variants: identical arithmetic, every step keeps (src, skip, t1, t2, t3) in `saved`
+// (lldwt_lifting_program reports the size and the per-step offsets)
+extern "C" int lldwt_lifting_forward_train(const float* x, float* ll, float* const* yh, int64_t planes, int64_t batch,
+                                           int64_t H, int64_t W, int levels, const float* taps, const float* packed,
+                                           int nblocks, int block_offset, int different, int C, int K, float res_weight,
+                                           int linear, void* ws, int64_t ws_bytes, float* saved, void* stream) {
+    LLDWT_REQUIRE(saved, "lifting_forward_train: null saved buffer");
+    return lifting_run("lifting_forward_train", 0, const_cast<float*>(x), ll, yh, planes, batch, H, W, levels, taps, packed,
+                       nblocks, block_offset, different, C, K, res_weight, linear, nullptr, nullptr, ws, ws_bytes, saved,
+                       stream);
+}
+
+extern "C" int lldwt_lifting_inverse_train(const float* ll, const float* const* yh, float* x, int64_t planes,
+                                           int64_t batch, int64_t H, int64_t W, int levels, const float* taps,
+                                           const float* packed, int nblocks, int block_offset, int C, int K,
+                                           float res_weight, int linear, void* ws, int64_t ws_bytes, float* saved,
+                                           void* stream) {
+    LLDWT_REQUIRE(saved, "lifting_inverse_train: null saved buffer");
+    return lifting_run("lifting_inverse_train", 1, x, const_cast<float*>(ll), const_cast<float* const*>(yh), planes, batch,
+                       H, W, levels, taps, packed, nblocks, block_offset, 0, C, K, res_weight, linear, nullptr, nullptr, ws,
+                       ws_bytes, saved, stream);
 }

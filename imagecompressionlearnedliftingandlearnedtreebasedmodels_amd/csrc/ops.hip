@@ -266,6 +266,45 @@ __global__ __launch_bounds__(256) void k_gauss_rate(const float* __restrict__ x,
     if (bit_sum) block_accumulate(local, bit_sum);
 }
 
+// backward of k_gauss_rate (training: v = x + noise).  With p = Phi(u) - Phi(l), u = (.5-a)/s, l = (-.5-a)/s, a = |v-mu|,
+// s = LowerBound(0.11)(sigma), bits = -log2(LowerBound(1e-9)(p)); both LowerBounds use the pass-through rule of
+// utils/bound_ops.py:26-28.  dparams gets (dsigma, dmu) interleaved like params.
+__global__ __launch_bounds__(256) void k_gauss_rate_bwd(const float* __restrict__ x, const float* __restrict__ params,
+                                                        const float* __restrict__ noise, const float* __restrict__ gbits,
+                                                        float* __restrict__ dx, float* __restrict__ dparams, int C,
+                                                        int64_t hw, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t zc = i / hw, p = i - zc * hw;
+        const int64_t z = zc / C;
+        const int c = (int)(zc - z * C);
+        const int64_t is = (z * 2 * C + 2 * c) * hw + p, im = is + hw;
+        const float sg = params[is], mu = params[im];
+        const float xv = x[i];
+        const bool train = noise != nullptr;
+        const float v = train ? xv + noise[i] : rintf(xv - mu) + mu;
+        const float dlt = v - mu;
+        const float a = fabsf(dlt);
+        const float s = fmaxf(sg, 0.11f);
+        const float u = (0.5f - a) / s, l = (-0.5f - a) / s;
+        const float cst = -0.70710678118654752440f;
+        const float pr = 0.5f * erfcf(cst * u) - 0.5f * erfcf(cst * l);
+        const float pb = fmaxf(pr, 1e-9f);
+        const float g = gbits[i];
+        float gp = -g / (pb * 0.69314718055994530942f);            // d bits / d p_bounded
+        if (!(pr >= 1e-9f || gp < 0.f)) gp = 0.f;                  // LowerBound(1e-9) gradient rule
+        const float inv = 0.39894228040143267794f;                 // 1/sqrt(2 pi)
+        const float phu = inv * expf(-0.5f * u * u), phl = inv * expf(-0.5f * l * l);
+        const float dpda = (phl - phu) / s;
+        float gs = gp * (l * phl - u * phu) / s;                   // d/ds
+        if (!(sg >= 0.11f || gs < 0.f)) gs = 0.f;                  // LowerBound(0.11) gradient rule
+        const float sgn = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+        const float gv = train ? gp * dpda * sgn : 0.f;            // eval: round() has zero gradient, v - mu is constant
+        dx[i] = gv;
+        dparams[is] = gs;
+        dparams[im] = -gv;
+    }
+}
+
 __global__ void k_quantize(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ q, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         q[i] = noise ? x[i] + noise[i] : rintf(x[i]);
@@ -511,3 +550,45 @@ extern "C" int lldwt_sum(const float* x, int64_t n, double* out, void* stream) {
     return check_launch("sum");
 }
 
+
+extern "C" int lldwt_gauss_rate_bwd(const float* x, const float* params, const float* noise, const float* gbits, float* dx,
+                                    float* dparams, int64_t Z, int C, int64_t hw, void* stream) {
+    LLDWT_REQUIRE(x && params && gbits && dx && dparams && Z > 0 && C > 0 && hw > 0, "gauss_rate_bwd: bad arguments");
+    const int64_t n = Z * C * hw;
+    hipLaunchKernelGGL(k_gauss_rate_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, params, noise, gbits, dx,
+                       dparams, C, hw, n);
+    return check_launch("gauss_rate_bwd");
+}
+
+// out[i] = alpha * a[i] + beta * b[i]  (b may be null); used for d(mse), d(sum) and the colour-transform backward glue
+__global__ void k_axpby(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n,
+                        float alpha, float beta) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+extern "C" int lldwt_axpby(const float* a, const float* b, float* out, int64_t n, float alpha, float beta, void* stream) {
+    LLDWT_REQUIRE(a && out && n >= 0, "axpby: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_axpby, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, alpha, beta);
+    return check_launch("axpby");
+}
+
+// backward of lldwt_ycc_to_rgb (no clamp): grgb (B,3,hw) -> gycc plane-major (3,B,hw); transpose of the BT.709 matrix
+__global__ void k_ycc_to_rgb_bwd(const float* __restrict__ grgb, float* __restrict__ gycc, int64_t B, int64_t hw) {
+    const int64_t n = B * hw;
+    const float cr_r = 2.f - 2.f * KR, cb_b = 2.f - 2.f * KB;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / hw, p = i - b * hw;
+        const float gr = grgb[(b * 3 + 0) * hw + p], gg = grgb[(b * 3 + 1) * hw + p], gb = grgb[(b * 3 + 2) * hw + p];
+        // r = y + cr_r*(cr-.5); b = y + cb_b*(cb-.5); g = (y - KR*r - KB*b)/KG
+        const float gr_t = gr - gg * KR / KG, gb_t = gb - gg * KB / KG;     // total grads wrt r and b
+        gycc[(0 * B + b) * hw + p] = gg / KG + gr_t + gb_t;
+        gycc[(1 * B + b) * hw + p] = gb_t * cb_b;
+        gycc[(2 * B + b) * hw + p] = gr_t * cr_r;
+    }
+}
+extern "C" int lldwt_ycc_to_rgb_bwd(const float* grgb, float* gycc, int64_t B, int64_t H, int64_t W, void* stream) {
+    LLDWT_REQUIRE(grgb && gycc && B > 0 && H > 0 && W > 0, "ycc_to_rgb_bwd: bad arguments");
+    hipLaunchKernelGGL(k_ycc_to_rgb_bwd, dim3(ew_grid(B * H * W)), dim3(256), 0, (hipStream_t)stream, grgb, gycc, B, H * W);
+    return check_launch("ycc_to_rgb_bwd");
+}

@@ -186,7 +186,7 @@ def flip_mask(mask, K):
     return sum(1 << (KK - 1 - t) for t in range(KK) if (mask >> t) & 1)
 
 
-def conv_pack(w, K, groups=1, transposed=False, tap_mask=None):
+def conv_pack(w, K, groups=1, transposed=False, tap_mask=None, swap_hw=False):
     """(P,cout,cin/groups,K,K) -> packed (P, floats) in MFMA A-operand order.  transposed: the weight is in
     ConvTranspose2d layout (P,cin,cout/groups,K,K) (or a forward Conv2d weight used for its backward-data pass:
     then `cin` is the forward cout) and the taps are flipped; tap_mask refers to the effective (flipped) taps."""
@@ -199,7 +199,7 @@ def conv_pack(w, K, groups=1, transposed=False, tap_mask=None):
     d = conv_desc(cin, cout, K, groups, transposed=transposed, tap_mask=tap_mask)
     n = lib.lldwt_conv_packed_floats(C.byref(d))
     packed = torch.empty(P, n, device=w.device, dtype=torch.float32)
-    check(lib.lldwt_conv_pack(_chk(w, "w"), _chk(packed), C.byref(d), P, _stream()), "conv_pack")
+    check(lib.lldwt_conv_pack_ex(_chk(w, "w"), _chk(packed), C.byref(d), P, int(bool(swap_hw)), _stream()), "conv_pack")
     return packed
 
 
@@ -236,17 +236,19 @@ def conv2d(x, w, bias, K, groups=1, act=ACT_NONE, upsample2=False, transposed=Fa
 
 
 def conv2d_wgrad(x, dy, wshape, K, groups=1, upsample2=False, tap_mask=None, want_bias=True, oc_block=None, oc_stride=0,
-                 oc_off=0, ic_block=0, ic_stride=0, ic_off=0):
+                 oc_off=0, ic_block=0, ic_stride=0, ic_off=0, dw=None, db=None, alpha=1.0, swap_hw=False):
     """-> (dw (P,cout,cin/groups,K,K), dbias (P,cout) or None); dy: (P,B,ytot,h,w) read through the output placement."""
     lib = _lib.load()
     P, B, ytot, h, wd = dy.shape
     cout, cin = wshape[1], wshape[2] * groups
-    dw = torch.zeros(wshape, device=x.device, dtype=torch.float32)
-    db = torch.zeros(P, cout, device=x.device, dtype=torch.float32) if want_bias else None
+    if dw is None:
+        dw = torch.zeros(wshape, device=x.device, dtype=torch.float32)
+    if db is None and want_bias:
+        db = torch.zeros(P, cout, device=x.device, dtype=torch.float32)
     d = conv_desc(cin, cout, K, groups, 0, upsample2, False, tap_mask, oc_block, oc_stride, oc_off, ytot, ic_block,
                   ic_stride, ic_off, x.shape[2] if ic_block else 0, 0)
-    check(lib.lldwt_conv2d_wgrad(_chk(x, "x"), _chk(dy, "dy"), _chk(dw), _opt(db), C.byref(d), P, B, h, wd, _stream()),
-          "conv2d_wgrad")
+    check(lib.lldwt_conv2d_wgrad_ex(_chk(x, "x"), _chk(dy, "dy"), _chk(dw), _opt(db), C.byref(d), P, B, h, wd,
+                                    float(alpha), int(bool(swap_hw)), _stream()), "conv2d_wgrad")
     return dw, db
 
 
@@ -362,3 +364,81 @@ def sq_err_sum(a, b, out):
 
 def sum_into(x, out):
     check(_lib.load().lldwt_sum(_chk(x), x.numel(), C.c_void_p(out.data_ptr()), _stream()), "sum")
+
+
+# ------------------------------------------------------------------------------------------------ training support
+def gauss_rate_bwd(x, params, noise, gbits):
+    P, B, Cc, h, w = x.shape
+    dx = torch.empty_like(x)
+    dparams = torch.empty_like(params)
+    check(_lib.load().lldwt_gauss_rate_bwd(_chk(x), _chk(params), _opt(noise), _chk(gbits), _chk(dx), _chk(dparams), P * B,
+                                           Cc, h * w, _stream()), "gauss_rate_bwd")
+    return dx, dparams
+
+
+def axpby(a, b, alpha, beta=0.0):
+    out = torch.empty_like(a)
+    check(_lib.load().lldwt_axpby(_chk(a), _opt(b), _chk(out), a.numel(), float(alpha), float(beta), _stream()), "axpby")
+    return out
+
+
+def ycc_to_rgb_bwd(grgb):
+    B, _, H, W = grgb.shape
+    g = torch.empty(3, B, 1, H, W, device=grgb.device, dtype=torch.float32)
+    check(_lib.load().lldwt_ycc_to_rgb_bwd(_chk(grgb), _chk(g), B, H, W, _stream()), "ycc_to_rgb_bwd")
+    return g
+
+
+def lifting_program(Z, H, W, levels, different, block_offset, inverse, Cc):
+    """-> (list of LiftOp, saved_floats): the step program of the transform (include/lldwt.h lldwt_lifting_program)."""
+    lib = _lib.load()
+    tot = C.c_int64(0)
+    n = lib.lldwt_lifting_program(None, 0, Z, H, W, levels, int(bool(different)), block_offset, int(bool(inverse)), 0, Cc,
+                                  C.byref(tot))
+    if n < 0:
+        check(n, "lifting_program")
+    arr = (_lib.LiftOp * n)()
+    lib.lldwt_lifting_program(arr, n, Z, H, W, levels, int(bool(different)), block_offset, int(bool(inverse)), 0, Cc,
+                              C.byref(tot))
+    return list(arr), int(tot.value)
+
+
+def lifting_forward_train(x, taps, packed, levels, Cc, K, res_weight, linear, different, block_offset, saved):
+    lib = _lib.load()
+    P, B, _, H, W = x.shape
+    dev = x.device
+    ll = torch.empty(P, B, 1, H >> levels, W >> levels, device=dev, dtype=torch.float32)
+    yh = [torch.empty(P, B, 3, H >> (i + 1), W >> (i + 1), device=dev, dtype=torch.float32) for i in range(levels)]
+    nb = lib.lldwt_lifting_ws_bytes(P * B, H, W, Cc)
+    ws = workspace(nb, dev)
+    check(lib.lldwt_lifting_forward_train(_chk(x, "x"), _chk(ll), _ptr_array(yh), P, B, H, W, levels, _chk(taps),
+                                          _chk(packed), int(packed.shape[1]), int(block_offset), int(bool(different)), Cc, K,
+                                          float(res_weight), int(bool(linear)), C.c_void_p(ws.data_ptr()), nb,
+                                          _chk(saved), _stream()), "lifting_forward_train")
+    return ll, yh
+
+
+def lifting_inverse_train(ll, yh, taps, packed, Cc, K, res_weight, linear, block_offset, saved):
+    lib = _lib.load()
+    levels = len(yh)
+    P, B, _, hl, wl = ll.shape
+    H, W = hl << levels, wl << levels
+    x = torch.empty(P, B, 1, H, W, device=ll.device, dtype=torch.float32)
+    for t in yh:
+        _chk(t, "yh")
+    nb = lib.lldwt_lifting_ws_bytes(P * B, H, W, Cc)
+    ws = workspace(nb, ll.device)
+    check(lib.lldwt_lifting_inverse_train(_chk(ll), _ptr_array(yh), _chk(x), P, B, H, W, levels, _chk(taps), _chk(packed),
+                                          int(packed.shape[1]), int(block_offset), Cc, K, float(res_weight),
+                                          int(bool(linear)), C.c_void_p(ws.data_ptr()), nb, _chk(saved), _stream()),
+          "lifting_inverse_train")
+    return x
+
+
+def lift_bwd_pre(g_dout, g_din, g, Z, h, w):
+    check(_lib.load().lldwt_lift_bwd_pre(g_dout, g_din, _chk(g), Z, h, w, _stream()), "lift_bwd_pre")
+
+
+def lift_bwd_fin(g, dsk, srcv, g_src, Z, batch, h, w, taps, dtaps, vertical, sign, rw):
+    check(_lib.load().lldwt_lift_bwd_fin(_chk(g), _chk(dsk), _chk(srcv), g_src, Z, batch, h, w, _chk(taps), _chk(dtaps),
+                                         int(vertical), float(sign), float(rw), _stream()), "lift_bwd_fin")

@@ -58,6 +58,8 @@ typedef struct lldwt_view {
  * inverse: ycc -> rgb, then "- 0.5" (agents/liftingDWT_agent.py:94) and optional clamp to [-0.5,0.5] (:181). */
 int lldwt_rgb_to_ycc(const float* rgb, float* ycc, int64_t B, int64_t H, int64_t W, void* stream);
 int lldwt_ycc_to_rgb(const float* ycc, float* rgb, int64_t B, int64_t H, int64_t W, int clamp, void* stream);
+/* backward of lldwt_ycc_to_rgb without clamp (training): grgb (B,3,H,W) -> gycc plane-major (3,B,1,H,W). */
+int lldwt_ycc_to_rgb_bwd(const float* grgb, float* gycc, int64_t B, int64_t H, int64_t W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * P/U block parameters (graphs/layers/P_block_v2.py:15-33) packed for the kernels.
@@ -105,6 +107,41 @@ int lldwt_lifting_inverse(const float* ll, const float* const* yh, float* x, int
                           int block_offset, int C, int K, float res_weight, int linear, const float* scale_nh,
                           const float* scale_nl, void* ws, int64_t ws_bytes, void* stream);
 
+/* Training support of the lifting transform.  The transform is a PROGRAM of lifting steps over symbolic buffers
+ * (0 = x, 1 = Lrow, 2 = Hrow, 3 = tmpL, 4 = tmpH, 5/6 = LL ping-pong, 7 = ll, 8+i = yh[i]); views are
+ * (buffer, element offset, z/row/col strides).  kind 0 = lifting step, 1..4 = per-plane scale (config.scale == 1).
+ * lldwt_lifting_program fills `ops` (pass NULL/0 to count) and reports the floats of the per-step `saved`
+ * intermediates [src | skip | t1 | t2 | t3] kept by the *_train variants; the backward pass walks the program in
+ * reverse over gradient buffers of identical layout (see autograd.py: G[dst_in] = G[dst_out];
+ * G[src] += J^T G[dst_out]; dW/dtaps accumulate).                                                          */
+typedef struct lldwt_lift_op {
+    int32_t kind, buf_src, buf_din, buf_dout;
+    int64_t off_src, sz_src, sy_src, sx_src;
+    int64_t off_din, sz_din, sy_din, sx_din;
+    int64_t off_dout, sz_dout, sy_dout, sx_dout;
+    int32_t h, w, vertical, tap, block, is_u;
+    float sign;
+    int32_t pad_;
+    int64_t saved_off;
+} lldwt_lift_op;
+int lldwt_lifting_program(lldwt_lift_op* ops, int max_ops, int64_t Z, int64_t H, int64_t W, int levels, int different,
+                          int block_offset, int inverse, int scale, int C, int64_t* saved_floats);
+int lldwt_lifting_forward_train(const float* x, float* ll, float* const* yh, int64_t planes, int64_t batch, int64_t H,
+                                int64_t W, int levels, const float* taps, const float* packed, int nblocks,
+                                int block_offset, int different, int C, int K, float res_weight, int linear, void* ws,
+                                int64_t ws_bytes, float* saved, void* stream);
+int lldwt_lifting_inverse_train(const float* ll, const float* const* yh, float* x, int64_t planes, int64_t batch,
+                                int64_t H, int64_t W, int levels, const float* taps, const float* packed, int nblocks,
+                                int block_offset, int C, int K, float res_weight, int linear, void* ws, int64_t ws_bytes,
+                                float* saved, void* stream);
+/* backward pieces of one step (chained by the host with lldwt_conv2d / lldwt_conv2d_wgrad_ex):
+ *   pre: g (dense Z,h,w) = G[dst_out];  G[dst_in] = g
+ *   fin: dskip = sign*(g + res_weight*dsk);  G[src] += taps^T (x) dskip;  dtaps (planes,3) += sum dskip * src shifted */
+int lldwt_lift_bwd_pre(lldwt_view g_dst_out, lldwt_view g_dst_in, float* g, int64_t Z, int64_t h, int64_t w, void* stream);
+int lldwt_lift_bwd_fin(const float* g, const float* dsk, const float* srcv, lldwt_view g_src, int64_t Z, int64_t batch,
+                       int64_t h, int64_t w, const float* taps, float* dtaps, int vertical, float sign, float res_weight,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * SubbandAutoEncoder (lifting_dwt_nets.py:99-110): per-coefficient scalar MLP 1 -> Hd -> Hd -> Hd -> 1, tanh
  * between, grouped 1x1 convs (groups == channels).  x,y: (Z,C,h,w).  Parameters per plane, PyTorch layouts:
@@ -149,6 +186,10 @@ typedef struct lldwt_conv_desc {
  * the activation (P_block_v2.py:53 "tmp + out_res").                                                       */
 int64_t lldwt_conv_packed_floats(const lldwt_conv_desc* d);
 int lldwt_conv_pack(const float* w, float* packed, const lldwt_conv_desc* d, int64_t planes, void* stream);
+/* As lldwt_conv_pack; swap_hw != 0 packs the (kh,kw)-transposed kernel W^T (the horizontal lifting pass:
+ * conv(x^T, W)^T == conv(x, W^T), replaces the torch.transpose calls of wavelet_forward_v2.py:32-51).      */
+int lldwt_conv_pack_ex(const float* w, float* packed, const lldwt_conv_desc* d, int64_t planes, int swap_hw,
+                       void* stream);
 /* y = act( (conv(x) + bias) * epi(aux) + residual ).  transposed != 0 builds the operator from a weight in
  * ConvTranspose2d layout (planes, cin, cout/groups, K, K) with the taps flipped: that is ConvTranspose2d (stride 1)
  * itself and, applied to a forward Conv2d weight with cin/cout swapped, the BACKWARD-DATA pass of that conv.      */
@@ -160,6 +201,11 @@ int lldwt_conv2d(const float* x, float* y, const float* packed, const float* bia
  * placement (oc_*), x through upsample2 / the input placement.  Accumulates with float atomics: zero dw/dbias first. */
 int lldwt_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const lldwt_conv_desc* d,
                        int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+/* As lldwt_conv2d_wgrad with dw += alpha * (...), dbias += alpha * (...); swap_hw != 0: the conv was applied with the
+ * (kh,kw)-transposed kernel, so tap (ky,kx) of the contraction is accumulated into dw[..][kx][ky].        */
+int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, float* dbias, const lldwt_conv_desc* d,
+                          int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw,
+                          void* stream);
 /* dx = dy * act'(y) elementwise (y = forward output); act as in lldwt_conv_desc. */
 int lldwt_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, void* stream);
 /* backward of the nearest-neighbour 2x upsampling: out (Z,C,h/2,w/2) = sum over each 2x2 block of g (Z,C,h,w). */
@@ -189,6 +235,10 @@ int lldwt_nonneg_param_bwd(const float* x, const float* gy, float* gx, int64_t n
  * bit_sum (optional): one device double, accumulated atomically (caller zeroes it).                       */
 int lldwt_gauss_rate(const float* x, const float* params, const float* noise, float* bits, float* qout,
                      double* bit_sum, int64_t Z, int C, int64_t hw, void* stream);
+/* Backward of lldwt_gauss_rate: gbits = dL/dbits -> dx (Z,C,hw) and dparams (Z,2C,hw) = (dsigma, dmu) interleaved;
+ * closed form, both LowerBound pass-through rules (utils/bound_ops.py:26-28) applied.                      */
+int lldwt_gauss_rate_bwd(const float* x, const float* params, const float* noise, const float* gbits, float* dx,
+                         float* dparams, int64_t Z, int C, int64_t hw, void* stream);
 /* quantize(x, mode, means=None): round(x) or x + noise (LiftingBasedDWT_net.py:330,341,352). */
 int lldwt_quantize(const float* x, const float* noise, float* q, int64_t n, void* stream);
 
@@ -217,6 +267,8 @@ int lldwt_factorized_rate(const float* x, const float* eb, const float* noise, f
 /* sum((a-b)^2) and sum(x) into a double (graphs/losses/rate_dist.py:36-41). */
 int lldwt_sq_err_sum(const float* a, const float* b, int64_t n, double* out, void* stream);
 int lldwt_sum(const float* x, int64_t n, double* out, void* stream);
+/* out = alpha*a + beta*b elementwise (b optional): gradient glue of the loss (d mse = 2(xhat-x)/N). */
+int lldwt_axpby(const float* a, const float* b, float* out, int64_t n, float alpha, float beta, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Fixed CDF 9/7 (bior4.4) DWT, periodization (DWTPytorchWaveletsLayer, lifting_dwt_nets.py:228-231,250,274).

@@ -82,3 +82,121 @@ def test_conv_backward_residual_and_large():
     assert maxdiff(xd.grad[0].cpu(), xr.grad) < 1e-4
     assert maxdiff(wd.grad[0].cpu(), wr.grad) < 2e-4 * max(1.0, float(wr.grad.abs().max()))
     assert maxdiff(rd.grad[0].cpu(), rr.grad) < 1e-6
+
+
+def _lift_stacks(sds, nblocks, gu):
+    """oracle per-plane state dicts -> taps (4,P,3) and the 8 stacked tensors (nblocks,2,P,...) on the device."""
+    taps = torch.stack([torch.stack([sd["preProcessingList.%d.weight" % j].reshape(3) for sd in sds], 0) for j in range(4)], 0)
+    W = []
+    for n in (1, 2, 3, 4):
+        for k in ("weight", "bias"):
+            W.append(torch.stack([torch.stack([torch.stack([sd["%s.%d.conv%d.%s" % (kind, b, n, k)] for sd in sds], 0)
+                                               for kind in ("P_blocks", "U_blocks")], 0) for b in range(nblocks)], 0))
+    return gu.dev(taps), [gu.dev(t) for t in W]
+
+
+@pytest.mark.parametrize("K,different,linear", [(5, False, False), (3, True, False), (3, False, True)])
+def test_lifting_forward_backward(K, different, linear):
+    """LiftingFn / LiftingInvFn gradients (input, skip-filter taps, every P/U-block parameter) vs torch autograd on the oracle."""
+    ag, ops, gu = _mods()
+    from helpers import filled
+    from oracle import lifting, model, weights
+    L, P, B, H, W = 2, 2, 2, 16, 32
+    cfg = dict(model.DEFAULT_CFG, dwtlevels=L, filtersize=K, block_property="different" if different else "same",
+               linearity_flag=0 if linear else 1)
+    nblocks = 2 * 2 * L if different else 2
+    sds = [filled(weights.autoencoder_template(cfg), "bw%d." % p) for p in range(P)]
+    meta = dict(levels=L, C=16, K=K, rw=0.1, linear=linear, different=different)
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(P, B, 1, H, W, generator=g) - 0.5
+    taps, Wt = _lift_stacks(sds, nblocks, gu)
+    taps.requires_grad_(True)
+    for t in Wt:
+        t.requires_grad_(True)
+    xd = gu.dev(x).requires_grad_(True)
+    outs = ag.LiftingFn.apply(xd, taps, meta, *Wt)
+    gouts = [torch.rand(o.shape, generator=g) - 0.5 for o in outs]
+    torch.autograd.backward(outs, [gu.dev(t) for t in gouts])
+    # inverse on the same coefficients
+    taps2, Wt2 = _lift_stacks(sds, nblocks, gu)
+    taps2.requires_grad_(True)
+    for t in Wt2:
+        t.requires_grad_(True)
+    cin = [o.detach().clone().requires_grad_(True) for o in outs]
+    xr = ag.LiftingInvFn.apply(taps2, meta, L, *cin, *Wt2)
+    gx = torch.rand(xr.shape, generator=g) - 0.5
+    xr.backward(gu.dev(gx))
+    for p in range(P):
+        sd = {k: v.clone().requires_grad_(True) for k, v in sds[p].items()}
+        xp = x[p].clone().requires_grad_(True)
+        oLL, oYh = lifting.lifting_forward(xp, sd, cfg)
+        ref = [oLL] + [t[:, 0] for t in oYh]
+        for a, b_ in zip(outs, ref):
+            assert maxdiff(a[p].detach().cpu(), b_) < 1e-4
+        torch.autograd.backward(ref, [t[p] for t in gouts])
+        assert maxdiff(xd.grad[p].cpu(), xp.grad) < 2e-4
+        for j in range(4):
+            assert maxdiff(taps.grad[j, p].cpu(), sd["preProcessingList.%d.weight" % j].grad.reshape(3)) < 2e-3
+        idx = 0
+        for n in (1, 2, 3, 4):
+            for k in ("weight", "bias"):
+                for b in range(nblocks):
+                    for u, kind in enumerate(("P_blocks", "U_blocks")):
+                        r = sd["%s.%d.conv%d.%s" % (kind, b, n, k)].grad
+                        got = Wt[idx].grad[b, u, p].cpu()
+                        if r is None:       # block not used by the forward of this configuration
+                            assert float(got.abs().max()) == 0.0
+                        else:
+                            assert maxdiff(got, r) < 5e-4 * max(1.0, float(r.abs().max())), (n, k, b, kind)
+                idx += 1
+        # inverse
+        sd2 = {k: v.clone().requires_grad_(True) for k, v in sds[p].items()}
+        ci = [c[p].detach().cpu().clone().requires_grad_(True) for c in cin]
+        oxr = lifting.lifting_inverse(ci[0], [t.unsqueeze(1) for t in ci[1:]], sd2, cfg)
+        assert maxdiff(xr[p].detach().cpu(), oxr) < 1e-4
+        oxr.backward(gx[p])
+        for a, b_ in zip(cin, ci):
+            assert maxdiff(a.grad[p].cpu(), b_.grad) < 2e-4
+        for j in range(4):
+            assert maxdiff(taps2.grad[j, p].cpu(), sd2["preProcessingList.%d.weight" % j].grad.reshape(3)) < 2e-3
+        r = sd2["U_blocks.%d.conv2.weight" % (2 * L if different else 0)].grad
+        assert maxdiff(Wt2[2].grad[2 * L if different else 0, 1, p].cpu(), r) < 5e-4 * max(1.0, float(r.abs().max()))
+
+
+def test_gauss_rate_backward():
+    ag, ops, gu = _mods()
+    g = torch.Generator().manual_seed(31)
+    P, B, C, h, w = 2, 2, 3, 6, 10
+    x = (torch.rand(P, B, C, h, w, generator=g) - 0.5) * 10
+    params = torch.rand(P, B, 2 * C, h, w, generator=g) * 3 - 0.4          # includes sigma < 0.11 (LowerBound rule)
+    noise = torch.rand(P, B, C, h, w, generator=g) - 0.5
+    gb = torch.rand(P, B, C, h, w, generator=g) - 0.3
+    xd, pd = gu.dev(x).requires_grad_(True), gu.dev(params).requires_grad_(True)
+    bits = ag.GaussRateFn.apply(xd, pd, gu.dev(noise))
+    bits.backward(gu.dev(gb))
+    xr, pr = x.clone().requires_grad_(True), params.clone().requires_grad_(True)
+    for p in range(P):
+        _, lik = entropy.gaussian_conditional_forward(xr[p], pr[p][:, 0::2], pr[p][:, 1::2], True, noise[p])
+        (-torch.log2(lik) * gb[p]).sum().backward()
+    assert maxdiff(xd.grad.cpu(), xr.grad) < 2e-4 * max(1.0, float(xr.grad.abs().max()))
+    assert maxdiff(pd.grad.cpu(), pr.grad) < 2e-4 * max(1.0, float(pr.grad.abs().max()))
+
+
+def test_colour_and_loss_backward():
+    ag, ops, gu = _mods()
+    from oracle import model
+    g = torch.Generator().manual_seed(41)
+    B, H, W = 2, 8, 12
+    ycc = torch.rand(3, B, 1, H, W, generator=g) - 0.5
+    tgt = torch.rand(B, 3, H, W, generator=g) - 0.5
+    yd = gu.dev(ycc).requires_grad_(True)
+    rgb = ag.YccToRgbFn.apply(yd)
+    se = ag.SqErrSumFn.apply(gu.dev(tgt), rgb)
+    (se / rgb.numel()).sum().backward()
+    yr = ycc.clone().requires_grad_(True)
+    rr = model.ycbcr2rgb(yr[:, :, 0].permute(1, 0, 2, 3) + model._YSHIFT) - 0.5
+    torch.mean((tgt - rr) ** 2).backward()
+    assert maxdiff(yd.grad.cpu(), yr.grad) < 1e-6
+    t = gu.dev(torch.rand(3, 4, 5, generator=g)).requires_grad_(True)
+    (ag.SumFn.apply(t) * 0.25).sum().backward()
+    assert maxdiff(t.grad.cpu(), torch.full((3, 4, 5), 0.25)) < 1e-7
