@@ -11,7 +11,9 @@ from torch import optim
 
 from .. import ops
 from ..graphs.losses.rate_dist import TrainDLoss, TrainRDLoss
-from ..graphs.models.LiftingBasedDWT_net import LiftingBasedDWTNetWrapper, forward_planes
+from .. import autograd as ag
+from .. import parallel
+from ..graphs.models.LiftingBasedDWT_net import LiftingBasedDWTNetWrapper, forward_planes, forward_planes_train
 from ..loggers import RDLogger
 from .base import BaseAgent
 
@@ -60,6 +62,7 @@ class LiftingBasedDWTAgent(BaseAgent):
         self.valid_loss = TrainRDLoss(config.lambda_)
         self.train_logger, self.trnit_logger = RDLogger(), RDLogger()
         self.aux_logger, self.valid_logger, self.test_logger = RDLogger(), RDLogger(), RDLogger()
+        self._bucket = None
         if config.mode in ("test", "validate") and "checkpoint_dir" in config:
             self.load_checkpoint("model_best.pth.tar")
         elif config.get("resume_training") and "checkpoint_dir" in config:
@@ -78,10 +81,41 @@ class LiftingBasedDWTAgent(BaseAgent):
         loss, mse, r1, r2 = loss_fn.forward3(xs, xhat, si_xe, si_xo)
         return loss, mse, r1, r2, xhat
 
+    def train_step(self, x, noise_fn=None):
+        """One optimisation step on a batch x (B,3,H,W) in [0,1] (agents/liftingDWT_agent.py:78-98): zero_grad, forward
+        (training noise), loss / grad_acc_iters, backward (HIP kernels), gradient all-reduce over ranks, Adam step."""
+        if self.clrch != 1:
+            raise NotImplementedError("training on the HIP path needs clrch == 1 (three per-plane networks)")
+        if self._bucket is None:
+            self._bucket = parallel.FlatGradBucket(self.model.parameters())     # one flat fp32 bucket for RCCL
+        self._bucket.zero_()
+        y = ops.rgb_to_ycc(x.contiguous())                                     # :86-87
+        yhat, si_xe, si_xo = forward_planes_train(self.model.nets(), y, noise_fn)
+        xhat = ag.YccToRgbFn.apply(yhat)                                        # :90-94
+        xs = (x - 0.5).contiguous()
+        loss, mse, r1, r2 = self.train_loss.forward3_train(xs, xhat, si_xe, si_xo)
+        (loss / self.grad_acc_iters).float().backward()                        # :97
+        self._bucket.all_reduce_mean()                                          # data-parallel: mean gradient over ranks
+        self.optimizer.step()                                                   # :98
+        self.current_iteration += 1
+        return loss, mse, r1, r2
+
     def train_one_epoch(self):
-        raise NotImplementedError(
-            "the backward kernels of the HIP path (lifting / conv data- and weight-gradients) are the next row of the "
-            "hot-path scope (DESIGN.md 'What comes next'); round 1 ships the forward / validation path")
+        """agents/liftingDWT_agent.py:75-111."""
+        self.model.train()
+        for x in self.data_loader.train_loader:
+            x = x.to(self.device)
+            loss, mse, r1, r2 = self.train_step(x)
+            vals = (loss.item(), mse.item(), r1.item(), r2.item())
+            self.train_logger(*vals)
+            self.trnit_logger(*vals)
+            if (self.current_iteration + 1) % self.loss_prnt_iters == 0:
+                _, trnit_mse, _, _ = self.trnit_logger.display(lr=self.optimizer.param_groups[0]["lr"], typ="it")
+                if trnit_mse < self.loss_switch_thr and self.training_loss_switch == 0:     # :104-109
+                    self.train_loss = TrainRDLoss(self.lambda_)
+                    self.training_loss_switch = 1
+        train_rd_loss, _, _, _ = self.train_logger.display(lr=self.optimizer.param_groups[0]["lr"], typ="tr")
+        self.scheduler.step(train_rd_loss)                                      # :111
 
     @torch.no_grad()
     def validate(self):

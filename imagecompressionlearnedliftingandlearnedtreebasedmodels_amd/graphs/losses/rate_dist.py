@@ -49,6 +49,23 @@ class TrainRDLoss(nn.Module):
         return loss, mse, r1
 
 
+    def forward3_train(self, x, x_hat, rate1, rate2list):
+        """Differentiable forward3 (rate_dist.py:35-42): float64 device sums with hand-written gradients."""
+        from ... import autograd as ag
+        n = x.numel()
+        self.mse = (ag.SqErrSumFn.apply(x, x_hat) / n)[0]
+        self.rate1 = (ag.SumFn.apply(rate1) / n * 3)[0]
+        r2 = 0
+        for r in rate2list:
+            r2 = r2 + ag.SumFn.apply(r)
+        self.rate2 = (r2 / n * 3)[0]
+        self.loss = self._combine()
+        return self.loss, self.mse, self.rate1, self.rate2
+
+    def _combine(self):
+        return self.rate1 + self.rate2 + self.lambda_ * self.mse
+
+
 class TrainDLoss(TrainRDLoss):
     """lambda * MSE only (rate_dist.py:45-71); the rates are still reported."""
 
@@ -56,3 +73,6 @@ class TrainDLoss(TrainRDLoss):
         self._terms(x, x_hat, rate1, rate2list)
         self.loss = self.lambda_ * self.mse
         return self.loss, self.mse, self.rate1, self.rate2
+
+    def _combine(self):
+        return self.lambda_ * self.mse

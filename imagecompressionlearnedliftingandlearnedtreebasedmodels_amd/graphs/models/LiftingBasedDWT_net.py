@@ -11,6 +11,7 @@ Real entropy coding (``compress`` / ``test``, :136-152,374-556) is outside the h
 import torch
 from torch import nn
 
+from ... import autograd as ag
 from ... import ops
 from ...entropy_models import EntropyBottleneck, GaussianConditional
 from ..layers.lifting_dwt_nets import (DWTPytorchWaveletsLayer, LiftingBasedNeuralWaveletv4, _cache, _stack,
@@ -230,6 +231,117 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
         q_list.reverse()
         si_list.reverse()
         return si_xe, si_list, xe_q, q_list
+
+
+# ------------------------------------------------------------------------------------------------ training path
+# Same maths as the eval path, but every op is a differentiable autograd.Function (forward AND backward are HIP
+# kernels; torch only keeps the tape and un-stacks the per-plane parameter gradients).  Built for the headline
+# configuration: LiftingBasedNeuralWaveletv4 + SubbandAutoEncoder + conditioned2ZTsepSubbands.
+def _tstack(mods, get):
+    return torch.stack([get(m) for m in mods], 0)
+
+
+def _tconv(mods, x, act=ops.ACT_NONE, upsample2=False):
+    m0 = mods[0]
+    mask = None
+    if isinstance(m0, MaskedConv2d):
+        for m in mods:
+            m.apply_mask_()
+        mask = m0.tap_bits()
+    return ag.conv(x, _tstack(mods, lambda m: m.weight), _tstack(mods, lambda m: m.bias), m0.kernel_size[0],
+                   groups=m0.groups, act=act, upsample2=upsample2, tap_mask=mask)
+
+
+def _tconv_transpose1x1(mods, x, act):
+    """Grouped 1x1 ConvTranspose2d (SubbandAutoEncoder.ae_up) as the equivalent grouped 1x1 conv."""
+    m0 = mods[0]
+    G = m0.groups
+    cin_g, cout_g = m0.in_channels // G, m0.out_channels // G
+    w = _tstack(mods, lambda m: m.weight.view(G, cin_g, cout_g).transpose(1, 2).reshape(G * cout_g, cin_g, 1, 1))
+    return ag.conv(x, w.contiguous(), _tstack(mods, lambda m: m.bias), 1, groups=G, act=act)
+
+
+def _ae_train(aes, x, decode):
+    from ..layers.lifting_dwt_nets import SubbandAutoEncoder
+    if not isinstance(aes[0], SubbandAutoEncoder):
+        raise NotImplementedError("training on the HIP path is built for SubbandAutoEncoder (the GDN backward of "
+                                  "SubbandAutoEncoderBerk is not written yet)")
+    seqs = [(a.ae_up if decode else a.ae_down) for a in aes]
+    t = x
+    for n in (0, 2, 4, 6):
+        act = ops.ACT_NONE if n == 6 else ops.ACT_TANH
+        layer = [s_[n] for s_ in seqs]
+        t = _tconv_transpose1x1(layer, t, act) if decode else _tconv(layer, t, act)
+    return t
+
+
+def _lift_params(nets):
+    """taps (4,P,3) and the 8 stacked P/U tensors (nblocks,2,P,...) WITH autograd history to the module parameters."""
+    nb = len(nets[0].P_blocks)
+    taps = torch.stack([_tstack(nets, lambda n, j=j: n.preProcessingList[j].weight.reshape(3)) for j in range(4)], 0)
+    Wt = []
+    for cn in ("conv1", "conv2", "conv3", "conv4"):
+        for attr in ("weight", "bias"):
+            Wt.append(torch.stack([torch.stack([_tstack(nets, lambda n, k=kind, b=b: getattr(getattr(getattr(n, k)[b], cn), attr))
+                                                for kind in ("P_blocks", "U_blocks")], 0) for b in range(nb)], 0).contiguous())
+    n0 = nets[0]
+    meta = dict(levels=n0.waveletLevel, C=n0.depth_scale, K=n0.conv_filter_size, rw=n0.res_connection_weight,
+                linear=n0.linearityflag != 1, different=n0.blockprop != "same")
+    return taps.contiguous(), meta, Wt
+
+
+def forward_planes_train(nets, x, noise_fn=None):
+    """Differentiable encode -> entropy model (noise) -> decode for the three plane nets (LiftingBasedDWT_net.py:154-170
+    in training mode: quirk 2 of SURVEY 8a -- the context/decoder see noise sample #1, the rate noise sample #2)."""
+    aenc = [n.autoencoder for n in nets]
+    em = [n.entropymodel for n in nets]
+    if not isinstance(aenc[0], LiftingBasedNeuralWaveletv4) or not isinstance(em[0], DWTConditioned2EntropyLayerZTsepSubbands):
+        raise NotImplementedError("training on the HIP path is built for LiftingBasedNeuralWaveletv4 + "
+                                  "conditioned2ZTsepSubbands (DESIGN.md 8)")
+    if aenc[0].config.scale == 1:
+        raise NotImplementedError("training with config.scale == 1 is not built")
+    L = aenc[0].waveletLevel
+    taps, meta, Wt = _lift_params(aenc)
+    outs = ag.LiftingFn.apply(x, taps, meta, *Wt)
+    ll, yh = outs[0], list(outs[1:])
+    out_xe = _ae_train([n.Yl_ae for n in aenc], ll, False)
+    out_xo = [_ae_train([n.Yh_ae[i] for n in aenc], yh[i], False) for i in range(L)]
+
+    def rnd(t):
+        return torch.empty_like(t).uniform_(-0.5, 0.5) if noise_fn is None else noise_fn(t)
+
+    def stack5(seqs, t):
+        for n in (0, 2, 4, 6, 8):
+            t = _tconv([s_[n] for s_ in seqs], t, ops.ACT_NONE if n == 8 else ops.ACT_LRELU)
+        return t
+    xe_q = ag.QuantNoiseFn.apply(out_xe, rnd(out_xe))
+    si_xe = ag.GaussRateFn.apply(out_xe, stack5([l.csc_xe for l in em], xe_q), rnd(out_xe))
+    q_list, si_list = [], []
+    i = L - 1
+    xo_q = ag.QuantNoiseFn.apply(out_xo[i], rnd(out_xo[i]))
+    si_list.append(ag.GaussRateFn.apply(out_xo[i], stack5([l.csc_list[i] for l in em], xo_q), rnd(out_xo[i])))
+    q_list.append(xo_q)
+    parent = xo_q
+    for i in range(L - 2, -1, -1):
+        xo_q = ag.QuantNoiseFn.apply(out_xo[i], rnd(out_xo[i]))
+        csc = _tconv([l.csc_list[i] for l in em], xo_q)
+        seqs = [l.plc_list[i] for l in em]
+        plc = _tconv([s_[2] for s_ in seqs], _tconv([s_[0] for s_ in seqs], parent, ops.ACT_LRELU, upsample2=True))
+        p0, p1, p2 = plc.chunk(3, dim=2)
+        c0, c1, c2 = csc.chunk(3, dim=2)
+        t = torch.cat((p0, c0, p1, c1, p2, c2), dim=2)                    # regroup (:357-359): data movement only
+        cg = [l.cgp_out_xo_list[i] for l in em]
+        for n in (0, 2, 4, 6):
+            t = _tconv([s_[n] for s_ in cg], t, ops.ACT_NONE if n == 6 else ops.ACT_LRELU)
+        si_list.append(ag.GaussRateFn.apply(out_xo[i], t, rnd(out_xo[i])))
+        q_list.append(xo_q)
+        parent = xo_q
+    q_list.reverse()
+    si_list.reverse()
+    Yl = _ae_train([n.Yl_ae for n in aenc], xe_q, True)
+    Yh = [_ae_train([n.Yh_ae[i] for n in aenc], q_list[i], True) for i in range(L)]
+    xhat = ag.LiftingInvFn.apply(taps, meta, L, Yl, *Yh, *Wt)
+    return xhat, si_xe, si_list
 
 
 _ENTROPY = {"factorized": DWTFactorizedEntropyLayer, "onlyEZWT": onlyEZWT,
