@@ -30,8 +30,18 @@ inline int check_launch(const char* what) {
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
 
+// tanh(x) = sign(x) * (1 - 2 / (exp(2|x|) + 1)) on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32): ~8 instructions
+// instead of ocml's ~40; absolute error <= 3e-7 over the whole range (checked against torch.tanh in the parity tests),
+// exact saturation to +-1 for |x| > 10.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fminf(fabsf(x), 15.f);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.88539008177792681472f);      // exp(2|x|) = 2^(2|x| log2 e)
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    return copysignf(t, x);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == LLDWT_ACT_TANH) return tanhf(v);
+    if (act == LLDWT_ACT_TANH) return fast_tanh(v);
     if (act == LLDWT_ACT_LRELU) return v >= 0.f ? v : 0.01f * v;
     return v;
 }

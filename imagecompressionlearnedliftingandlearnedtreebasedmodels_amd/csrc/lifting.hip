@@ -262,6 +262,220 @@ __global__ __launch_bounds__(NT) void k_lift_b(const float* __restrict__ skip, c
     }
 }
 
+// ---- MFMA variants of kernels A and B for C == 16 (the reference's depth_scale*8, liftingDWT.json:22) ------------------
+// The 16->16 kxk convs are implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32): D[oc][px] += W[oc][(ic,tap)] X[(ic,tap)][px].
+//   A = weights, staged once per workgroup into LDS in lane order [tap][s][64] (lane = kk*16 + oc, ic = 4s + kk)
+//   B = activation tile in LDS, planar [ic][rows][cols] with plane stride == 16 (mod 32) dwords (20*36 = 720)
+// A wave owns 8 pixel tiles (4 rows x 2 segments of 16) of the 16x32 output tile: 8 accumulators, 1 A read per 8 MFMAs.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int K>
+__device__ __forceinline__ void stage_w16(float* __restrict__ wl, const float* __restrict__ Wp, int tid) {
+    // Wp: packed [ic][tap][oc] (pack_off layout) -> wl[(tap*4 + s)*64 + kk*16 + oc], ic = 4s + kk
+    constexpr int KK = K * K;
+    for (int i = tid; i < KK * 4 * 64; i += NT) {
+        const int l = i & 63, s = (i >> 6) & 3, tap = i >> 8;
+        const int oc = l & 15, kk = l >> 4;
+        wl[i] = Wp[((4 * s + kk) * KK + tap) * 16 + oc];
+    }
+}
+
+// acc[n] += conv over the 16-channel LDS tile t (planes of stride PS, rows of PITCH) for this wave's 8 pixel tiles
+template <int K, int PS, int PITCH>
+__device__ __forceinline__ void conv16_mfma_ps(const float* __restrict__ t, const float* __restrict__ wl, int wave,
+                                               int lane, floatx4 (&acc)[8]) {
+    const int px = lane & 15, kk = lane >> 4;
+    const float* tb = t + kk * PS + (wave * 4) * PITCH + px;
+    const float* wa = wl + lane;
+#pragma unroll
+    for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float A = wa[((dy * K + dx) * 4 + s) * 64];
+                float B[8];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) B[n] = tb[(4 * s) * PS + ((n >> 1) + dy) * PITCH + (n & 1) * 16 + dx];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B[n], acc[n], 0, 0, 0);
+            }
+        }
+}
+
+// conv1 (1 -> 16) as a GEMM with K = taps (padded to a multiple of 4): B gathered from the single-channel skip tile
+template <int K, int SPITCH>
+__device__ __forceinline__ void conv1_mfma(const float* __restrict__ sl, const float* __restrict__ w1l, int wave, int lane,
+                                           int row_off, int col_off, floatx4 (&acc)[8]) {
+    constexpr int KK = K * K, KS4 = (KK + 3) / 4;
+    const int px = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < KS4; ++s) {
+        const int tap = 4 * s + kk;
+        const int dy = tap < KK ? tap / K : 0, dx = tap < KK ? tap % K : 0;
+        const float A = w1l[s * 64 + lane];
+        float B[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            B[n] = sl[(row_off + wave * 4 + (n >> 1) + dy) * SPITCH + col_off + (n & 1) * 16 + px + dx];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B[n], acc[n], 0, 0, 0);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void stage_w1(float* __restrict__ w1l, const float* __restrict__ W1p, int tid) {
+    // W1p: packed [tap][oc] -> w1l[s*64 + kk*16 + oc] = W1[oc][tap = 4s+kk] (0 beyond the last tap)
+    constexpr int KK = K * K, KS4 = (KK + 3) / 4;
+    for (int i = tid; i < KS4 * 64; i += NT) {
+        const int l = i & 63, s = i >> 6;
+        const int tap = 4 * s + (l >> 4);
+        w1l[i] = tap < KK ? W1p[tap * 16 + (l & 15)] : 0.f;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(NT) void k_lift_a_mfma(CView src, float* __restrict__ skip_out, float* __restrict__ t2_out,
+                                                    float* __restrict__ t1_out, float* __restrict__ src_out, int batch,
+                                                    int h, int w, const float* __restrict__ taps,
+                                                    const float* __restrict__ packed, int64_t packed_plane_stride,
+                                                    int vertical, int linear) {
+    constexpr int C = 16, R = K / 2, R2 = 2 * R, KK = K * K;
+    constexpr int SH = TH + 2 * R2, SW = TW + 2 * R2;
+    constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;      // 20 x 36 for K = 5: plane stride 720 == 16 (mod 32)
+    constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_lds = lds;                                    // [SH][SW+1]
+    float* t1 = s_lds + SH * (SW + 1);                     // [C] planes of stride T1PS, rows of T1W
+    float* wl = t1 + C * T1PS;                             // [KK][4][64]
+    const PackOff o = pack_off(C, K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
+    const float tp0 = taps[plane * 3 + 0], tp1 = taps[plane * 3 + 1], tp2 = taps[plane * 3 + 2];
+    const int act = linear ? LLDWT_ACT_NONE : LLDWT_ACT_TANH;
+    stage_w16<K>(wl, pk + o.w2, tid);
+    for (int i = tid; i < SH * SW; i += NT) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int gy = y0 - R2 + ly, gx = x0 - R2 + lx;
+        float v = 0.f;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            const int ddy = vertical ? 1 : 0, ddx = vertical ? 0 : 1;
+            const float a = ld_view(src, z, gy - ddy, gx - ddx, h, w);
+            const float b = ld_view(src, z, gy, gx, h, w);
+            const float c = ld_view(src, z, gy + ddy, gx + ddx, h, w);
+            v = tp0 * a + tp1 * b + tp2 * c;
+            if (ly >= R2 && ly < R2 + TH && lx >= R2 && lx < R2 + TW) {
+                skip_out[(z * h + gy) * (int64_t)w + gx] = v;
+                if (src_out) src_out[(z * h + gy) * (int64_t)w + gx] = b;
+            }
+        }
+        s_lds[ly * (SW + 1) + lx] = v;
+    }
+    __syncthreads();
+    // conv1 (1 -> 16) + act on the (TH+2R)x(TW+2R) region (VALU: 6 % of the step's MACs); zero outside the image
+    for (int i = tid; i < T1H * T1W; i += NT) {
+        const int ly = i / T1W, lx = i - ly * T1W;
+        const int gy = y0 - R + ly, gx = x0 - R + lx;
+        float acc[C];
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+#pragma unroll
+        for (int oc = 0; oc < C; ++oc) acc[oc] = pk[o.b1 + oc];
+        if (in) {
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    const float v = s_lds[(ly + dy) * (SW + 1) + lx + dx];
+                    const float* wt = pk + o.w1 + (dy * K + dx) * C;
+#pragma unroll
+                    for (int oc = 0; oc < C; ++oc) acc[oc] = fmaf(wt[oc], v, acc[oc]);
+                }
+        }
+        const bool centre = t1_out && in && ly >= R && ly < R + TH && lx >= R && lx < R + TW;
+#pragma unroll
+        for (int oc = 0; oc < C; ++oc) {
+            const float tv = in ? act_apply(acc[oc], act) : 0.f;
+            t1[oc * T1PS + ly * T1W + lx] = tv;
+            if (centre) t1_out[(z * C + oc) * ((int64_t)h * w) + (int64_t)gy * w + gx] = tv;
+        }
+    }
+    __syncthreads();
+    floatx4 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    conv16_mfma_ps<K, T1PS, T1W>(t1, wl, wave, lane, acc);
+    // epilogue: lane holds channels 4*kk + r of pixel px of its 8 pixel tiles
+    const int px = lane & 15, kk = lane >> 4;
+    const int64_t cs = (int64_t)h * w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oc = 4 * kk + r;
+        const float bv = pk[o.b2 + oc];
+        float* op = t2_out + (z * C + oc) * cs;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
+            if (gy < h && gx < w) op[(int64_t)gy * w + gx] = act_apply(acc[n][r] + bv, act);
+        }
+    }
+    (void)KK;
+}
+
+template <int K>
+__global__ __launch_bounds__(NT) void k_lift_b_mfma(const float* __restrict__ skip, const float* __restrict__ t2,
+                                                    float* __restrict__ t3_out, int batch, int h, int w,
+                                                    const float* __restrict__ packed, int64_t packed_plane_stride,
+                                                    int vertical) {
+    constexpr int C = 16, R = K / 2, KK = K * K, KS4 = (KK + 3) / 4;
+    constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;
+    constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_lds = lds;                                    // [T1H][T1W+1]
+    float* t = s_lds + T1H * (T1W + 1);                    // [C] planes
+    float* wl = t + C * T1PS;                              // conv3 weights [KK][4][64]
+    float* w1l = wl + KK * 4 * 64;                         // conv1 weights [KS4][64]
+    const PackOff o = pack_off(C, K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
+    const int64_t cs = (int64_t)h * w;
+    stage_w16<K>(wl, pk + o.w3, tid);
+    stage_w1<K>(w1l, pk + o.w1, tid);
+    for (int i = tid; i < T1H * T1W; i += NT) {
+        const int ly = i / T1W, lx = i - ly * T1W;
+        const int gy = y0 - R + ly, gx = x0 - R + lx;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const int64_t off = (int64_t)gy * w + gx;
+        s_lds[ly * (T1W + 1) + lx] = in ? skip[z * cs + off] : 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) t[c * T1PS + ly * T1W + lx] = in ? t2[(z * C + c) * cs + off] : 0.f;
+    }
+    __syncthreads();
+    floatx4 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    conv1_mfma<K, T1W + 1>(s_lds, w1l, wave, lane, 0, 0, acc);          // residual r = conv1(skip), pre-activation
+    conv16_mfma_ps<K, T1PS, T1W>(t, wl, wave, lane, acc);               // + conv3(t2)
+    const int px = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oc = 4 * kk + r;
+        const float bv = pk[o.b3 + oc] + pk[o.b1 + oc];
+        float* op = t3_out + (z * C + oc) * cs;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
+            if (gy < h && gx < w) op[(int64_t)gy * w + gx] = acc[n][r] + bv;
+        }
+    }
+    (void)KS4;
+}
+
 // ---- kernel C: conv4(t3) ; dst_out = dst_in + sign*(skip + rw*net) -------------------------------------------
 template <int C, int K>
 __global__ __launch_bounds__(NT) void k_lift_c(const float* __restrict__ skip, const float* __restrict__ t3,
@@ -401,10 +615,28 @@ static int launch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, in
                        int64_t w, const float* taps, const float* packed, int64_t pstride, int vertical, float sign,
                        float rw, int linear, const StepBufs& b, hipStream_t st) {
     dim3 grid((unsigned)cdiv(w, TW), (unsigned)cdiv(h, TH), (unsigned)Z), block(NT);
-    hipLaunchKernelGGL((k_lift_a<C, K>), grid, block, 0, st, cv(src), b.skip, b.t2, b.t1, b.srcv, (int)batch, (int)h,
-                       (int)w, taps, packed, pstride, vertical, linear);
-    hipLaunchKernelGGL((k_lift_b<C, K>), grid, block, 0, st, b.skip, b.t2, b.t3, (int)batch, (int)h, (int)w, packed,
-                       pstride, vertical);
+    if constexpr (C == 16) {
+        constexpr int R = K / 2, R2 = 2 * R, KK = K * K;
+        constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;
+        constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
+        constexpr size_t sh_a = sizeof(float) * ((TH + 2 * R2) * (TW + 2 * R2 + 1) + 16 * T1PS + KK * 4 * 64);
+        constexpr size_t sh_b = sizeof(float) * (T1H * (T1W + 1) + 16 * T1PS + KK * 4 * 64 + ((KK + 3) / 4) * 64);
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute((const void*)k_lift_a_mfma<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_a);
+            hipFuncSetAttribute((const void*)k_lift_b_mfma<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((k_lift_a_mfma<K>), grid, block, sh_a, st, cv(src), b.skip, b.t2, b.t1, b.srcv, (int)batch,
+                           (int)h, (int)w, taps, packed, pstride, vertical, linear);
+        hipLaunchKernelGGL((k_lift_b_mfma<K>), grid, block, sh_b, st, b.skip, b.t2, b.t3, (int)batch, (int)h, (int)w,
+                           packed, pstride, vertical);
+    } else {
+        hipLaunchKernelGGL((k_lift_a<C, K>), grid, block, 0, st, cv(src), b.skip, b.t2, b.t1, b.srcv, (int)batch, (int)h,
+                           (int)w, taps, packed, pstride, vertical, linear);
+        hipLaunchKernelGGL((k_lift_b<C, K>), grid, block, 0, st, b.skip, b.t2, b.t3, (int)batch, (int)h, (int)w, packed,
+                           pstride, vertical);
+    }
     hipLaunchKernelGGL((k_lift_c<C, K>), grid, block, 0, st, b.skip, b.t3, cv(dst_in), dst_out, (int)batch, (int)h,
                        (int)w, packed, pstride, vertical, sign, rw);
     return check_launch("lift_step");

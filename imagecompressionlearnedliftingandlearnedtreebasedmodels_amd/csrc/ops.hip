@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_subband_mlp(const float* __restrict__ x
         const float v = xp[i];
         float ha[HD], hb[HD];
 #pragma unroll
-        for (int j = 0; j < HD; ++j) ha[j] = tanhf(fmaf(sw0[j], v, sb0[j]));
+        for (int j = 0; j < HD; ++j) ha[j] = tanhf(fmaf(sw0[j], v, sb0[j]));   // (ocml tanhf measured faster here than exp2+rcp)
 #pragma unroll
         for (int j = 0; j < HD; ++j) {
             float a = sb1[j];
