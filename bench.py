@@ -149,6 +149,12 @@ def main():
     log("timed region done: %.3f s for %d steps" % (dt, a.steps))
     dt = parallel.max_over_ranks(dt, dev)                    # the slowest rank defines the step time
 
+    traffic, traffic_src = None, None
+    tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath) and a.batch == 8 and a.size == 512 and a.levels == 4:
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
     dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom["events"])
     n_launch = max(len(dom["events"]), 1)
     achieved = dom["flops"] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -163,7 +169,7 @@ def main():
                    "per_gpu_batch": a.batch, "sharding": "batch over ranks, no data-path collective"},
         "roofline": {"bound": "mfma", "kernel": "plc conv 243->243 3x3 (tree context, 61% of the step's FLOPs)",
                      "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_ms": dom_ms / n_launch, "launches": len(dom["events"]),
                      "algorithmic_flop_per_launch": dom["flops"] / n_launch},
     }

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the HBM-bound kernels of the path (north_star's HBM-roofline target applies to these):
+fixed CDF 9/7 4-level DWT, Gaussian / factorized rate kernels, colour transform.  Prints one JSON object.
+
+    python tools_bench_kernels.py [--batch 8 --size 512 --iters 20]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK = 8000.0
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.entropy_models import EntropyBottleneck
+    dev = torch.device("cuda:0")
+    B, S = a.batch, a.size
+    x = torch.rand(B, 3, S, S, device=dev)
+    npx = B * 3 * S * S
+    out = {}
+    # colour: read 12 B + write 12 B per RGB pixel
+    t = timeit(lambda: ops.rgb_to_ycc(x), a.iters)
+    out["rgb_to_ycc"] = {"GB/s": 2 * npx * 4 / t / 1e9}
+    # CDF 9/7 forward, 4 levels: algorithmic traffic = read input + write all subbands = 8 B per sample
+    y = ops.rgb_to_ycc(x).reshape(1, B, 3, S, S).contiguous()
+    t = timeit(lambda: ops.cdf97_forward(y, 4), a.iters)
+    out["cdf97_forward_L4"] = {"GB/s": 2 * npx * 4 / t / 1e9, "Mpixels/s": B * S * S / t / 1e6, "ms": t * 1e3}
+    ll, yh = ops.cdf97_forward(y, 4)
+    t = timeit(lambda: ops.cdf97_inverse(ll, yh), a.iters)
+    out["cdf97_inverse_L4"] = {"GB/s": 2 * npx * 4 / t / 1e9, "ms": t * 1e3}
+    # Gaussian rate: read x, sigma, mu; write bits = 16 B per coefficient
+    c = torch.randn(3, B, 3, S // 2, S // 2, device=dev) * 3
+    prm = torch.rand(3, B, 6, S // 2, S // 2, device=dev) * 2
+    t = timeit(lambda: ops.gauss_rate(c, prm), a.iters)
+    out["gauss_rate"] = {"GB/s": c.numel() * 16 / t / 1e9}
+    eb = torch.stack([EntropyBottleneck(3).packed() for _ in range(3)], 0).to(dev)
+    t = timeit(lambda: ops.factorized_rate(c, eb), a.iters)
+    out["factorized_rate"] = {"GB/s": c.numel() * 12 / t / 1e9}      # read x, write bits and q
+    for k in out:
+        out[k]["frac_of_8TBps"] = out[k]["GB/s"] / HBM_PEAK
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
