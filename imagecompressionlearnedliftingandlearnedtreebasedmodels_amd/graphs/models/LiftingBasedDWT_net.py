@@ -233,6 +233,85 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
         return si_xe, si_list, xe_q, q_list
 
 
+class DWTConditioned2EntropyLayerZTBlock(_EntropyLayerBase):
+    """Block-wise variant (LiftingBasedDWT_net.py:558-757): the four polyphase phases of each subband are predicted in
+    sequence from the (not upsampled) parent subband and the phases already coded, by eight 5-layer CNNs (mu / sigma)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self._level_channels(config)
+        self.dwtLevels = config.dwtlevels
+        self.multiplier = 8
+        hid = 32
+        for k in range(1, 5):
+            setattr(self, "dep_%d_list_mu" % k, nn.ModuleList())
+        for k in range(1, 5):
+            setattr(self, "dep_%d_list_sigma" % k, nn.ModuleList())
+        self.cgp_out_xo_list = nn.ModuleList()
+        self.ent_out_xo_list = nn.ModuleList()
+        self.scl_out_xo_list = nn.ParameterList()
+        self.scb_out_xo_list = nn.ParameterList()
+
+        def net(cin):
+            return nn.Sequential(nn.Conv2d(cin, hid, 3, padding=1), nn.LeakyReLU(inplace=True),
+                                 nn.Conv2d(hid, hid, 3, padding=1), nn.LeakyReLU(inplace=True),
+                                 nn.Conv2d(hid, hid, 1), nn.LeakyReLU(inplace=True),
+                                 nn.Conv2d(hid, hid, 1), nn.LeakyReLU(inplace=True), nn.Conv2d(hid, 1, 1))
+        for i in range(self.num_lifting_layers - 1):
+            for _ in range(3):
+                self.ent_out_xo_list.append(GaussianConditional(scale_table=None, scale_bound=0.11))
+                self.scl_out_xo_list.append(nn.Parameter(torch.full((1, self.sos[i], 1, 1), i * 1.0 + 1.0)))
+                self.scb_out_xo_list.append(nn.Parameter(torch.full((1, self.sos[i], 1, 1), 1.0)))
+                for k in range(1, 5):
+                    getattr(self, "dep_%d_list_mu" % k).append(net(k))
+                for k in range(1, 5):
+                    getattr(self, "dep_%d_list_sigma" % k).append(net(k))
+        self.ent_out_xo_list.append(GaussianConditional(scale_table=None, scale_bound=0.11))
+        self.gaussian_conditional = GaussianConditional(None)
+        self.ent_out_xe = EntropyBottleneck(channels=1)
+        self.ent_out_xo = EntropyBottleneck(channels=3)
+
+    @staticmethod
+    def forward_planes(layers, out_xe, out_xo_list, training):
+        L = len(out_xo_list)
+        si_xe, xe_q = ops.factorized_rate(out_xe, _eb_packed([l.ent_out_xe for l in layers]), _noise(out_xe, training))
+        bits, q = ops.factorized_rate(out_xo_list[L - 1], _eb_packed([l.ent_out_xo for l in layers]),
+                                      _noise(out_xo_list[L - 1], training))
+        si_list, q_list = [bits], [q]
+        con = q
+        slots = ((0, 0), (0, 1), (1, 0), (1, 1))
+        for i in range(L - 1):
+            lev = L - i - 2
+            x = out_xo_list[lev]
+            P, B, _, H, W = x.shape
+            sis, qs = [], []
+            for j in range(3):
+                xj = x[:, :, j:j + 1].contiguous()
+                qj = ops.quantize(xj, _noise(xj, training))                                   # :716-718
+                ee, eo, oe = qj[..., 0::2, 0::2], qj[..., 0::2, 1::2], qj[..., 1::2, 0::2]    # :719-721
+                dep1 = con[:, :, j:j + 1]
+                deps = (dep1, torch.cat((dep1, ee), 2), torch.cat((dep1, ee, eo), 2), torch.cat((dep1, ee, eo, oe), 2))
+                params = torch.empty(P, B, 2, H, W, device=x.device, dtype=torch.float32)     # (sigma, mu)
+                idx = j + i * 3
+                for k in range(4):                                                            # :723-740
+                    d = deps[k].contiguous()
+                    for ch, kind in ((1, "mu"), (0, "sigma")):
+                        seqs = [getattr(l, "dep_%d_list_%s" % (k + 1, kind))[idx] for l in layers]
+                        t = d
+                        for n in (0, 2, 4, 6, 8):
+                            t = _conv([s_[n] for s_ in seqs], t, ops.ACT_NONE if n == 8 else ops.ACT_LRELU)
+                        params[:, :, ch:ch + 1, slots[k][0]::2, slots[k][1]::2] = t          # strided placement
+                bits, _ = ops.gauss_rate(xj, params, _noise(xj, training))                    # :743-744
+                sis.append(bits)
+                qs.append(qj)
+            si_list.append(torch.cat(sis, 2))
+            con = torch.cat(qs, 2)
+            q_list.append(con)
+        q_list.reverse()
+        si_list.reverse()
+        return si_xe, si_list, xe_q, q_list
+
+
 # ------------------------------------------------------------------------------------------------ training path
 # Same maths as the eval path, but every op is a differentiable autograd.Function (forward AND backward are HIP
 # kernels; torch only keeps the tape and un-stacks the per-plane parameter gradients).  Built for the headline
@@ -345,7 +424,8 @@ def forward_planes_train(nets, x, noise_fn=None):
 
 
 _ENTROPY = {"factorized": DWTFactorizedEntropyLayer, "onlyEZWT": onlyEZWT,
-            "conditioned2ZTsepSubbands": DWTConditioned2EntropyLayerZTsepSubbands}
+            "conditioned2ZTsepSubbands": DWTConditioned2EntropyLayerZTsepSubbands,
+            "DWTConditioned2EntropyLayerZTBlock": DWTConditioned2EntropyLayerZTBlock}
 _TRANSFORM = {"CDF97": DWTPytorchWaveletsLayer, "LiftingBasedNeuralWaveletv4": LiftingBasedNeuralWaveletv4}
 
 

@@ -253,8 +253,64 @@ def only_ezwt_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None)
     return si_xe, si_list, xe_q, q_list
 
 
+def _dep_net(x, sd, prefix):
+    """5-layer CNN of DWTConditioned2EntropyLayerZTBlock (LiftingBasedDWT_net.py:618-624): 3x3, 3x3, 1x1, 1x1, 1x1."""
+    t = x
+    for n in (0, 2, 4, 6, 8):
+        w = sd[prefix + "%d.weight" % n]
+        t = F.conv2d(t, w, sd[prefix + "%d.bias" % n], padding=w.shape[-1] // 2)
+        if n != 8:
+            t = F.leaky_relu(t, 0.01)
+    return t
+
+
+def ztblock_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None):
+    """DWTConditioned2EntropyLayerZTBlock.forward (LiftingBasedDWT_net.py:691-757): the four polyphase phases of every
+    subband are predicted in sequence from the (not upsampled) parent and the phases already coded.
+    noises (training): {'xe': n, 'xo_top': n, 'xo': [[(n1,n2) per subband j] per level]}."""
+    L = cfg["dwtlevels"]
+    mode = "noise" if training else "dequantize"
+    xe_q, p = entropy_bottleneck_forward(out_xe, sd, "ent_out_xe.", training, None if noises is None else noises["xe"])
+    si_xe = _neg_log2(p)
+    xo_q, p = entropy_bottleneck_forward(out_xo_list[L - 1], sd, "ent_out_xo.", training,
+                                         None if noises is None else noises["xo_top"])
+    si_list, q_list = [_neg_log2(p)], [xo_q]
+    con = xo_q
+    for i in range(L - 1):
+        lev = L - i - 2
+        x = out_xo_list[lev]
+        B, C, H, W = x.shape
+        sis, qs = [], []
+        for j in range(3):
+            xj = x[:, j:j + 1]
+            n1 = None if noises is None else noises["xo"][lev][j][0]
+            n2 = None if noises is None else noises["xo"][lev][j][1]
+            q = quantize(xj, mode, None, n1)                                             # :716-718
+            ee, eo, oe = q[:, :, 0::2, 0::2], q[:, :, 0::2, 1::2], q[:, :, 1::2, 0::2]   # :719-721
+            dep1 = con[:, j:j + 1]
+            mu = torch.empty(B, 1, H, W)
+            sg = torch.empty(B, 1, H, W)
+            idx = j + i * 3
+            deps = [dep1, torch.cat((dep1, ee), 1), torch.cat((dep1, ee, eo), 1), torch.cat((dep1, ee, eo, oe), 1)]
+            slots = [(slice(0, None, 2), slice(0, None, 2)), (slice(0, None, 2), slice(1, None, 2)),
+                     (slice(1, None, 2), slice(0, None, 2)), (slice(1, None, 2), slice(1, None, 2))]
+            for k in range(4):                                                            # :723-740
+                mu[:, :, slots[k][0], slots[k][1]] = _dep_net(deps[k], sd, "dep_%d_list_mu.%d." % (k + 1, idx))
+                sg[:, :, slots[k][0], slots[k][1]] = _dep_net(deps[k], sd, "dep_%d_list_sigma.%d." % (k + 1, idx))
+            _, p = gaussian_conditional_forward(xj, sg, mu, training, n2)                 # :743-744
+            sis.append(_neg_log2(p))
+            qs.append(q)
+        si_list.append(torch.cat(sis, 1))
+        con = torch.cat(qs, 1)
+        q_list.append(con)
+    q_list.reverse()
+    si_list.reverse()
+    return si_xe, si_list, xe_q, q_list
+
+
 ENTROPY_LAYERS = {
     "factorized": factorized_forward,
     "conditioned2ZTsepSubbands": conditioned2_forward,
     "onlyEZWT": only_ezwt_forward,
+    "DWTConditioned2EntropyLayerZTBlock": ztblock_forward,
 }

@@ -116,6 +116,21 @@ def entropy_template(cfg, gen=None):
                 _masked(sd, "%s.%d" % (prefix, n), t, a, b, 3, g)
         stack("csc_list.%d" % (L - 1), so)
         stack("csc_xe", se)
+    elif layer == "DWTConditioned2EntropyLayerZTBlock":
+        hid = 32
+        for i in range(L - 1):
+            for j in range(3):
+                n = j + i * 3
+                sd["scl_out_xo_list.%d" % n] = torch.full((1, so, 1, 1), i * 1.0 + 1.0)
+                sd["scb_out_xo_list.%d" % n] = torch.full((1, so, 1, 1), 1.0)
+                for k in range(1, 5):
+                    for kind in ("mu", "sigma"):
+                        pre = "dep_%d_list_%s.%d" % (k, kind, n)
+                        for idx, (a, b, ks) in zip((0, 2, 4, 6, 8), [(k, hid, 3), (hid, hid, 3), (hid, hid, 1),
+                                                                     (hid, hid, 1), (hid, 1, 1)]):
+                            _conv(sd, "%s.%d" % (pre, idx), b, a, ks, ks)
+        eb("ent_out_xe.", 1)
+        eb("ent_out_xo.", 3)
     else:
         raise ValueError(layer)
     return sd

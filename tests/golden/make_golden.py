@@ -280,6 +280,15 @@ def main():
     wrapper_case("ref_wrapper_ezwt_L3", (1, 3, 32, 64), 22, dwtlevels=3, entropy_layer="onlyEZWT")
     wrapper_case("ref_wrapper_fact_L2", (2, 3, 32, 32), 23, dwtlevels=2, entropy_layer="factorized")
     wrapper_case("ref_wrapper_cond2_berk_L2", (1, 3, 32, 32), 24, dwtlevels=2, autoencoder="SubbandAutoEncoderBerk")
+    # DWTConditioned2EntropyLayerZTBlock.forward allocates with `.cuda()` unconditionally (LiftingBasedDWT_net.py:717-718);
+    # the build container has no GPU, so Tensor.cuda is made a no-op for this one call (the reference source is unchanged)
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        wrapper_case("ref_wrapper_ztblock_L3", (1, 3, 32, 32), 25, dwtlevels=3,
+                     entropy_layer="DWTConditioned2EntropyLayerZTBlock")
+    finally:
+        torch.Tensor.cuda = _cuda
 
 
 if __name__ == "__main__":

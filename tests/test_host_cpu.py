@@ -55,7 +55,7 @@ def test_product_never_imports_oracle():
     assert not bad, bad
 
 
-@pytest.mark.parametrize("ent", ["factorized", "onlyEZWT", "conditioned2ZTsepSubbands"])
+@pytest.mark.parametrize("ent", ["factorized", "onlyEZWT", "conditioned2ZTsepSubbands", "DWTConditioned2EntropyLayerZTBlock"])
 @pytest.mark.parametrize("ae", ["SubbandAutoEncoder", "SubbandAutoEncoderBerk"])
 @pytest.mark.parametrize("nt", ["LiftingBasedNeuralWaveletv4", "CDF97"])
 def test_state_dict_layout_matches_reference(ent, ae, nt):

@@ -130,7 +130,7 @@ def test_lifting_encode_decode(name):
 
 
 @pytest.mark.parametrize("name", ["ref_wrapper_cond2_L3", "ref_wrapper_ezwt_L3", "ref_wrapper_fact_L2",
-                                  "ref_wrapper_cond2_berk_L2"])
+                                  "ref_wrapper_cond2_berk_L2", "ref_wrapper_ztblock_L3"])
 def test_wrapper_forward(name):
     g = load_golden(name)
     cfg = g["cfg"]
