@@ -69,6 +69,33 @@ def cpu_baseline(sd, cfg, size, seconds_budget=25.0):
             "sample": "oracle (torch-CPU restatement of the reference path), 1x3x%dx%d, %d timed runs after 1 warm-up" % (size, size, n)}
 
 
+def train_leg(a, dev, rank, world, x):
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.agents.liftingDWT_agent import LiftingBasedDWTAgent
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
+    from oracle import weights as oweights
+    cfg = make_config(dwtlevels=a.levels, mode="train", batch_size=a.batch, patch_size=a.size, seed=1337)
+    agent = LiftingBasedDWTAgent(cfg)
+    agent.model.load_state_dict(oweights.fill_by_name(oweights.wrapper_template(dict(cfg))), strict=False)
+    agent.model.train()
+    torch.manual_seed(parallel.rank_seed(1337, rank))
+    torch.cuda.empty_cache()
+    agent.train_step(x)                                   # warm-up (allocator, packs)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.train_steps):
+        loss, mse, r1, r2 = agent.train_step(x)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    log("train leg done: %.3f s for %d steps" % (dt, a.train_steps))
+    return {"ms_per_step": dt / a.train_steps * 1e3, "Mpixels/s": a.batch * a.size * a.size * world * a.train_steps / dt / 1e6,
+            "steps": a.train_steps, "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "what": "forward (noise) + hand-written backward + flat-bucket gradient all-reduce (mean over ranks) + Adam, "
+                    "same workload, batch sharded over ranks"}
+
+
 def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
 
@@ -85,6 +112,9 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=2,
+                    help="extra (not part of `value`): time this many full training steps (fwd + hand-written bwd + "
+                         "gradient all-reduce + Adam) on the same workload; 0 disables")
     a = ap.parse_args()
 
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
@@ -173,6 +203,13 @@ def main():
                      "avg_launch_ms": dom_ms / n_launch, "launches": len(dom["events"]),
                      "algorithmic_flop_per_launch": dom["flops"] / n_launch},
     }
+    # ---- extra, reported beside the metric: the training step of the same workload (north_star: fwd/bwd path, batch
+    # sharded over ranks, ONE flat-bucket gradient all-reduce over RCCL per step)
+    if a.train_steps > 0:
+        try:
+            out["train"] = train_leg(a, dev, rank, world, x)
+        except Exception as e:       # never lose the metric line because of the extra leg
+            out["train"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, cfg, min(a.size, 256))
     elif rank == 0:

@@ -81,12 +81,15 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < WNT; ++j) acc[m][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    // K (= images x spatial chunks) is split over blockIdx.y: slice s takes chunks s, s + zsplit, ...
     const int tiles_x = (w + WG_TW - 1) / WG_TW, tiles_y = (h + WG_TH - 1) / WG_TH;
-    for (int b = blockIdx.y; b < a.batch; b += a.zsplit) {
-        const int64_t z = (int64_t)plane * a.batch + b;
-        const float* dyz = a.dy + z * d.ytot * hw;
-        const float* xz = a.x + z * xtot * hwi;
-        for (int t = 0; t < tiles_x * tiles_y; ++t) {
+    const int ntile = tiles_x * tiles_y;
+    {
+        for (int q = blockIdx.y; q < a.batch * ntile; q += a.zsplit) {
+            const int b = q / ntile, t = q - b * ntile;
+            const int64_t z = (int64_t)plane * a.batch + b;
+            const float* dyz = a.dy + z * d.ytot * hw;
+            const float* xz = a.x + z * xtot * hwi;
             const int y0 = (t / tiles_x) * WG_TH, x0 = (t % tiles_x) * WG_TW;
             __syncthreads();
             // stage dY: MT*16 channels x 128 px (zero outside the image / beyond cout_g)
@@ -260,8 +263,18 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
     a.ntaps = nt;
     const int cin_g = d->cin / d->groups, cout_g = d->cout / d->groups;
     a.n_total = cin_g * nt;
-    // split K over images so that the grid fills the chip
-    a.zsplit = (int)(batch < 16 ? batch : 16);
+    // split K (images x 8x16 chunks) so that the grid fills the chip several times over: ~2048 workgroups
+    {
+        const bool narrow_ = cout_g <= 16;
+        const int nt_ = narrow_ ? 16 : 4, mt_ = narrow_ ? 1 : 4;
+        const int64_t out_tiles = cdiv(a.n_total, nt_ * 16) * cdiv(cout_g, mt_ * 16) * d->groups * planes;
+        const int64_t chunks = batch * cdiv(h, WG_TH) * cdiv(w_, WG_TW);
+        int64_t sp = cdiv(2048, out_tiles);
+        if (sp < 1) sp = 1;
+        if (sp > chunks) sp = chunks;
+        if (sp > 65535) sp = 65535;
+        a.zsplit = (int)sp;
+    }
     int r;
     const bool narrow = cout_g <= 16;      // 16 x 256 tile for the lifting convs, 64 x 64 otherwise
 #define LLDWT_WG(KS_)                                                                                  \

@@ -1,0 +1,78 @@
+"""GPU: size-independent properties at BASELINE.json's full sizes (the oracle is too slow there)."""
+import pytest
+import torch
+
+from helpers import filled
+from oracle import weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(levels, **over):
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import \
+        LiftingBasedDWTNetWrapper
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
+    cfg = make_config(dwtlevels=levels, mode="validate", **over)
+    net = LiftingBasedDWTNetWrapper(cfg)
+    net.load_state_dict(filled(weights.wrapper_template(dict(cfg))), strict=False)
+    return net.to("cuda:0").eval(), cfg
+
+
+@pytest.mark.parametrize("B,S,L", [(8, 512, 4), (16, 256, 3), (1, 1024, 4)])
+def test_perfect_reconstruction_full_size(B, S, L):
+    """inverse(forward(x)) == x to fp32 round-off for block_property == 'same' (SURVEY 4.1), configs 2-4 sizes."""
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.layers.lifting_dwt_nets import (
+        lifting_forward_planes, lifting_inverse_planes)
+    net, _ = _net(L)
+    aes = [n.autoencoder for n in net.nets()]
+    x = torch.rand(3, B, 1, S, S, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1)) - 0.5
+    with torch.no_grad():
+        ll, yh = lifting_forward_planes(aes, x)
+        xr = lifting_inverse_planes(aes, ll, yh)
+    assert float((xr - x).abs().max()) < 5e-5
+    assert ll.shape == (3, B, 1, S >> L, S >> L) and yh[0].shape == (3, B, 3, S // 2, S // 2)
+
+
+def test_full_size_forward_properties():
+    """cfg 3 (8x3x512x512, L=4, conditioned2): bits >= 0, finite, deterministic; shard consistency: the batch run equals
+    the per-image runs (images are independent -> data-parallel sharding changes nothing)."""
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import rate_planes
+    net, _ = _net(4)
+    x = torch.rand(8, 3, 512, 512, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(2))
+    with torch.no_grad():
+        y = ops.rgb_to_ycc(x)
+        si_xe, si_xo = rate_planes(net.nets(), y, False)
+        si_xe2, si_xo2 = rate_planes(net.nets(), y, False)
+        assert torch.equal(si_xe, si_xe2) and all(torch.equal(a, b) for a, b in zip(si_xo, si_xo2))    # deterministic
+        for t in [si_xe] + si_xo:
+            assert bool(torch.isfinite(t).all()) and float(t.min()) >= 0.0
+        assert [tuple(t.shape[2:]) for t in si_xo] == [(3, 256, 256), (3, 128, 128), (3, 64, 64), (3, 32, 32)]
+        # shard of 2 images == the same images inside the batch of 8
+        y2 = ops.rgb_to_ycc(x[2:4].contiguous())
+        s_xe, s_xo = rate_planes(net.nets(), y2, False)
+        assert float((s_xe - si_xe[:, 2:4]).abs().max()) < 1e-5
+        for a, b in zip(s_xo, si_xo):
+            assert float((a - b[:, 2:4]).abs().max()) < 1e-4
+    total = sum(float(t.double().sum()) for t in [si_xe] + si_xo)
+    assert total > 0
+
+
+def test_linear_lifting_is_linear_full_size():
+    """linearity_flag != 1 (no tanh): the transform is linear in x -> T(a x1 + b x2) == a T(x1) + b T(x2)."""
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.layers.lifting_dwt_nets import \
+        lifting_forward_planes
+    net, _ = _net(4, linearity_flag=0)
+    aes = [n.autoencoder for n in net.nets()]
+    # a linear P-block still has biases: compare against the affine map, i.e. T(x) - T(0)
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    x1 = torch.rand(3, 2, 1, 512, 512, device="cuda:0", generator=g) - 0.5
+    x2 = torch.rand(3, 2, 1, 512, 512, device="cuda:0", generator=g) - 0.5
+    with torch.no_grad():
+        f = lambda t: lifting_forward_planes(aes, t.contiguous())
+        l0, y0 = f(torch.zeros_like(x1))
+        l1, y1 = f(x1)
+        l2, y2 = f(x2)
+        l3, y3 = f(0.3 * x1 - 1.7 * x2)
+    assert float((l3 - l0 - (0.3 * (l1 - l0) - 1.7 * (l2 - l0))).abs().max()) < 2e-4
+    assert float((y3[0] - y0[0] - (0.3 * (y1[0] - y0[0]) - 1.7 * (y2[0] - y0[0]))).abs().max()) < 2e-4
