@@ -90,11 +90,14 @@ SIGNATURES = {
     "lldwt_ycc_to_rgb_bwd": (_i, [_p, _p, _i64, _i64, _i64, _p]),
     "lldwt_quantize": (_i, [_p, _p, _p, _i64, _p]),
     "lldwt_factorized_rate": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
+    "lldwt_factorized_rate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
     "lldwt_sq_err_sum": (_i, [_p, _p, _i64, _p, _p]),
     "lldwt_sum": (_i, [_p, _i64, _p, _p]),
     "lldwt_cdf97_ws_bytes": (_i64, [_i64, _i64, _i64]),
     "lldwt_cdf97_forward": (_i, [_p, _p, C.POINTER(_p), _i64, _i64, _i64, _i, _p, _i64, _p]),
     "lldwt_cdf97_inverse": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i, _p, _i64, _p]),
+    "lldwt_cdf97_forward_ex": (_i, [_p, _p, C.POINTER(_p), _i64, _i64, _i64, _i, _i, _p, _i64, _p]),
+    "lldwt_cdf97_inverse_ex": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i, _i, _p, _i64, _p]),
 }
 
 _lib = None

@@ -84,15 +84,17 @@ class LiftingBasedDWTAgent(BaseAgent):
     def train_step(self, x, noise_fn=None):
         """One optimisation step on a batch x (B,3,H,W) in [0,1] (agents/liftingDWT_agent.py:78-98): zero_grad, forward
         (training noise), loss / grad_acc_iters, backward (HIP kernels), gradient all-reduce over ranks, Adam step."""
-        if self.clrch != 1:
-            raise NotImplementedError("training on the HIP path needs clrch == 1 (three per-plane networks)")
         if self._bucket is None:
             self._bucket = parallel.FlatGradBucket(self.model.parameters())     # one flat fp32 bucket for RCCL
         self._bucket.zero_()
-        y = ops.rgb_to_ycc(x.contiguous())                                     # :86-87
-        yhat, si_xe, si_xo = forward_planes_train(self.model.nets(), y, noise_fn)
-        xhat = ag.YccToRgbFn.apply(yhat)                                        # :90-94
         xs = (x - 0.5).contiguous()
+        if self.clrch == 1:
+            y = ops.rgb_to_ycc(x.contiguous())                                 # :86-87
+            yhat, si_xe, si_xo = forward_planes_train(self.model.nets(), y, noise_fn)
+            xhat = ag.YccToRgbFn.apply(yhat)                                    # :90-94
+        else:                                                                   # rgb processed together (:80-84)
+            xh, si_xe, si_xo = forward_planes_train(self.model.nets(), xs[None].contiguous(), noise_fn)
+            xhat, si_xe, si_xo = xh[0], si_xe[0], [t[0] for t in si_xo]
         loss, mse, r1, r2 = self.train_loss.forward3_train(xs, xhat, si_xe, si_xo)
         (loss / self.grad_acc_iters).float().backward()                        # :97
         self._bucket.all_reduce_mean()                                          # data-parallel: mean gradient over ranks

@@ -60,6 +60,51 @@ class GaussRateFn(torch.autograd.Function):
         return dx, dparams, None
 
 
+class FactorizedRateFn(torch.autograd.Function):
+    """(bits, q) of the factorized model (lldwt_factorized_rate); eb: (P,C,59) packed raw parameters (built by torch.cat
+    from the module parameters, so their gradients flow back through the tape)."""
+
+    @staticmethod
+    def forward(ctx, x, eb, noise):
+        bits, q = ops.factorized_rate(x, eb, noise)
+        ctx.save_for_backward(x, eb, noise)
+        ctx.mark_non_differentiable(q) if noise is None else None
+        return bits, q
+
+    @staticmethod
+    def backward(ctx, gbits, gq):
+        x, eb, noise = ctx.saved_tensors
+        dx, deb = ops.factorized_rate_bwd(x, eb, noise, gbits.contiguous())
+        if noise is not None and gq is not None:
+            dx = dx + gq            # q = x + noise: identity path to the decoder
+        return dx, deb, None
+
+
+class Cdf97Fn(torch.autograd.Function):
+    """Fixed CDF 9/7 analysis; backward = its adjoint (lldwt_cdf97_inverse_ex adj=1; bior4.4 is not orthogonal)."""
+
+    @staticmethod
+    def forward(ctx, x, levels):
+        ll, yh = ops.cdf97_forward(x, levels)
+        return (ll, *yh)
+
+    @staticmethod
+    def backward(ctx, g_ll, *g_yh):
+        return ops.cdf97_inverse(g_ll.contiguous(), [t.contiguous() for t in g_yh], adj=True), None
+
+
+class Cdf97InvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ll, *yh):
+        ctx.levels = len(yh)
+        return ops.cdf97_inverse(ll.contiguous(), [t.contiguous() for t in yh])
+
+    @staticmethod
+    def backward(ctx, gx):
+        g_ll, g_yh = ops.cdf97_forward(gx.contiguous(), ctx.levels, adj=True)
+        return (g_ll, *g_yh)
+
+
 class QuantNoiseFn(torch.autograd.Function):
     """quantize(x, 'noise') = x + U(-.5,.5): identity gradient."""
 

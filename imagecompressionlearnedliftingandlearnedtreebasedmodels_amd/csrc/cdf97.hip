@@ -25,7 +25,9 @@ struct V3 {   // (Z, rows, cols) strided view
 };
 
 // analysis along `axis` (0 = rows/height, 1 = cols/width).  in: (Z,h,w); lo,hi: half size along axis.
-__global__ __launch_bounds__(256) void k_afb(V3 in, V3 lo, V3 hi, int h, int w, int axis) {
+// adj == 0: analysis (dec filters, x[(2k + 5 - m) mod N]);  adj == 1: ADJOINT of the synthesis k_sfb, needed by the
+// backward pass of the inverse transform (rec filters, g[(2k - 4 + m) mod N])
+__global__ __launch_bounds__(256) void k_afb(V3 in, V3 lo, V3 hi, int h, int w, int axis, int adj) {
     const int64_t z = blockIdx.z;
     const int oh = axis == 0 ? h / 2 : h, ow = axis == 1 ? w / 2 : w;
     const int N = axis == 0 ? h : w;
@@ -35,12 +37,12 @@ __global__ __launch_bounds__(256) void k_afb(V3 in, V3 lo, V3 hi, int h, int w, 
             float a = 0.f, d = 0.f;
 #pragma unroll
             for (int m = 0; m < 10; ++m) {
-                int n = (2 * k + 5 - m) % N;
+                int n = (adj ? 2 * k - 4 + m : 2 * k + 5 - m) % N;
                 if (n < 0) n += N;
                 const int yy = axis == 0 ? n : y, xx = axis == 1 ? n : x;
                 const float v = in.p[z * in.sz + (int64_t)yy * in.sy + (int64_t)xx * in.sx];
-                a = fmaf(c_dec_lo[m], v, a);
-                d = fmaf(c_dec_hi[m], v, d);
+                a = fmaf(adj ? c_rec_lo[m] : c_dec_lo[m], v, a);
+                d = fmaf(adj ? c_rec_hi[m] : c_dec_hi[m], v, d);
             }
             lo.p[z * lo.sz + (int64_t)y * lo.sy + (int64_t)x * lo.sx] = a;
             hi.p[z * hi.sz + (int64_t)y * hi.sy + (int64_t)x * hi.sx] = d;
@@ -48,7 +50,9 @@ __global__ __launch_bounds__(256) void k_afb(V3 in, V3 lo, V3 hi, int h, int w, 
 }
 
 // synthesis along `axis`.  lo,hi: half size along axis; out: (Z,h,w).
-__global__ __launch_bounds__(256) void k_sfb(V3 lo, V3 hi, V3 out, int h, int w, int axis) {
+// adj == 0: synthesis (rec filters, q = (n + 4 - t) mod N);  adj == 1: ADJOINT of the analysis k_afb, needed by the backward
+// pass of the forward transform (dec filters, q = (n - 5 + t) mod N)
+__global__ __launch_bounds__(256) void k_sfb(V3 lo, V3 hi, V3 out, int h, int w, int axis, int adj) {
     const int64_t z = blockIdx.z;
     const int N = axis == 0 ? h : w;
     for (int y = blockIdx.y; y < h; y += gridDim.y)
@@ -57,13 +61,13 @@ __global__ __launch_bounds__(256) void k_sfb(V3 lo, V3 hi, V3 out, int h, int w,
             float acc = 0.f;
 #pragma unroll
             for (int t = 0; t < 10; ++t) {
-                int q = (n + 4 - t) % N;
+                int q = (adj ? n - 5 + t : n + 4 - t) % N;
                 if (q < 0) q += N;
                 if ((q & 1) == 0) {
                     const int k = q >> 1;
                     const int yy = axis == 0 ? k : y, xx = axis == 1 ? k : x;
-                    acc = fmaf(lo.p[z * lo.sz + (int64_t)yy * lo.sy + (int64_t)xx * lo.sx], c_rec_lo[t], acc);
-                    acc = fmaf(hi.p[z * hi.sz + (int64_t)yy * hi.sy + (int64_t)xx * hi.sx], c_rec_hi[t], acc);
+                    acc = fmaf(lo.p[z * lo.sz + (int64_t)yy * lo.sy + (int64_t)xx * lo.sx], adj ? c_dec_lo[t] : c_rec_lo[t], acc);
+                    acc = fmaf(hi.p[z * hi.sz + (int64_t)yy * hi.sy + (int64_t)xx * hi.sx], adj ? c_dec_hi[t] : c_rec_hi[t], acc);
                 }
             }
             out.p[z * out.sz + (int64_t)y * out.sy + (int64_t)x * out.sx] = acc;
@@ -96,6 +100,11 @@ static int cdf_args(const char* who, int64_t Z, int64_t H, int64_t W, int levels
 
 extern "C" int lldwt_cdf97_forward(const float* x, float* ll, float* const* yh, int64_t Z, int64_t H, int64_t W,
                                    int levels, void* ws, int64_t ws_bytes, void* stream) {
+    return lldwt_cdf97_forward_ex(x, ll, yh, Z, H, W, levels, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int lldwt_cdf97_forward_ex(const float* x, float* ll, float* const* yh, int64_t Z, int64_t H, int64_t W,
+                                      int levels, int adj, void* ws, int64_t ws_bytes, void* stream) {
     int r = cdf_args("cdf97_forward", Z, H, W, levels, ws, ws_bytes);
     if (r) return r;
     LLDWT_REQUIRE(x && ll && yh, "cdf97_forward: null pointer");
@@ -108,12 +117,12 @@ extern "C" int lldwt_cdf97_forward(const float* x, float* ll, float* const* yh, 
         const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2, sub = hh * wh;
         V3 in{const_cast<float*>(cur), h * w, w, 1};
         V3 lw{low, h * wh, wh, 1}, hw_{hiw, h * wh, wh, 1};
-        hipLaunchKernelGGL(k_afb, grid2d(h, wh, Z), dim3(256), 0, st, in, lw, hw_, (int)h, (int)w, 1);
+        hipLaunchKernelGGL(k_afb, grid2d(h, wh, Z), dim3(256), 0, st, in, lw, hw_, (int)h, (int)w, 1, adj);
         float* llout = lev == levels - 1 ? ll : llb[lev & 1];
         float* y = yh[lev];
         V3 vLL{llout, sub, wh, 1}, vLH{y, 3 * sub, wh, 1}, vHL{y + sub, 3 * sub, wh, 1}, vHH{y + 2 * sub, 3 * sub, wh, 1};
-        hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, lw, vLL, vLH, (int)h, (int)wh, 0);
-        hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, hw_, vHL, vHH, (int)h, (int)wh, 0);
+        hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, lw, vLL, vLH, (int)h, (int)wh, 0, adj);
+        hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, hw_, vHL, vHH, (int)h, (int)wh, 0, adj);
         cur = llout;
     }
     return check_launch("cdf97_forward");
@@ -121,6 +130,11 @@ extern "C" int lldwt_cdf97_forward(const float* x, float* ll, float* const* yh, 
 
 extern "C" int lldwt_cdf97_inverse(const float* ll, const float* const* yh, float* x, int64_t Z, int64_t H, int64_t W,
                                    int levels, void* ws, int64_t ws_bytes, void* stream) {
+    return lldwt_cdf97_inverse_ex(ll, yh, x, Z, H, W, levels, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int lldwt_cdf97_inverse_ex(const float* ll, const float* const* yh, float* x, int64_t Z, int64_t H, int64_t W,
+                                      int levels, int adj, void* ws, int64_t ws_bytes, void* stream) {
     int r = cdf_args("cdf97_inverse", Z, H, W, levels, ws, ws_bytes);
     if (r) return r;
     LLDWT_REQUIRE(x && ll && yh, "cdf97_inverse: null pointer");
@@ -135,11 +149,11 @@ extern "C" int lldwt_cdf97_inverse(const float* ll, const float* const* yh, floa
         V3 vLL{const_cast<float*>(cur), sub, wh, 1}, vLH{y, 3 * sub, wh, 1}, vHL{y + sub, 3 * sub, wh, 1},
             vHH{y + 2 * sub, 3 * sub, wh, 1};
         V3 lw{low, h * wh, wh, 1}, hw_{hiw, h * wh, wh, 1};
-        hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vLL, vLH, lw, (int)h, (int)wh, 0);
-        hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vHL, vHH, hw_, (int)h, (int)wh, 0);
+        hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vLL, vLH, lw, (int)h, (int)wh, 0, adj);
+        hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vHL, vHH, hw_, (int)h, (int)wh, 0, adj);
         float* out = lev == 0 ? x : llb[lev & 1];
         V3 vo{out, h * w, w, 1};
-        hipLaunchKernelGGL(k_sfb, grid2d(h, w, Z), dim3(256), 0, st, lw, hw_, vo, (int)h, (int)w, 1);
+        hipLaunchKernelGGL(k_sfb, grid2d(h, w, Z), dim3(256), 0, st, lw, hw_, vo, (int)h, (int)w, 1, adj);
         cur = out;
     }
     return check_launch("cdf97_inverse");

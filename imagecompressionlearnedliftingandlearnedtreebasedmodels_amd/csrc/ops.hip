@@ -389,6 +389,144 @@ __global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict
     if (bit_sum) block_accumulate(local, bit_sum);
 }
 
+// ---- backward of the factorized rate (training: v = x + noise) -------------------------------------------------------
+// forward chain on processed params e (softplus / tanh applied), keeping what the backward needs
+struct EbTrace {
+    float a[4][3];    // pre-gate activations of layers 0..3
+    float h[4][3];    // gated outputs
+};
+
+__device__ __forceinline__ float eb_logits_trace(const float* __restrict__ e, float v, EbTrace& tr) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        tr.a[0][j] = e[j] * v + e[3 + j];
+        tr.h[0][j] = tr.a[0][j] + e[6 + j] * tanhf(tr.a[0][j]);
+    }
+    const float* q = e + 9;
+#pragma unroll
+    for (int layer = 1; layer < 4; ++layer) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float a = q[j * 3 + 0] * tr.h[layer - 1][0];
+            a += q[j * 3 + 1] * tr.h[layer - 1][1];
+            a += q[j * 3 + 2] * tr.h[layer - 1][2];
+            a += q[9 + j];
+            tr.a[layer][j] = a;
+            tr.h[layer][j] = a + q[12 + j] * tanhf(a);
+        }
+        q += 15;
+    }
+    return q[0] * tr.h[3][0] + q[1] * tr.h[3][1] + q[2] * tr.h[3][2] + q[3];
+}
+
+// accumulates d(out)/d(processed params) * g into ge[59] (same layout as e) and returns d(out)/dv * g
+__device__ __forceinline__ float eb_logits_bwd(const float* __restrict__ e, float v, const EbTrace& tr, float g, float* ge) {
+    float gh[3];
+    const float* q = e + 54;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ge[54 + k] += tr.h[3][k] * g;
+        gh[k] = q[k] * g;
+    }
+    ge[57] += g;
+#pragma unroll
+    for (int layer = 3; layer >= 1; --layer) {
+        q = e + 9 + 15 * (layer - 1);
+        float* gq = ge + 9 + 15 * (layer - 1);
+        float ga[3], ghp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float th = tanhf(tr.a[layer][j]);
+            ga[j] = gh[j] * (1.f + q[12 + j] * (1.f - th * th));
+            gq[12 + j] += gh[j] * th;
+            gq[9 + j] += ga[j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                gq[j * 3 + k] += ga[j] * tr.h[layer - 1][k];
+                ghp[k] += q[j * 3 + k] * ga[j];
+            }
+        }
+        gh[0] = ghp[0]; gh[1] = ghp[1]; gh[2] = ghp[2];
+    }
+    float gv = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float th = tanhf(tr.a[0][j]);
+        const float ga = gh[j] * (1.f + e[6 + j] * (1.f - th * th));
+        ge[6 + j] += gh[j] * th;
+        ge[3 + j] += ga;
+        ge[j] += ga * v;
+        gv += e[j] * ga;
+    }
+    return gv;
+}
+
+// grads wrt x (Z,C,hw) and wrt the RAW packed EntropyBottleneck parameters deb (planes,C,59) (atomics; zero it first).
+__global__ __launch_bounds__(256) void k_factorized_rate_bwd(const float* __restrict__ x, const float* __restrict__ eb,
+                                                             const float* __restrict__ noise, const float* __restrict__ gbits,
+                                                             float* __restrict__ dx, float* __restrict__ deb, int batch,
+                                                             int C, int64_t hw) {
+    __shared__ float e[LLDWT_EB_FLOATS + 5];
+    __shared__ float dfac[LLDWT_EB_FLOATS + 5];     // d processed / d raw (sigmoid for softplus, 1 - t^2 for tanh, 1 else)
+    __shared__ float red[4][LLDWT_EB_FLOATS + 1];
+    const int c = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const float* src = eb + ((int64_t)plane * C + c) * LLDWT_EB_FLOATS;
+    if (threadIdx.x < LLDWT_EB_FLOATS) {
+        const int i = threadIdx.x;
+        float v = src[i], f = 1.f;
+        bool is_m, is_f;
+        if (i < 9) { is_m = i < 3; is_f = i >= 6; }
+        else if (i < 54) { const int r = (i - 9) % 15; is_m = r < 9; is_f = r >= 12; }
+        else { is_m = i < 57; is_f = false; }
+        if (is_m) { f = 1.f / (1.f + expf(-v)); v = softplusf(v); }
+        else if (is_f) { v = tanhf(v); f = 1.f - v * v; }
+        if (i == 58) f = 0.f;      // the median does not enter the training-mode forward
+        e[i] = v;
+        dfac[i] = f;
+    }
+    __syncthreads();
+    const int64_t base = (z * C + c) * hw;
+    float ge[LLDWT_EB_FLOATS];
+#pragma unroll
+    for (int i = 0; i < LLDWT_EB_FLOATS; ++i) ge[i] = 0.f;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[base + p] + (noise ? noise[base + p] : 0.f);
+        EbTrace tl, tu;
+        const float lower = eb_logits_trace(e, v - 0.5f, tl);
+        const float upper = eb_logits_trace(e, v + 0.5f, tu);
+        const float sm = lower + upper;
+        const float sign = sm > 0.f ? -1.f : (sm < 0.f ? 1.f : 0.f);
+        const float su = 1.f / (1.f + expf(-sign * upper)), sl = 1.f / (1.f + expf(-sign * lower));
+        const float diff = su - sl;
+        const float pr = fabsf(diff), pb = fmaxf(pr, 1e-9f);
+        float gp = -gbits[base + p] / (pb * 0.69314718055994530942f);
+        if (!(pr >= 1e-9f || gp < 0.f)) gp = 0.f;                       // LowerBound(1e-9) rule
+        const float sd = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        const float gu = gp * sd * su * (1.f - su) * sign;
+        const float gl = -gp * sd * sl * (1.f - sl) * sign;
+        float gv = eb_logits_bwd(e, v + 0.5f, tu, gu, ge);
+        gv += eb_logits_bwd(e, v - 0.5f, tl, gl, ge);
+        dx[base + p] = noise ? gv : 0.f;                                 // eval: round() has zero gradient
+    }
+    // block reduction of the 58 parameter partials, then one atomic per parameter
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < LLDWT_EB_FLOATS - 1; ++i) {
+        float v = ge[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wv][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LLDWT_EB_FLOATS - 1) {
+        const int i = threadIdx.x;
+        const float s = (red[0][i] + red[1][i] + red[2][i] + red[3][i]) * dfac[i];
+        atomicAdd(deb + ((int64_t)plane * C + c) * LLDWT_EB_FLOATS + i, s);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sq_err_sum(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
                                                     double* __restrict__ out) {
     double local = 0;
@@ -591,4 +729,17 @@ extern "C" int lldwt_ycc_to_rgb_bwd(const float* grgb, float* gycc, int64_t B, i
     LLDWT_REQUIRE(grgb && gycc && B > 0 && H > 0 && W > 0, "ycc_to_rgb_bwd: bad arguments");
     hipLaunchKernelGGL(k_ycc_to_rgb_bwd, dim3(ew_grid(B * H * W)), dim3(256), 0, (hipStream_t)stream, grgb, gycc, B, H * W);
     return check_launch("ycc_to_rgb_bwd");
+}
+
+extern "C" int lldwt_factorized_rate_bwd(const float* x, const float* eb, const float* noise, const float* gbits, float* dx,
+                                         float* deb, int64_t planes, int64_t batch, int C, int64_t hw, void* stream) {
+    LLDWT_REQUIRE(x && eb && gbits && dx && deb && planes > 0 && batch > 0 && C > 0 && hw > 0, "factorized_rate_bwd: bad arguments");
+    LLDWT_REQUIRE(planes * batch <= 65535 && C <= 65535, "factorized_rate_bwd: grid too large");
+    int64_t gx = cdiv(hw, 256 * 8);
+    if (gx < 1) gx = 1;
+    if (gx > 256) gx = 256;
+    dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_factorized_rate_bwd, grid, dim3(256), 0, (hipStream_t)stream, x, eb, noise, gbits, dx, deb,
+                       (int)batch, C, hw);
+    return check_launch("factorized_rate_bwd");
 }

@@ -369,36 +369,26 @@ def _lift_params(nets):
     return taps.contiguous(), meta, Wt
 
 
-def forward_planes_train(nets, x, noise_fn=None):
-    """Differentiable encode -> entropy model (noise) -> decode for the three plane nets (LiftingBasedDWT_net.py:154-170
-    in training mode: quirk 2 of SURVEY 8a -- the context/decoder see noise sample #1, the rate noise sample #2)."""
-    aenc = [n.autoencoder for n in nets]
-    em = [n.entropymodel for n in nets]
-    if not isinstance(aenc[0], LiftingBasedNeuralWaveletv4) or not isinstance(em[0], DWTConditioned2EntropyLayerZTsepSubbands):
-        raise NotImplementedError("training on the HIP path is built for LiftingBasedNeuralWaveletv4 + "
-                                  "conditioned2ZTsepSubbands (DESIGN.md 8)")
-    if aenc[0].config.scale == 1:
-        raise NotImplementedError("training with config.scale == 1 is not built")
-    L = aenc[0].waveletLevel
-    taps, meta, Wt = _lift_params(aenc)
-    outs = ag.LiftingFn.apply(x, taps, meta, *Wt)
-    ll, yh = outs[0], list(outs[1:])
-    out_xe = _ae_train([n.Yl_ae for n in aenc], ll, False)
-    out_xo = [_ae_train([n.Yh_ae[i] for n in aenc], yh[i], False) for i in range(L)]
+def _eb_train(ebs):
+    """(P,C,59) packed EntropyBottleneck parameters WITH autograd history."""
+    from ...entropy_models import pack_entropy_bottleneck
+    return torch.stack([pack_entropy_bottleneck(dict(e.named_parameters())) for e in ebs], 0).contiguous()
 
-    def rnd(t):
-        return torch.empty_like(t).uniform_(-0.5, 0.5) if noise_fn is None else noise_fn(t)
 
-    def stack5(seqs, t):
-        for n in (0, 2, 4, 6, 8):
-            t = _tconv([s_[n] for s_ in seqs], t, ops.ACT_NONE if n == 8 else ops.ACT_LRELU)
-        return t
+def _stack5(seqs, t):
+    for n in (0, 2, 4, 6, 8):
+        t = _tconv([s_[n] for s_ in seqs], t, ops.ACT_NONE if n == 8 else ops.ACT_LRELU)
+    return t
+
+
+def _entropy_train_cond2(em, out_xe, out_xo, rnd):
+    L = len(out_xo)
     xe_q = ag.QuantNoiseFn.apply(out_xe, rnd(out_xe))
-    si_xe = ag.GaussRateFn.apply(out_xe, stack5([l.csc_xe for l in em], xe_q), rnd(out_xe))
+    si_xe = ag.GaussRateFn.apply(out_xe, _stack5([l.csc_xe for l in em], xe_q), rnd(out_xe))
     q_list, si_list = [], []
     i = L - 1
     xo_q = ag.QuantNoiseFn.apply(out_xo[i], rnd(out_xo[i]))
-    si_list.append(ag.GaussRateFn.apply(out_xo[i], stack5([l.csc_list[i] for l in em], xo_q), rnd(out_xo[i])))
+    si_list.append(ag.GaussRateFn.apply(out_xo[i], _stack5([l.csc_list[i] for l in em], xo_q), rnd(out_xo[i])))
     q_list.append(xo_q)
     parent = xo_q
     for i in range(L - 2, -1, -1):
@@ -417,9 +407,113 @@ def forward_planes_train(nets, x, noise_fn=None):
         parent = xo_q
     q_list.reverse()
     si_list.reverse()
+    return si_xe, si_list, xe_q, q_list
+
+
+def _entropy_train_factorized(em, out_xe, out_xo, rnd):
+    si_list, q_list = [], []
+    for i in range(len(out_xo)):
+        bits, q = ag.FactorizedRateFn.apply(out_xo[i], _eb_train([l.ent_out_xo_list[i] for l in em]), rnd(out_xo[i]))
+        si_list.append(bits)
+        q_list.append(q)
+    si_xe, xe_q = ag.FactorizedRateFn.apply(out_xe, _eb_train([l.ent_out_xe for l in em]), rnd(out_xe))
+    return si_xe, si_list, xe_q, q_list
+
+
+def _entropy_train_ezwt(em, out_xe, out_xo, rnd):
+    L = len(out_xo)
+    si_xe, xe_q = ag.FactorizedRateFn.apply(out_xe, _eb_train([l.ent_out_xe for l in em]), rnd(out_xe))
+    bits, q = ag.FactorizedRateFn.apply(out_xo[L - 1], _eb_train([l.ent_out_xo for l in em]), rnd(out_xo[L - 1]))
+    si_list, q_list = [bits], [q]
+    parent = q
+    for i in range(L - 2, -1, -1):
+        seqs = [l.plc_list[i] for l in em]
+        t = _tconv([s_[0] for s_ in seqs], parent, ops.ACT_LRELU, upsample2=True)
+        t = _tconv([s_[2] for s_ in seqs], t, ops.ACT_LRELU)
+        ms = _tconv([s_[4] for s_ in seqs], t)
+        noise = rnd(out_xo[i])
+        si_list.append(ag.GaussRateFn.apply(out_xo[i], ms, noise))
+        q = ag.QuantNoiseFn.apply(out_xo[i], noise)       # forward() returns x + the SAME noise as the rate (:832)
+        q_list.append(q)
+        parent = q
+    q_list.reverse()
+    si_list.reverse()
+    return si_xe, si_list, xe_q, q_list
+
+
+def _entropy_train_ztblock(em, out_xe, out_xo, rnd):
+    L = len(out_xo)
+    si_xe, xe_q = ag.FactorizedRateFn.apply(out_xe, _eb_train([l.ent_out_xe for l in em]), rnd(out_xe))
+    bits, q = ag.FactorizedRateFn.apply(out_xo[L - 1], _eb_train([l.ent_out_xo for l in em]), rnd(out_xo[L - 1]))
+    si_list, q_list = [bits], [q]
+    con = q
+    slots = ((0, 0), (0, 1), (1, 0), (1, 1))
+    for i in range(L - 1):
+        lev = L - i - 2
+        x = out_xo[lev]
+        P, B, _, H, W = x.shape
+        sis, qs = [], []
+        for j in range(3):
+            xj = x[:, :, j:j + 1].contiguous()
+            qj = ag.QuantNoiseFn.apply(xj, rnd(xj))
+            ee, eo, oe = qj[..., 0::2, 0::2], qj[..., 0::2, 1::2], qj[..., 1::2, 0::2]
+            dep1 = con[:, :, j:j + 1]
+            deps = (dep1, torch.cat((dep1, ee), 2), torch.cat((dep1, ee, eo), 2), torch.cat((dep1, ee, eo, oe), 2))
+            idx = j + i * 3
+            rows = []
+            for ch, kind in ((0, "sigma"), (1, "mu")):
+                ph = []
+                for k in range(4):
+                    ph.append(_stack5([getattr(l, "dep_%d_list_%s" % (k + 1, kind))[idx] for l in em], deps[k].contiguous()))
+                # interleave the 4 phases back to (H, W): data movement only
+                top = torch.stack((ph[0], ph[1]), -1).flatten(-2)          # even rows: ee, eo interleaved along W
+                bot = torch.stack((ph[2], ph[3]), -1).flatten(-2)
+                rows.append(torch.stack((top, bot), -2).flatten(-3, -2))   # interleave rows
+            params = torch.cat(rows, 2).contiguous()
+            sis.append(ag.GaussRateFn.apply(xj, params, rnd(xj)))
+            qs.append(qj)
+        si_list.append(torch.cat(sis, 2))
+        con = torch.cat(qs, 2)
+        q_list.append(con)
+    q_list.reverse()
+    si_list.reverse()
+    return si_xe, si_list, xe_q, q_list
+
+
+def forward_planes_train(nets, x, noise_fn=None):
+    """Differentiable encode -> entropy model (noise) -> decode for the plane nets (LiftingBasedDWT_net.py:154-170 in
+    training mode; quirk 2 of SURVEY 8a: the context/decoder see noise sample #1, the rate an independent sample #2)."""
+    aenc = [n.autoencoder for n in nets]
+    em = [n.entropymodel for n in nets]
+
+    def rnd(t):
+        return torch.empty_like(t).uniform_(-0.5, 0.5) if noise_fn is None else noise_fn(t)
+
+    lifting = isinstance(aenc[0], LiftingBasedNeuralWaveletv4)
+    if lifting:
+        if aenc[0].config.scale == 1:
+            raise NotImplementedError("training with config.scale == 1 is not built")
+        L = aenc[0].waveletLevel
+        taps, meta, Wt = _lift_params(aenc)
+        outs = ag.LiftingFn.apply(x, taps, meta, *Wt)
+        ll, yh = outs[0], list(outs[1:])
+    else:
+        L = aenc[0].dwtlevels
+        outs = ag.Cdf97Fn.apply(x, L)
+        ll = outs[0]
+        yh = [t.reshape(t.shape[0], t.shape[1], -1, t.shape[4], t.shape[5]) for t in outs[1:]]
+    out_xe = _ae_train([n.Yl_ae for n in aenc], ll, False)
+    out_xo = [_ae_train([n.Yh_ae[i] for n in aenc], yh[i], False) for i in range(L)]
+    fn = {DWTConditioned2EntropyLayerZTsepSubbands: _entropy_train_cond2, DWTFactorizedEntropyLayer: _entropy_train_factorized,
+          onlyEZWT: _entropy_train_ezwt, DWTConditioned2EntropyLayerZTBlock: _entropy_train_ztblock}[type(em[0])]
+    si_xe, si_list, xe_q, q_list = fn(em, out_xe, out_xo, rnd)
     Yl = _ae_train([n.Yl_ae for n in aenc], xe_q, True)
     Yh = [_ae_train([n.Yh_ae[i] for n in aenc], q_list[i], True) for i in range(L)]
-    xhat = ag.LiftingInvFn.apply(taps, meta, L, Yl, *Yh, *Wt)
+    if lifting:
+        xhat = ag.LiftingInvFn.apply(taps, meta, L, Yl, *Yh, *Wt)
+    else:
+        Yh6 = [t.reshape(t.shape[0], t.shape[1], t.shape[2] // 3, 3, t.shape[3], t.shape[4]) for t in Yh]
+        xhat = ag.Cdf97InvFn.apply(Yl, *Yh6)
     return xhat, si_xe, si_list
 
 

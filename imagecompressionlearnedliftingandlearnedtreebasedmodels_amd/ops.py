@@ -130,7 +130,7 @@ def lifting_inverse(ll, yh, taps, packed, Cc, K, res_weight, linear=False, scale
     return x
 
 
-def cdf97_forward(x, levels):
+def cdf97_forward(x, levels, adj=False):
     """x: (Z..., H, W) as (P,B,C,H,W) -> (ll, [yh_i (P,B,C*3? no: (P,B*C,3,h,w))]).  Channels are folded into batch."""
     lib = _lib.load()
     P, B, Cc, H, W = x.shape
@@ -140,12 +140,12 @@ def cdf97_forward(x, levels):
     yh = [torch.empty(P, B, Cc, 3, H >> (i + 1), W >> (i + 1), device=dev, dtype=torch.float32) for i in range(levels)]
     nb = lib.lldwt_cdf97_ws_bytes(Z, H, W)
     ws = workspace(nb, dev)
-    check(lib.lldwt_cdf97_forward(_chk(x, "x"), _chk(ll), _ptr_array(yh), Z, H, W, levels, C.c_void_p(ws.data_ptr()), nb,
-                                  _stream()), "cdf97_forward")
+    check(lib.lldwt_cdf97_forward_ex(_chk(x, "x"), _chk(ll), _ptr_array(yh), Z, H, W, levels, int(bool(adj)),
+                                     C.c_void_p(ws.data_ptr()), nb, _stream()), "cdf97_forward")
     return ll, yh
 
 
-def cdf97_inverse(ll, yh):
+def cdf97_inverse(ll, yh, adj=False):
     lib = _lib.load()
     levels = len(yh)
     P, B, Cc, hl, wl = ll.shape
@@ -156,8 +156,8 @@ def cdf97_inverse(ll, yh):
         _chk(t, "yh")
     nb = lib.lldwt_cdf97_ws_bytes(Z, H, W)
     ws = workspace(nb, ll.device)
-    check(lib.lldwt_cdf97_inverse(_chk(ll, "ll"), _ptr_array(yh), _chk(x), Z, H, W, levels, C.c_void_p(ws.data_ptr()), nb,
-                                  _stream()), "cdf97_inverse")
+    check(lib.lldwt_cdf97_inverse_ex(_chk(ll, "ll"), _ptr_array(yh), _chk(x), Z, H, W, levels, int(bool(adj)),
+                                     C.c_void_p(ws.data_ptr()), nb, _stream()), "cdf97_inverse")
     return x
 
 
@@ -374,6 +374,15 @@ def gauss_rate_bwd(x, params, noise, gbits):
     check(_lib.load().lldwt_gauss_rate_bwd(_chk(x), _chk(params), _opt(noise), _chk(gbits), _chk(dx), _chk(dparams), P * B,
                                            Cc, h * w, _stream()), "gauss_rate_bwd")
     return dx, dparams
+
+
+def factorized_rate_bwd(x, eb, noise, gbits):
+    P, B, Cc, h, w = x.shape
+    dx = torch.empty_like(x)
+    deb = torch.zeros_like(eb)
+    check(_lib.load().lldwt_factorized_rate_bwd(_chk(x), _chk(eb), _opt(noise), _chk(gbits), _chk(dx), _chk(deb), P, B, Cc,
+                                                h * w, _stream()), "factorized_rate_bwd")
+    return dx, deb
 
 
 def axpby(a, b, alpha, beta=0.0):

@@ -264,6 +264,11 @@ int lldwt_cgp_rate(const float* cat, const float* x, const float* noise, const f
 int lldwt_factorized_rate(const float* x, const float* eb, const float* noise, float* bits, float* qout,
                           double* bit_sum, int64_t planes, int64_t batch, int C, int64_t hw, void* stream);
 
+/* Backward of lldwt_factorized_rate (training, v = x + noise): dx (Z,C,hw) and deb (planes,C,59) += gradient wrt the RAW
+ * packed parameters (softplus' / tanh' applied; median slot stays 0).  deb is accumulated with atomics: zero it first. */
+int lldwt_factorized_rate_bwd(const float* x, const float* eb, const float* noise, const float* gbits, float* dx,
+                              float* deb, int64_t planes, int64_t batch, int C, int64_t hw, void* stream);
+
 /* sum((a-b)^2) and sum(x) into a double (graphs/losses/rate_dist.py:36-41). */
 int lldwt_sq_err_sum(const float* a, const float* b, int64_t n, double* out, void* stream);
 int lldwt_sum(const float* x, int64_t n, double* out, void* stream);
@@ -278,6 +283,13 @@ int lldwt_cdf97_forward(const float* x, float* ll, float* const* yh, int64_t Z, 
                         void* ws, int64_t ws_bytes, void* stream);
 int lldwt_cdf97_inverse(const float* ll, const float* const* yh, float* x, int64_t Z, int64_t H, int64_t W,
                         int levels, void* ws, int64_t ws_bytes, void* stream);
+/* Adjoints for training (bior4.4 is not orthogonal, so the backward pass is NOT the other transform):
+ * lldwt_cdf97_inverse_ex(adj=1) maps (g_ll, g_yh) -> g_x   = adjoint of lldwt_cdf97_forward (backward of the analysis);
+ * lldwt_cdf97_forward_ex(adj=1) maps g_x -> (g_ll, g_yh)   = adjoint of lldwt_cdf97_inverse (backward of the synthesis). */
+int lldwt_cdf97_forward_ex(const float* x, float* ll, float* const* yh, int64_t Z, int64_t H, int64_t W, int levels,
+                           int adj, void* ws, int64_t ws_bytes, void* stream);
+int lldwt_cdf97_inverse_ex(const float* ll, const float* const* yh, float* x, int64_t Z, int64_t H, int64_t W,
+                           int levels, int adj, void* ws, int64_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }
