@@ -75,6 +75,8 @@ def train_leg(a, dev, rank, world, x):
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
     from oracle import weights as oweights
     cfg = make_config(dwtlevels=a.levels, mode="train", batch_size=a.batch, patch_size=a.size, seed=1337)
+    if x.shape[2] != x.shape[3] and x.numel() > 3 * 1024 * 1024 * 8:
+        return {"skipped": "training leg is sized for the square BASELINE crops"}
     agent = LiftingBasedDWTAgent(cfg)
     agent.model.load_state_dict(oweights.fill_by_name(oweights.wrapper_template(dict(cfg))), strict=False)
     agent.model.train()
@@ -90,7 +92,8 @@ def train_leg(a, dev, rank, world, x):
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     log("train leg done: %.3f s for %d steps" % (dt, a.train_steps))
-    return {"ms_per_step": dt / a.train_steps * 1e3, "Mpixels/s": a.batch * a.size * a.size * world * a.train_steps / dt / 1e6,
+    return {"ms_per_step": dt / a.train_steps * 1e3,
+            "Mpixels/s": x.shape[0] * x.shape[2] * x.shape[3] * world * a.train_steps / dt / 1e6,
             "steps": a.train_steps, "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
             "what": "forward (noise) + hand-written backward + flat-bucket gradient all-reduce (mean over ranks) + Adam, "
                     "same workload, batch sharded over ranks"}
@@ -110,12 +113,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--height", type=int, default=0, help="non-square input (e.g. 2160 x 3840 for BASELINE configs[4]); default: --size")
+    ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=2,
                     help="extra (not part of `value`): time this many full training steps (fwd + hand-written bwd + "
                          "gradient all-reduce + Adam) on the same workload; 0 disables")
     a = ap.parse_args()
+    H_, W_ = (a.height or a.size), (a.width or a.size)
 
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
     rank, world, local = parallel.env_rank()
@@ -129,7 +135,7 @@ def main():
     net, sd, cfg = build_model(a.levels, dev)
     log("model ready")
     nets = net.nets()
-    x = torch.rand(a.batch, 3, a.size, a.size, device=dev, generator=torch.Generator(device=dev).manual_seed(parallel.rank_seed(1337, rank)))
+    x = torch.rand(a.batch, 3, H_, W_, device=dev, generator=torch.Generator(device=dev).manual_seed(parallel.rank_seed(1337, rank)))
     bit_acc = torch.zeros(1, dtype=torch.float64, device=dev)
 
     # HIP events around the dominant kernel (plc second conv, 243 -> 243 3x3, LiftingBasedDWT_net.py:271-272): the
@@ -188,14 +194,14 @@ def main():
     dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom["events"])
     n_launch = max(len(dom["events"]), 1)
     achieved = dom["flops"] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    pixels = a.batch * a.size * a.size * world * a.steps
+    pixels = a.batch * H_ * W_ * world * a.steps
     out = {
         "metric": "Mpixels/sec (lifting DWT + entropy-model fwd) at 512x512 RGB",
         "value": pixels / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: learned %d-level lifting (k=5,16ch) + SubbandAutoEncoder + "
-                               "conditioned2ZTsepSubbands, %dx3x%dx%d per GPU, eval" % (a.levels, a.batch, a.size, a.size),
+                               "conditioned2ZTsepSubbands, %dx3x%dx%d per GPU, eval" % (a.levels, a.batch, H_, W_),
                    "per_gpu_batch": a.batch, "sharding": "batch over ranks, no data-path collective"},
         "roofline": {"bound": "mfma", "kernel": "plc conv 243->243 3x3 (tree context, 61% of the step's FLOPs)",
                      "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -77,6 +77,9 @@ SIGNATURES = {
     "lldwt_downsum2": (_i, [_p, _p, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_direct": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
     "lldwt_gdn": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i64, _i, _f, _p]),
+    "lldwt_ew_mul": (_i, [_p, _p, _p, _i64, _f, _p]),
+    "lldwt_gdn_apply": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "lldwt_gdn_apply_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _p]),
     "lldwt_lower_bound_fwd": (_i, [_p, _p, _i64, _f, _p]),
     "lldwt_lower_bound_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
     "lldwt_nonneg_param_fwd": (_i, [_p, _p, _i64, _f, _p]),

@@ -105,6 +105,58 @@ class Cdf97InvFn(torch.autograd.Function):
         return (g_ll, *g_yh)
 
 
+class SquareFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.ew_mul(x, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.ew_mul(x, g.contiguous(), 2.0)
+
+
+class GdnApplyFn(torch.autograd.Function):
+    """y = x * rsqrt(nrm)  (inverse: x * sqrt(nrm)) -- graphs/layers/gdn.py:85-90."""
+
+    @staticmethod
+    def forward(ctx, x, nrm, inverse):
+        ctx.save_for_backward(x, nrm)
+        ctx.inverse = inverse
+        return ops.gdn_apply(x, nrm, inverse)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, nrm = ctx.saved_tensors
+        dx, dn = ops.gdn_apply_bwd(x, nrm, g.contiguous(), ctx.inverse)
+        return dx, dn, None
+
+
+class NonNegParamFn(torch.autograd.Function):
+    """NonNegativeParametrizer: max(x, bound)^2 - pedestal with the LowerBound gradient rule (utils/parametrizers.py:45-48)."""
+
+    @staticmethod
+    def forward(ctx, x, minimum):
+        ctx.save_for_backward(x)
+        ctx.minimum = minimum
+        return ops.nonneg_param_fwd(x.contiguous(), minimum)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.nonneg_param_bwd(x.contiguous(), g.contiguous(), ctx.minimum), None
+
+
+def gdn_train(x, beta, gamma, inverse, beta_min):
+    """Differentiable GDN on plane-major tensors: x (P,B,C,h,w), beta (P,C), gamma (P,C,C)."""
+    P, C_ = beta.shape
+    b = NonNegParamFn.apply(beta, beta_min)
+    g = NonNegParamFn.apply(gamma, 0.0).reshape(P, C_, C_, 1, 1)
+    nrm = conv(SquareFn.apply(x), g, b, 1)
+    return GdnApplyFn.apply(x, nrm, inverse)
+
+
 class QuantNoiseFn(torch.autograd.Function):
     """quantize(x, 'noise') = x + U(-.5,.5): identity gradient."""
 

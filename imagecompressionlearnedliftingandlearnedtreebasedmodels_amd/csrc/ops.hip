@@ -743,3 +743,51 @@ extern "C" int lldwt_factorized_rate_bwd(const float* x, const float* eb, const 
                        (int)batch, C, hw);
     return check_launch("factorized_rate_bwd");
 }
+
+// ---- small elementwise pieces used by the differentiable (training) composition of GDN -------------------------------------
+// out = scale * a * b
+__global__ void k_ew_mul(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n, float scale) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = scale * a[i] * b[i];
+}
+// y = x * rsqrt(nrm)  (inverse: x * sqrt(nrm))   -- graphs/layers/gdn.py:85-90
+__global__ void k_gdn_apply(const float* __restrict__ x, const float* __restrict__ nrm, float* __restrict__ y, int64_t n, int inverse) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float r = inverse ? sqrtf(nrm[i]) : 1.0f / sqrtf(nrm[i]);
+        y[i] = x[i] * r;
+    }
+}
+__global__ void k_gdn_apply_bwd(const float* __restrict__ x, const float* __restrict__ nrm, const float* __restrict__ g,
+                                float* __restrict__ dx, float* __restrict__ dn, int64_t n, int inverse) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float nv = nrm[i], xv = x[i], gv = g[i];
+        if (inverse) {
+            const float r = sqrtf(nv);
+            dx[i] = gv * r;
+            dn[i] = gv * xv * 0.5f / r;
+        } else {
+            const float r = 1.0f / sqrtf(nv);
+            dx[i] = gv * r;
+            dn[i] = -0.5f * gv * xv * r * r * r;
+        }
+    }
+}
+extern "C" int lldwt_ew_mul(const float* a, const float* b, float* out, int64_t n, float scale, void* stream) {
+    LLDWT_REQUIRE(a && b && out && n >= 0, "ew_mul: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_ew_mul, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, scale);
+    return check_launch("ew_mul");
+}
+extern "C" int lldwt_gdn_apply(const float* x, const float* nrm, float* y, int64_t n, int inverse, void* stream) {
+    LLDWT_REQUIRE(x && nrm && y && n >= 0, "gdn_apply: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_gdn_apply, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, nrm, y, n, inverse);
+    return check_launch("gdn_apply");
+}
+extern "C" int lldwt_gdn_apply_bwd(const float* x, const float* nrm, const float* g, float* dx, float* dn, int64_t n,
+                                   int inverse, void* stream) {
+    LLDWT_REQUIRE(x && nrm && g && dx && dn && n >= 0, "gdn_apply_bwd: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_gdn_apply_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, nrm, g, dx, dn, n, inverse);
+    return check_launch("gdn_apply_bwd");
+}

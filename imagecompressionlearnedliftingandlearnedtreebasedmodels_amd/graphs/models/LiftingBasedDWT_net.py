@@ -340,13 +340,24 @@ def _tconv_transpose1x1(mods, x, act):
     return ag.conv(x, w.contiguous(), _tstack(mods, lambda m: m.bias), 1, groups=G, act=act)
 
 
+def _tconv_transpose3x3(mods, x):
+    """Dense 3x3 ConvTranspose2d (stride 1, padding 1) as the equivalent conv: swap in/out, flip the taps."""
+    w = _tstack(mods, lambda m: m.weight.transpose(0, 1).flip(-1, -2))
+    return ag.conv(x, w.contiguous(), _tstack(mods, lambda m: m.bias), 3)
+
+
 def _ae_train(aes, x, decode):
     from ..layers.lifting_dwt_nets import SubbandAutoEncoder
-    if not isinstance(aes[0], SubbandAutoEncoder):
-        raise NotImplementedError("training on the HIP path is built for SubbandAutoEncoder (the GDN backward of "
-                                  "SubbandAutoEncoderBerk is not written yet)")
     seqs = [(a.ae_up if decode else a.ae_down) for a in aes]
     t = x
+    if not isinstance(aes[0], SubbandAutoEncoder):           # SubbandAutoEncoderBerk: 3x3 convs + GDN (:139-150)
+        for n in (0, 2, 4, 6):
+            layer = [s_[n] for s_ in seqs]
+            t = _tconv_transpose3x3(layer, t) if decode else _tconv(layer, t)
+            if n != 6:
+                g = [s_[n + 1] for s_ in seqs]
+                t = ag.gdn_train(t, _tstack(g, lambda m: m.beta), _tstack(g, lambda m: m.gamma), decode, g[0].beta_min)
+        return t
     for n in (0, 2, 4, 6):
         act = ops.ACT_NONE if n == 6 else ops.ACT_TANH
         layer = [s_[n] for s_ in seqs]

@@ -451,3 +451,22 @@ def lift_bwd_pre(g_dout, g_din, g, Z, h, w):
 def lift_bwd_fin(g, dsk, srcv, g_src, Z, batch, h, w, taps, dtaps, vertical, sign, rw):
     check(_lib.load().lldwt_lift_bwd_fin(_chk(g), _chk(dsk), _chk(srcv), g_src, Z, batch, h, w, _chk(taps), _chk(dtaps),
                                          int(vertical), float(sign), float(rw), _stream()), "lift_bwd_fin")
+
+
+def ew_mul(a, b, scale=1.0):
+    out = torch.empty_like(a)
+    check(_lib.load().lldwt_ew_mul(_chk(a), _chk(b), _chk(out), a.numel(), float(scale), _stream()), "ew_mul")
+    return out
+
+
+def gdn_apply(x, nrm, inverse):
+    y = torch.empty_like(x)
+    check(_lib.load().lldwt_gdn_apply(_chk(x), _chk(nrm), _chk(y), x.numel(), int(bool(inverse)), _stream()), "gdn_apply")
+    return y
+
+
+def gdn_apply_bwd(x, nrm, g, inverse):
+    dx, dn = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.load().lldwt_gdn_apply_bwd(_chk(x), _chk(nrm), _chk(g), _chk(dx), _chk(dn), x.numel(), int(bool(inverse)),
+                                          _stream()), "gdn_apply_bwd")
+    return dx, dn

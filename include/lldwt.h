@@ -219,6 +219,13 @@ int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* b
 int lldwt_gdn(const float* x, float* y, const float* beta, const float* gamma, int64_t planes, int64_t batch,
               int C, int64_t hw, int inverse, float beta_min, void* stream);
 
+/* Differentiable (training) composition of GDN: nrm = conv1x1(x*x, gamma', beta') on the conv engine, then
+ * y = x * rsqrt(nrm) (inverse: x * sqrt(nrm)); these are its elementwise pieces and their backward.           */
+int lldwt_ew_mul(const float* a, const float* b, float* out, int64_t n, float scale, void* stream);     /* out = scale*a*b */
+int lldwt_gdn_apply(const float* x, const float* nrm, float* y, int64_t n, int inverse, void* stream);
+int lldwt_gdn_apply_bwd(const float* x, const float* nrm, const float* g, float* dx, float* dn, int64_t n, int inverse,
+                        void* stream);
+
 /* LowerBound (utils/bound_ops.py:22-28) and NonNegativeParametrizer (utils/parametrizers.py:45-48), elementwise. */
 int lldwt_lower_bound_fwd(const float* x, float* y, int64_t n, float bound, void* stream);
 int lldwt_lower_bound_bwd(const float* x, const float* gy, float* gx, int64_t n, float bound, void* stream);
