@@ -23,9 +23,11 @@ struct WgradArgs {
     const float* x;
     const float* dy;
     float* dw;
+    float* db;         // bias gradient folded in as one extra (ic,tap) column whose B operand is the constant 1, or null
     lldwt_conv_desc d;
     int batch, h, w, ntaps, zsplit;
-    int n_total;       // cin_g * ntaps
+    int n_total;       // cin_g * ntaps (+1 when db != null: the bias column)
+    int n_w;           // cin_g * ntaps
     float alpha;
     int8_t tdy[25], tdx[25];
     int8_t tap_of[25];
@@ -53,11 +55,11 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
     const int n0 = nb * NT * 16, oc0 = mb * MT * 16;
     // input channels touched by this n-block: ic_first .. ic_last
     const int ic_first = n0 / a.ntaps;
-    const int n_end = min(n0 + NT * 16, a.n_total);
-    const int ic_last = (n_end - 1) / a.ntaps;
+    const int n_end = min(n0 + NT * 16, a.n_w);
+    const int ic_last = n_end > n0 ? (n_end - 1) / a.ntaps : ic_first;
     const int nic = ic_last - ic_first + 1;
     float* la = lds;                               // [MT*16][WG_PSA]
-    float* lx = lds + MT * 16 * WG_PSA;            // [nic][PSX]
+    float* lx = lds + MT * 16 * WG_PSA + 1;        // [nic][PSX]; lx[-1] holds the constant 1 of the bias column
     const int h = a.h, w = a.w;
     const int hi = d.upsample2 ? h >> 1 : h, wi = d.upsample2 ? w >> 1 : w;
     const int64_t hw = (int64_t)h * w, hwi = (int64_t)hi * wi;
@@ -66,15 +68,17 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
 
     // per-lane B bases for this wave's n tiles
     int bbase[WNT];
-    bool nvalid[WNT];
+    bool isb[WNT];
 #pragma unroll
     for (int j = 0; j < WNT; ++j) {
         const int n = n0 + (wave * WNT + j) * 16 + col;
-        nvalid[j] = n < a.n_total;
-        const int icl = nvalid[j] ? n / a.ntaps : ic_first;
-        const int tl = nvalid[j] ? n - icl * a.ntaps : 0;
-        bbase[j] = (icl - ic_first) * PSX + a.tdy[tl] * IW + a.tdx[tl];
+        const bool nv = n < a.n_w;
+        isb[j] = a.db != nullptr && n == a.n_w;
+        const int icl = nv ? n / a.ntaps : ic_first;
+        const int tl = nv ? n - icl * a.ntaps : 0;
+        bbase[j] = isb[j] ? -1 : (icl - ic_first) * PSX + a.tdy[tl] * IW + a.tdx[tl];
     }
+    if (tid == 0) lx[-1] = 1.0f;
     floatx4 acc[MT][WNT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
                 const int ly = rem / IW, lxx = rem - ly * IW;
                 const int gy = y0 - R + ly, gx = x0 - R + lxx;
                 float v = 0.f;
-                if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+                if (gy >= 0 && gy < h && gx >= 0 && gx < w && ic_first + c < cin_g) {
                     const int icg = g * cin_g + ic_first + c;
                     const int icm = (icg / icb) * ics + ico + icg % icb;
                     const int sy = d.upsample2 ? gy >> 1 : gy, sx = d.upsample2 ? gx >> 1 : gx;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) A[m] = la[(m * 16 + col) * WG_PSA + p + kk];
 #pragma unroll
-                for (int j = 0; j < WNT; ++j) B[j] = lx[bbase[j] + poff];
+                for (int j = 0; j < WNT; ++j) B[j] = lx[bbase[j] + (isb[j] ? 0 : poff)];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -144,7 +148,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
     for (int j = 0; j < WNT; ++j) {
         const int n = n0 + (wave * WNT + j) * 16 + col;
         if (n >= a.n_total) continue;
-        const int icl = n / a.ntaps, tl = n - icl * a.ntaps;
+        const bool bias_col = n == a.n_w;
+        const int icl = bias_col ? 0 : n / a.ntaps, tl = bias_col ? 0 : n - icl * a.ntaps;
         const int tap = a.tap_of[tl];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -153,7 +158,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
                 const int ocl = oc0 + m * 16 + 4 * kk + r;
                 if (ocl < cout_g) {
                     const int oc = g * cout_g + ocl;
-                    atomicAdd(dwp + ((int64_t)oc * cin_g + icl) * KK + tap, a.alpha * acc[m][j][r]);
+                    if (bias_col) atomicAdd(a.db + (int64_t)plane * d.cout + oc, a.alpha * acc[m][j][r]);
+                    else atomicAdd(dwp + ((int64_t)oc * cin_g + icl) * KK + tap, a.alpha * acc[m][j][r]);
                 }
             }
     }
@@ -206,7 +212,7 @@ static int launch_wgrad(const WgradArgs& a, int planes, hipStream_t st) {
     // distinct input channels per n-block: ceil(NT*16 / ntaps) + 1
     const int cin_g_ = d.cin / d.groups;
     const int nic_max = min((NT * 16 + a.ntaps - 1) / a.ntaps + 1, cin_g_);
-    const size_t shmem = sizeof(float) * ((size_t)MT * 16 * WG_PSA + (size_t)nic_max * PSX);
+    const size_t shmem = sizeof(float) * ((size_t)MT * 16 * WG_PSA + 1 + (size_t)nic_max * PSX);
     auto kern = k_conv_wgrad<KS, MT, NT>;
     if (shmem > 160 * 1024) {
         set_error("conv2d_wgrad: tile needs %zu bytes of LDS", shmem);
@@ -247,7 +253,7 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
     LLDWT_REQUIRE(d->oc_block > 0 && d->ytot >= d->cout, "conv2d_wgrad: bad output placement");
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a;
-    a.x = x; a.dy = dy; a.dw = dw; a.d = *d;
+    a.x = x; a.dy = dy; a.dw = dw; a.db = dbias; a.d = *d;
     a.batch = (int)batch; a.h = (int)h; a.w = (int)w_; a.alpha = alpha;
     const int KK = d->K * d->K, P = d->K / 2;
     int nt = 0;
@@ -262,7 +268,8 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
     LLDWT_REQUIRE(nt > 0, "conv2d_wgrad: empty tap mask");
     a.ntaps = nt;
     const int cin_g = d->cin / d->groups, cout_g = d->cout / d->groups;
-    a.n_total = cin_g * nt;
+    a.n_w = cin_g * nt;
+    a.n_total = a.n_w + (dbias ? 1 : 0);
     // split K (images x 8x16 chunks) so that the grid fills the chip several times over: ~2048 workgroups
     {
         const bool narrow_ = cout_g <= 16;
@@ -270,8 +277,8 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
         const int64_t out_tiles = cdiv(a.n_total, nt_ * 16) * cdiv(cout_g, mt_ * 16) * d->groups * planes;
         const int64_t chunks = batch * cdiv(h, WG_TH) * cdiv(w_, WG_TW);
         int64_t sp = cdiv(2048, out_tiles);
+        if (sp > chunks / 4) sp = chunks / 4;      // every slice accumulates >= 4 chunks before its atomics
         if (sp < 1) sp = 1;
-        if (sp > chunks) sp = chunks;
         if (sp > 65535) sp = 65535;
         a.zsplit = (int)sp;
     }
@@ -283,13 +290,7 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
     else if (d->K == 3) { LLDWT_WG(3) }
     else { LLDWT_WG(5) }
 #undef LLDWT_WG
-    if (r) return r;
-    if (dbias) {
-        dim3 grid((unsigned)d->cout, (unsigned)batch, (unsigned)planes);
-        hipLaunchKernelGGL(k_bias_grad, grid, dim3(256), 0, st, dy, dbias, *d, (int)batch, h * w_, alpha);
-        return check_launch("bias_grad");
-    }
-    return 0;
+    return r;
 }
 
 extern "C" int lldwt_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, void* stream) {
