@@ -30,11 +30,10 @@ def build_model(levels, device):
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import \
         LiftingBasedDWTNetWrapper
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
-    from oracle import weights as oweights   # deterministic by-name weight filler only (no oracle compute here)
     cfg = make_config(dwtlevels=levels, mode="validate")
-    sd = oweights.fill_by_name(oweights.wrapper_template(dict(cfg)))
+    torch.manual_seed(1337)                       # random-init weights of the architecture (PyTorch default initialisers)
     net = LiftingBasedDWTNetWrapper(cfg)
-    net.load_state_dict(sd, strict=False)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}    # host copy, handed to the cpu_baseline leg only
     return net.to(device).eval(), sd, cfg
 
 
@@ -73,12 +72,11 @@ def train_leg(a, dev, rank, world, x):
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.agents.liftingDWT_agent import LiftingBasedDWTAgent
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
-    from oracle import weights as oweights
     cfg = make_config(dwtlevels=a.levels, mode="train", batch_size=a.batch, patch_size=a.size, seed=1337)
     if x.shape[2] != x.shape[3] and x.numel() > 3 * 1024 * 1024 * 8:
         return {"skipped": "training leg is sized for the square BASELINE crops"}
-    agent = LiftingBasedDWTAgent(cfg)
-    agent.model.load_state_dict(oweights.fill_by_name(oweights.wrapper_template(dict(cfg))), strict=False)
+    torch.manual_seed(1337)
+    agent = LiftingBasedDWTAgent(cfg)                     # random-init weights (same on every rank: replicated model)
     agent.model.train()
     torch.manual_seed(parallel.rank_seed(1337, rank))
     torch.cuda.empty_cache()

@@ -25,8 +25,15 @@ class BaseAgent:
         self.cuda = True
         self.manual_seed = config.seed
         self.lr = config.learning_rate
-        torch.manual_seed(self.manual_seed + int(os.environ.get("RANK", 0)))   # per-rank noise streams
-        torch.cuda.manual_seed(self.manual_seed + int(os.environ.get("RANK", 0)))
+        # the replicated model must be initialised identically on every rank: seed with the config seed here; the agent
+        # switches to a per-rank stream for the quantisation noise after the model is built (seed_noise_stream)
+        torch.manual_seed(self.manual_seed)
+        torch.cuda.manual_seed(self.manual_seed)
+
+    def seed_noise_stream(self):
+        rank = int(os.environ.get("RANK", 0))
+        torch.manual_seed(self.manual_seed + 7919 * rank)
+        torch.cuda.manual_seed(self.manual_seed + 7919 * rank)
 
     # the four hooks of agents/base.py:30-61
     def train_one_epoch(self):

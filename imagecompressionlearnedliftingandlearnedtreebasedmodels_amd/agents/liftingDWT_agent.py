@@ -49,6 +49,7 @@ class LiftingBasedDWTAgent(BaseAgent):
         self.clrch = config.clrch
         self.lr = config.learning_rate
         self.model = LiftingBasedDWTNetWrapper(config).to(self.device)
+        self.seed_noise_stream()
         self.optimizer = configure_optimizers(self.model, self.lr)
         self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, factor=0.5, patience=5, threshold=0.0001,
                                                               threshold_mode="rel", cooldown=0, min_lr=1e-06, eps=1e-08)
