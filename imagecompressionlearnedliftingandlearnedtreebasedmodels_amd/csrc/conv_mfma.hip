@@ -214,6 +214,8 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     const float* abase = lw + (wm * WM) * 64 + lane;                    // + ((tl*S+s)*OCT + m)*64
 
     LLDWT_STAGE_LOAD(0)
+    // (a half-chunk start stagger between co-resident workgroups, keyed on the hardware wave slot, measured 0 +- 0.3 %
+    //  on the 243->243 layer -- the workgroups do not run in lockstep -- and is not kept)
     for (int chunk = 0; chunk < a.p.nchunk; ++chunk) {
         __syncthreads();          // all waves are done reading the previous chunk
         LLDWT_STAGE_STORE()
