@@ -74,6 +74,161 @@ __global__ __launch_bounds__(256) void k_sfb(V3 lo, V3 hi, V3 out, int h, int w,
         }
 }
 
+// ---- fused per-level kernels (adj == 0): both passes of one level through LDS, one read and one write of the data ------
+// forward: a workgroup produces a CT x CT tile of each of the 4 subbands from a (2CT+8)^2 input patch (periodic wrap)
+constexpr int CT = 32;                     // subband tile edge
+constexpr int CIN = 2 * CT + 8;            // input patch edge (72)
+
+__global__ __launch_bounds__(256) void k_cdf97_fwd_level(V3 in, V3 ll, V3 lh, V3 hl, V3 vhh, int h, int w) {
+    __shared__ float sin[CIN][CIN + 1];
+    __shared__ float sL[CIN][CT + 1], sH[CIN][CT + 1];
+    const int64_t z = blockIdx.z;
+    const int ky0 = blockIdx.y * CT, kx0 = blockIdx.x * CT;
+    const int tid = threadIdx.x;
+    // input patch rows (2*ky0 - 4 + ly) mod h, cols (2*kx0 - 4 + lx) mod w
+    // periodic wrap by conditional add/sub (an integer modulo per element made this phase instruction-bound); the
+    // modulo is only needed when the image is smaller than the patch (deep levels, negligible work)
+    const bool small = h < CIN || w < CIN;
+    const float* inz = in.p + z * in.sz;
+    // all loads of a thread are issued before the first LDS store (a load -> store loop waits vmcnt(0) per element and
+    // serialises the HBM latency: measured 68 % of the wave cycles parked)
+    constexpr int NLD = (CIN * CIN + 255) / 256;
+    float v[NLD];
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+        const int i = tid + r * 256;
+        const int ly = i / CIN, lx = i - ly * CIN;
+        int gy = 2 * ky0 - 4 + ly, gx = 2 * kx0 - 4 + lx;
+        if (small) {
+            gy %= h; gx %= w;
+            if (gy < 0) gy += h;
+            if (gx < 0) gx += w;
+        } else {
+            gy += gy < 0 ? h : (gy >= h ? -h : 0);
+            gx += gx < 0 ? w : (gx >= w ? -w : 0);
+        }
+        v[r] = i < CIN * CIN ? inz[gy * (int)in.sy + gx * (int)in.sx] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+        const int i = tid + r * 256;
+        if (i < CIN * CIN) sin[i / CIN][i % CIN] = v[r];
+    }
+    __syncthreads();
+    // width pass: lo/hi[ly][c] = sum_m dec[m] * sin[ly][2c + 9 - m]
+    for (int i = tid; i < CIN * CT; i += 256) {
+        const int ly = i / CT, c = i - ly * CT;
+        float a = 0.f, d = 0.f;
+#pragma unroll
+        for (int m = 0; m < 10; ++m) {
+            const float v = sin[ly][2 * c + 9 - m];
+            a = fmaf(c_dec_lo[m], v, a);
+            d = fmaf(c_dec_hi[m], v, d);
+        }
+        sL[ly][c] = a;
+        sH[ly][c] = d;
+    }
+    __syncthreads();
+    // height pass on both halves
+    const int hh = h / 2, wh = w / 2;
+    for (int i = tid; i < CT * CT; i += 256) {
+        const int r = i / CT, c = i - r * CT;
+        const int ky = ky0 + r, kx = kx0 + c;
+        if (ky >= hh || kx >= wh) continue;
+        float a0 = 0.f, d0 = 0.f, a1 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 10; ++m) {
+            const float vl = sL[2 * r + 9 - m][c], vh = sH[2 * r + 9 - m][c];
+            a0 = fmaf(c_dec_lo[m], vl, a0);
+            d0 = fmaf(c_dec_hi[m], vl, d0);
+            a1 = fmaf(c_dec_lo[m], vh, a1);
+            d1 = fmaf(c_dec_hi[m], vh, d1);
+        }
+        const int o = ky * (int)ll.sy + kx;                                   // the four outputs share row/col strides
+        ll.p[z * ll.sz + o] = a0;     // low width, low height
+        lh.p[z * lh.sz + o] = d0;     // low width, high height
+        hl.p[z * hl.sz + o] = a1;
+        vhh.p[z * vhh.sz + o] = d1;
+    }
+}
+
+// inverse: a workgroup reconstructs a (2CT)^2 output tile from (CT+4)^2 patches of the 4 subbands
+constexpr int CS = CT + 4;
+__global__ __launch_bounds__(256) void k_cdf97_inv_level(V3 ll, V3 lh, V3 hl, V3 vhh, V3 out, int h, int w) {
+    __shared__ float s4[4][CS][CS + 1];
+    __shared__ float sLw[2 * CT][CS + 1], sHw[2 * CT][CS + 1];
+    const int64_t z = blockIdx.z;
+    const int y0 = blockIdx.y * 2 * CT, x0 = blockIdx.x * 2 * CT;
+    const int hh = h / 2, wh = w / 2;
+    const int tid = threadIdx.x;
+    V3 sb[4] = {ll, lh, hl, vhh};
+    const bool small = hh < CS || wh < CS;
+    constexpr int NLD = (CS * CS + 255) / 256;
+    float v[4][NLD];
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+        const int i = tid + r * 256;
+        const int lk = i / CS, lc = i - lk * CS;
+        int gy = y0 / 2 - 2 + lk, gx = x0 / 2 - 2 + lc;
+        if (small) {
+            gy %= hh; gx %= wh;
+            if (gy < 0) gy += hh;
+            if (gx < 0) gx += wh;
+        } else {
+            gy += gy < 0 ? hh : (gy >= hh ? -hh : 0);
+            gx += gx < 0 ? wh : (gx >= wh ? -wh : 0);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            v[b][r] = i < CS * CS ? sb[b].p[z * sb[b].sz + gy * (int)sb[b].sy + gx * (int)sb[b].sx] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+        const int i = tid + r * 256;
+        if (i < CS * CS) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s4[b][i / CS][i % CS] = v[b][r];
+        }
+    }
+    __syncthreads();
+    // height synthesis: lw[dn][lc] from (LL, LH), hw[dn][lc] from (HL, HH).  Only the 5 taps t = 2u + (dn & 1) contribute,
+    // at rows (dn + 8 - t)/2 = (dn >> 1) + 4 - u: branch-free, the parity only selects the filter taps.
+    for (int i = tid; i < 2 * CT * CS; i += 256) {
+        const int dn = i / CS, lc = i - dn * CS;
+        const int par = dn & 1, base = (dn >> 1) + 4;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const float rl = par ? c_rec_lo[2 * u + 1] : c_rec_lo[2 * u];
+            const float rh = par ? c_rec_hi[2 * u + 1] : c_rec_hi[2 * u];
+            const int lk = base - u;
+            a = fmaf(s4[0][lk][lc], rl, a);
+            a = fmaf(s4[1][lk][lc], rh, a);
+            b = fmaf(s4[2][lk][lc], rl, b);
+            b = fmaf(s4[3][lk][lc], rh, b);
+        }
+        sLw[dn][lc] = a;
+        sHw[dn][lc] = b;
+    }
+    __syncthreads();
+    float* oz = out.p + z * out.sz;
+    for (int i = tid; i < 4 * CT * CT; i += 256) {
+        const int dn = i / (2 * CT), dm = i - dn * (2 * CT);
+        const int gy = y0 + dn, gx = x0 + dm;
+        if (gy >= h || gx >= w) continue;
+        const int par = dm & 1, base = (dm >> 1) + 4;
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const float rl = par ? c_rec_lo[2 * u + 1] : c_rec_lo[2 * u];
+            const float rh = par ? c_rec_hi[2 * u + 1] : c_rec_hi[2 * u];
+            acc = fmaf(sLw[dn][base - u], rl, acc);
+            acc = fmaf(sHw[dn][base - u], rh, acc);
+        }
+        oz[gy * (int)out.sy + gx * (int)out.sx] = acc;
+    }
+}
+
 static inline dim3 grid2d(int64_t h, int64_t w, int64_t Z) {
     return dim3((unsigned)cdiv(w, 256), (unsigned)(h < 2048 ? h : 2048), (unsigned)Z);
 }
@@ -117,12 +272,17 @@ extern "C" int lldwt_cdf97_forward_ex(const float* x, float* ll, float* const* y
         const int64_t h = H >> lev, w = W >> lev, hh = h / 2, wh = w / 2, sub = hh * wh;
         V3 in{const_cast<float*>(cur), h * w, w, 1};
         V3 lw{low, h * wh, wh, 1}, hw_{hiw, h * wh, wh, 1};
-        hipLaunchKernelGGL(k_afb, grid2d(h, wh, Z), dim3(256), 0, st, in, lw, hw_, (int)h, (int)w, 1, adj);
         float* llout = lev == levels - 1 ? ll : llb[lev & 1];
         float* y = yh[lev];
         V3 vLL{llout, sub, wh, 1}, vLH{y, 3 * sub, wh, 1}, vHL{y + sub, 3 * sub, wh, 1}, vHH{y + 2 * sub, 3 * sub, wh, 1};
-        hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, lw, vLL, vLH, (int)h, (int)wh, 0, adj);
-        hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, hw_, vHL, vHH, (int)h, (int)wh, 0, adj);
+        if (!adj) {       // fused level: one read of the input, one write of the four subbands
+            dim3 grid((unsigned)cdiv(wh, CT), (unsigned)cdiv(hh, CT), (unsigned)Z);
+            hipLaunchKernelGGL(k_cdf97_fwd_level, grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
+        } else {
+            hipLaunchKernelGGL(k_afb, grid2d(h, wh, Z), dim3(256), 0, st, in, lw, hw_, (int)h, (int)w, 1, adj);
+            hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, lw, vLL, vLH, (int)h, (int)wh, 0, adj);
+            hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, hw_, vHL, vHH, (int)h, (int)wh, 0, adj);
+        }
         cur = llout;
     }
     return check_launch("cdf97_forward");
@@ -149,11 +309,16 @@ extern "C" int lldwt_cdf97_inverse_ex(const float* ll, const float* const* yh, f
         V3 vLL{const_cast<float*>(cur), sub, wh, 1}, vLH{y, 3 * sub, wh, 1}, vHL{y + sub, 3 * sub, wh, 1},
             vHH{y + 2 * sub, 3 * sub, wh, 1};
         V3 lw{low, h * wh, wh, 1}, hw_{hiw, h * wh, wh, 1};
-        hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vLL, vLH, lw, (int)h, (int)wh, 0, adj);
-        hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vHL, vHH, hw_, (int)h, (int)wh, 0, adj);
         float* out = lev == 0 ? x : llb[lev & 1];
         V3 vo{out, h * w, w, 1};
-        hipLaunchKernelGGL(k_sfb, grid2d(h, w, Z), dim3(256), 0, st, lw, hw_, vo, (int)h, (int)w, 1, adj);
+        if (!adj) {
+            dim3 grid((unsigned)cdiv(w, 2 * CT), (unsigned)cdiv(h, 2 * CT), (unsigned)Z);
+            hipLaunchKernelGGL(k_cdf97_inv_level, grid, dim3(256), 0, st, vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
+        } else {
+            hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vLL, vLH, lw, (int)h, (int)wh, 0, adj);
+            hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vHL, vHH, hw_, (int)h, (int)wh, 0, adj);
+            hipLaunchKernelGGL(k_sfb, grid2d(h, w, Z), dim3(256), 0, st, lw, hw_, vo, (int)h, (int)w, 1, adj);
+        }
         cur = out;
     }
     return check_launch("cdf97_inverse");

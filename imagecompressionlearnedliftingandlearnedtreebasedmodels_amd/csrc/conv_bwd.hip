@@ -96,32 +96,56 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
             const float* xz = a.x + z * xtot * hwi;
             const int y0 = (t / tiles_x) * WG_TH, x0 = (t % tiles_x) * WG_TW;
             __syncthreads();
-            // stage dY: MT*16 channels x 128 px (zero outside the image / beyond cout_g)
-            for (int i = tid; i < MT * 16 * WG_PX; i += 256) {
-                const int c = i / WG_PX, p = i - c * WG_PX;
-                const int gy = y0 + p / WG_TW, gx = x0 + p % WG_TW;
-                const int ocl = oc0 + c;
-                float v = 0.f;
-                if (ocl < cout_g && gy < h && gx < w) {
-                    const int oc = g * cout_g + ocl;
-                    const int ocp = (oc / d.oc_block) * d.oc_stride + d.oc_off + oc % d.oc_block;
-                    v = dyz[ocp * hw + (int64_t)gy * w + gx];
+            // stage dY: MT*16 channels x 128 px (zero outside the image / beyond cout_g).  Loads are issued in batches of
+            // 8 before the LDS stores: a plain load -> store loop waits vmcnt(0) per element and serialises the latency.
+            constexpr int NA = MT * 16 * WG_PX / 256;
+#pragma unroll
+            for (int r0 = 0; r0 < NA; r0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int i = tid + (r0 + r) * 256;
+                    const int c = i / WG_PX, p = i - c * WG_PX;
+                    const int gy = y0 + p / WG_TW, gx = x0 + p % WG_TW;
+                    const int ocl = oc0 + c;
+                    v[r] = 0.f;
+                    if (ocl < cout_g && gy < h && gx < w) {
+                        const int oc = g * cout_g + ocl;
+                        const int ocp = (oc / d.oc_block) * d.oc_stride + d.oc_off + oc % d.oc_block;
+                        v[r] = dyz[ocp * hw + (int64_t)gy * w + gx];
+                    }
                 }
-                la[c * WG_PSA + p] = v;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int i = tid + (r0 + r) * 256;
+                    la[(i / WG_PX) * WG_PSA + (i % WG_PX)] = v[r];
+                }
             }
             // stage X patch: nic channels x IH x IW
-            for (int i = tid; i < nic * IH * IW; i += 256) {
-                const int c = i / (IH * IW), rem = i - c * (IH * IW);
-                const int ly = rem / IW, lxx = rem - ly * IW;
-                const int gy = y0 - R + ly, gx = x0 - R + lxx;
-                float v = 0.f;
-                if (gy >= 0 && gy < h && gx >= 0 && gx < w && ic_first + c < cin_g) {
-                    const int icg = g * cin_g + ic_first + c;
-                    const int icm = (icg / icb) * ics + ico + icg % icb;
-                    const int sy = d.upsample2 ? gy >> 1 : gy, sx = d.upsample2 ? gx >> 1 : gx;
-                    v = xz[icm * hwi + (int64_t)sy * wi + sx];
+            for (int i0 = 0; i0 < nic * IH * IW; i0 += 8 * 256) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int i = i0 + tid + r * 256;
+                    const int c = i / (IH * IW), rem = i - c * (IH * IW);
+                    const int ly = rem / IW, lxx = rem - ly * IW;
+                    const int gy = y0 - R + ly, gx = x0 - R + lxx;
+                    v[r] = 0.f;
+                    if (i < nic * IH * IW && gy >= 0 && gy < h && gx >= 0 && gx < w && ic_first + c < cin_g) {
+                        const int icg = g * cin_g + ic_first + c;
+                        const int icm = (icg / icb) * ics + ico + icg % icb;
+                        const int sy = d.upsample2 ? gy >> 1 : gy, sx = d.upsample2 ? gx >> 1 : gx;
+                        v[r] = xz[icm * hwi + (int64_t)sy * wi + sx];
+                    }
                 }
-                lx[c * PSX + ly * IW + lxx] = v;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int i = i0 + tid + r * 256;
+                    if (i < nic * IH * IW) {
+                        const int c = i / (IH * IW), rem = i - c * (IH * IW);
+                        lx[c * PSX + rem] = v[r];
+                    }
+                }
             }
             __syncthreads();
 #pragma unroll 4
