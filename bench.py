@@ -92,7 +92,7 @@ def train_leg(a, dev, rank, world, x):
     log("train leg done: %.3f s for %d steps" % (dt, a.train_steps))
     return {"ms_per_step": dt / a.train_steps * 1e3,
             "Mpixels/s": x.shape[0] * x.shape[2] * x.shape[3] * world * a.train_steps / dt / 1e6,
-            "steps": a.train_steps, "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "steps": a.train_steps, "loss": float(loss.detach()), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
             "what": "forward (noise) + hand-written backward + flat-bucket gradient all-reduce (mean over ranks) + Adam, "
                     "same workload, batch sharded over ranks"}
 

@@ -27,6 +27,14 @@ inline int check_launch(const char* what) {
         }                                 \
     } while (0)
 
+// compute units of the current device (256 on MI355X); 256 if the query fails
+static inline int lldwt_num_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        return 256;
+    return n;
+}
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
 

@@ -28,10 +28,14 @@ struct WgradArgs {
     int batch, h, w, ntaps, zsplit;
     int n_total;       // cin_g * ntaps (+1 when db != null: the bias column)
     int n_w;           // cin_g * ntaps
+    int nic_max;       // most input channels any n-block touches (sizes the X patch in LDS)
     float alpha;
     int8_t tdy[25], tdx[25];
     int8_t tap_of[25];
 };
+
+// 4-byte aligned float4: global_load_dwordx4 without the 16-byte alignment promise (rows start at any pixel)
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 
 template <int KS, int MT, int NT>
 __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
@@ -40,6 +44,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
     constexpr int R = KS / 2;
     constexpr int IH = WG_TH + 2 * R, IW = WG_TW + 2 * R;
     constexpr int PSX = IH * IW + 1;
+    constexpr int NV = MT * 16 * WG_PX / 4 / 256;   // dY float4s per thread and chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const lldwt_conv_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,13 +64,34 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
     const int ic_last = n_end > n0 ? (n_end - 1) / a.ntaps : ic_first;
     const int nic = ic_last - ic_first + 1;
     float* la = lds;                               // [MT*16][WG_PSA]
-    float* lx = lds + MT * 16 * WG_PSA + 1;        // [nic][PSX]; lx[-1] holds the constant 1 of the bias column
+    float* lx = lds + MT * 16 * WG_PSA + 2;        // [nic][PSX]; lx[-1] holds the constant 1 of the bias column
+    int* s_xoff = (int*)(lx + a.nic_max * PSX);    // [nic_max] memory channel of X channel c, or -1
+    int* s_aoff = s_xoff + a.nic_max;              // [MT*16]   memory channel of dY row c, or -1
     const int h = a.h, w = a.w;
     const int hi = d.upsample2 ? h >> 1 : h, wi = d.upsample2 ? w >> 1 : w;
     const int64_t hw = (int64_t)h * w, hwi = (int64_t)hi * wi;
     const int xtot = d.ic_block > 0 ? d.xtot : d.cin;
     const int icb = d.ic_block > 0 ? d.ic_block : d.cin, ics = d.ic_block > 0 ? d.ic_stride : 0, ico = d.ic_block > 0 ? d.ic_off : 0;
+    const int ups = d.upsample2;
 
+    // channel placement tables (the runtime divisions happen once per workgroup, not once per loaded element)
+    if (tid < MT * 16) {
+        const int ocl = oc0 + tid;
+        int v = -1;
+        if (ocl < cout_g) {
+            const int oc = g * cout_g + ocl;
+            v = (oc / d.oc_block) * d.oc_stride + d.oc_off + oc % d.oc_block;
+        }
+        s_aoff[tid] = v;
+    }
+    for (int c = tid; c < a.nic_max; c += 256) {
+        int v = -1;
+        if (c < nic && ic_first + c < cin_g) {
+            const int icg = g * cin_g + ic_first + c;
+            v = (icg / icb) * ics + ico + icg % icb;
+        }
+        s_xoff[c] = v;
+    }
     // per-lane B bases for this wave's n tiles
     int bbase[WNT];
     bool isb[WNT];
@@ -84,87 +110,119 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < WNT; ++j) acc[m][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
 
     // K (= images x spatial chunks) is split over blockIdx.y: slice s takes chunks s, s + zsplit, ...
     const int tiles_x = (w + WG_TW - 1) / WG_TW, tiles_y = (h + WG_TH - 1) / WG_TH;
     const int ntile = tiles_x * tiles_y;
-    {
-        for (int q = blockIdx.y; q < a.batch * ntile; q += a.zsplit) {
-            const int b = q / ntile, t = q - b * ntile;
-            const int64_t z = (int64_t)plane * a.batch + b;
-            const float* dyz = a.dy + z * d.ytot * hw;
-            const float* xz = a.x + z * xtot * hwi;
-            const int y0 = (t / tiles_x) * WG_TH, x0 = (t % tiles_x) * WG_TW;
-            __syncthreads();
-            // stage dY: MT*16 channels x 128 px (zero outside the image / beyond cout_g).  Loads are issued in batches of
-            // 8 before the LDS stores: a plain load -> store loop waits vmcnt(0) per element and serialises the latency.
-            constexpr int NA = MT * 16 * WG_PX / 256;
+    const int total = a.batch * ntile;
+    const int nxe = nic * IH * IW;                 // X elements per chunk
+    const bool xvec = KS == 1 && !ups;             // 1x1: the X patch is 8 rows of 16 contiguous pixels, like dY
+
+    // one row segment of 4 pixels: a single dwordx4 load when it lies inside the image (safe address + select, no
+    // branch per element); the ragged right edge (w % 4 != 0) takes the per-pixel path
+#define LLDWT_WG_LOAD4(dst_, base_, choff_, cstride_, wrow_, iv_)                                                \
+    {                                                                                                            \
+        const int c_ = (iv_) / (WG_PX / 4), rq_ = (iv_) % (WG_PX / 4);                                           \
+        const int gy_ = y0 + rq_ / (WG_TW / 4), gx_ = x0 + 4 * (rq_ % (WG_TW / 4));                              \
+        const int co_ = choff_[c_];                                                                              \
+        const bool row_ = co_ >= 0 && gy_ < h;                                                                   \
+        const bool ok4_ = row_ && gx_ + 3 < w;                                                                   \
+        const int64_t off_ = co_ * (cstride_) + (int64_t)gy_ * (wrow_) + gx_;                                    \
+        const f4u t4_ = *reinterpret_cast<const f4u*>(base_ + (ok4_ ? off_ : 0));                                \
+        dst_ = ok4_ ? floatx4{t4_.x, t4_.y, t4_.z, t4_.w} : floatx4{0.f, 0.f, 0.f, 0.f};                         \
+        if (row_ && !ok4_ && gx_ < w) {                                                                          \
+            _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_)                                                     \
+                if (gx_ + e_ < w) dst_[e_] = base_[off_ + e_];                                                   \
+        }                                                                                                        \
+    }
+#define LLDWT_WG_STORE4(arr_, stride_, src_, iv_)                                                                \
+    {                                                                                                            \
+        const int c_ = (iv_) / (WG_PX / 4), rq_ = (iv_) % (WG_PX / 4);                                           \
+        float2* q_ = reinterpret_cast<float2*>(arr_ + c_ * (stride_) + 4 * rq_);                                 \
+        q_[0] = float2{src_[0], src_[1]};                                                                        \
+        q_[1] = float2{src_[2], src_[3]};                                                                        \
+    }
+#define LLDWT_WG_LOAD_X(dst_, i_)                                                                                \
+    {                                                                                                            \
+        const int c_ = (i_) / (IH * IW), rem_ = (i_) - c_ * (IH * IW);                                           \
+        const int ly_ = rem_ / IW, lx_ = rem_ - ly_ * IW;                                                        \
+        const int gy_ = y0 - R + ly_, gx_ = x0 - R + lx_;                                                        \
+        const int xo_ = (i_) < nxe ? s_xoff[c_] : -1;                                                            \
+        const int sy_ = ups ? gy_ >> 1 : gy_, sx_ = ups ? gx_ >> 1 : gx_;                                        \
+        const bool ok_ = xo_ >= 0 && gy_ >= 0 && gy_ < h && gx_ >= 0 && gx_ < w;                                 \
+        const float t_v = xz[ok_ ? xo_ * hwi + (int64_t)sy_ * wi + sx_ : 0];                                     \
+        dst_ = ok_ ? t_v : 0.f;                                                                                  \
+    }
+#define LLDWT_WG_STORE_X(src_, i_)                                                                               \
+    if ((i_) < nxe) {                                                                                            \
+        const int c_ = (i_) / (IH * IW), rem_ = (i_) - c_ * (IH * IW);                                           \
+        lx[c_ * PSX + rem_] = src_;                                                                              \
+    }
+
+    for (int q = blockIdx.y; q < total; q += a.zsplit) {
+        const int b_ = q / ntile, t_ = q - b_ * ntile;
+        const int64_t z_ = (int64_t)plane * a.batch + b_;
+        const float* dyz = a.dy + z_ * d.ytot * hw;
+        const float* xz = a.x + z_ * xtot * hwi;
+        const int y0 = (t_ / tiles_x) * WG_TH, x0 = (t_ % tiles_x) * WG_TW;
+        __syncthreads();
+        // stage dY: MT*16 channels x 128 px (zero outside the image / beyond cout_g); all loads of a thread are issued
+        // before its first LDS store (a load -> store loop waits vmcnt(0) per element and serialises the latency)
+        {
+            floatx4 v4[NV];
 #pragma unroll
-            for (int r0 = 0; r0 < NA; r0 += 8) {
-                float v[8];
+            for (int r = 0; r < NV; ++r) LLDWT_WG_LOAD4(v4[r], dyz, s_aoff, hw, w, tid + r * 256)
+#pragma unroll
+            for (int r = 0; r < NV; ++r) LLDWT_WG_STORE4(la, WG_PSA, v4[r], tid + r * 256)
+        }
+        if (xvec) {
+            // 1x1: nic channels x 128 px, rows of 16 contiguous pixels (PSX = 129: scalar LDS stores)
+            for (int i0 = 0; i0 < nic * (WG_PX / 4); i0 += 8 * 256) {
+                floatx4 v4[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const int i = tid + (r0 + r) * 256;
-                    const int c = i / WG_PX, p = i - c * WG_PX;
-                    const int gy = y0 + p / WG_TW, gx = x0 + p % WG_TW;
-                    const int ocl = oc0 + c;
-                    v[r] = 0.f;
-                    if (ocl < cout_g && gy < h && gx < w) {
-                        const int oc = g * cout_g + ocl;
-                        const int ocp = (oc / d.oc_block) * d.oc_stride + d.oc_off + oc % d.oc_block;
-                        v[r] = dyz[ocp * hw + (int64_t)gy * w + gx];
-                    }
+                    const int iv = i0 + tid + r * 256;
+                    if (iv < nic * (WG_PX / 4)) LLDWT_WG_LOAD4(v4[r], xz, s_xoff, hwi, wi, iv)
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const int i = tid + (r0 + r) * 256;
-                    la[(i / WG_PX) * WG_PSA + (i % WG_PX)] = v[r];
+                    const int iv = i0 + tid + r * 256;
+                    if (iv < nic * (WG_PX / 4)) {
+                        float* q_ = lx + (iv / (WG_PX / 4)) * PSX + 4 * (iv % (WG_PX / 4));
+                        q_[0] = v4[r][0]; q_[1] = v4[r][1]; q_[2] = v4[r][2]; q_[3] = v4[r][3];
+                    }
                 }
             }
-            // stage X patch: nic channels x IH x IW
-            for (int i0 = 0; i0 < nic * IH * IW; i0 += 8 * 256) {
+        } else {
+            // X patch: nic channels x IH x IW with the halo, 8 loads in flight per thread
+            for (int i0 = 0; i0 < nxe; i0 += 8 * 256) {
                 float v[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int i = i0 + tid + r * 256;
-                    const int c = i / (IH * IW), rem = i - c * (IH * IW);
-                    const int ly = rem / IW, lxx = rem - ly * IW;
-                    const int gy = y0 - R + ly, gx = x0 - R + lxx;
-                    v[r] = 0.f;
-                    if (i < nic * IH * IW && gy >= 0 && gy < h && gx >= 0 && gx < w && ic_first + c < cin_g) {
-                        const int icg = g * cin_g + ic_first + c;
-                        const int icm = (icg / icb) * ics + ico + icg % icb;
-                        const int sy = d.upsample2 ? gy >> 1 : gy, sx = d.upsample2 ? gx >> 1 : gx;
-                        v[r] = xz[icm * hwi + (int64_t)sy * wi + sx];
-                    }
-                }
+                for (int r = 0; r < 8; ++r) LLDWT_WG_LOAD_X(v[r], i0 + tid + r * 256)
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int i = i0 + tid + r * 256;
-                    if (i < nic * IH * IW) {
-                        const int c = i / (IH * IW), rem = i - c * (IH * IW);
-                        lx[c * PSX + rem] = v[r];
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll 4
-            for (int s = 0; s < WG_PX / 4; ++s) {
-                const int p = 4 * s;                       // 4 consecutive pixels of one row
-                const int poff = (p / WG_TW) * IW + (p % WG_TW) + kk;
-                float A[MT], B[WNT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) A[m] = la[(m * 16 + col) * WG_PSA + p + kk];
-#pragma unroll
-                for (int j = 0; j < WNT; ++j) B[j] = lx[bbase[j] + (isb[j] ? 0 : poff)];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int j = 0; j < WNT; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m], B[j], acc[m][j], 0, 0, 0);
+                for (int r = 0; r < 8; ++r) LLDWT_WG_STORE_X(v[r], i0 + tid + r * 256)
             }
         }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < WG_PX / 4; ++s) {
+            const int p = 4 * s;                       // 4 consecutive pixels of one row
+            const int poff = (p / WG_TW) * IW + (p % WG_TW) + kk;
+            float A[MT], B[WNT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) A[m] = la[(m * 16 + col) * WG_PSA + p + kk];
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) B[j] = lx[bbase[j] + (isb[j] ? 0 : poff)];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m], B[j], acc[m][j], 0, 0, 0);
+        }
     }
+#undef LLDWT_WG_LOAD_X
+#undef LLDWT_WG_STORE_X
     // epilogue: D[row = oc (4*kk + r)][col = n]
     const int KK = KS * KS;
     float* dwp = a.dw + (int64_t)plane * d.cout * cin_g * KK;
@@ -186,6 +244,251 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
                     else atomicAdd(dwp + ((int64_t)oc * cin_g + icl) * KK + tap, a.alpha * acc[m][j][r]);
                 }
             }
+    }
+}
+
+// ---- lifting P-block shapes (graphs/layers/P_block_v2.py:15-33: 1 -> 16 -> 16 -> 16 -> 1, all taps live, no placement) ----
+// With cout = 16 the generic tile wastes most of its work: N = 400 columns are padded to 512, and the 1 <-> 16 convs fill
+// 26 of 256 columns (conv1) or 1 of 16 rows (conv4).  Two dedicated kernels:
+//   k_wgrad16<K>    16 -> 16: one 16x16 tile per tap (n = ic, no padding); K waves, wave dy owns the K taps of kernel row dy
+//   k_wgrad_thin<K> 1 <-> 16: D[m][tap] = sum_p A16[m][p] * B1[p +- tap]; conv1: A16 = dY, B1 = X; conv4: A16 = X, B1 = dY
+//                   with the tap offsets mirrored (X[q] dY[q - t] summed over q)
+// Both prefetch the next 8x16 pixel chunk into registers while the matrix cores work on the current one.
+struct W16Args {
+    const float* x;
+    const float* dy;
+    float* dw;
+    float* db;
+    int batch, h, w;
+    float alpha;
+    int8_t tap_of[25];
+};
+
+template <int K>
+__global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
+    constexpr int NTH = K * 64, KK = K * K, R = K / 2;
+    constexpr int IH = WG_TH + 2 * R, IW = WG_TW + 2 * R, IHW = IH * IW, PSX = IHW + 1;
+    constexpr int NA = (16 * WG_PX + NTH - 1) / NTH, NX = (16 * IHW + NTH - 1) / NTH;
+    constexpr int NSM = 16 * WG_PSA + 16 * PSX > 256 * KK ? 16 * WG_PSA + 16 * PSX : 256 * KK;
+    __shared__ float smem[NSM];
+    float* la = smem;                 // [16][WG_PSA]
+    float* lx = smem + 16 * WG_PSA;   // [16][PSX]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    const int plane = blockIdx.z;
+    const int h = a.h, w = a.w;
+    const int64_t hw = (int64_t)h * w;
+    const int tiles_x = (w + WG_TW - 1) / WG_TW, tiles_y = (h + WG_TH - 1) / WG_TH;
+    const int ntile = tiles_x * tiles_y, total = a.batch * ntile;
+    floatx4 acc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int bb = col * PSX + wave * IW + kk;
+    float va[NA], vx[NX];
+
+#define LLDWT_W16_LOAD(q_)                                                                                       \
+    {                                                                                                            \
+        const int b_ = (q_) / ntile, t_ = (q_) - b_ * ntile;                                                     \
+        const int64_t z_ = (int64_t)plane * a.batch + b_;                                                        \
+        const float* dyz = a.dy + z_ * 16 * hw;                                                                  \
+        const float* xz = a.x + z_ * 16 * hw;                                                                    \
+        const int y0 = (t_ / tiles_x) * WG_TH, x0 = (t_ % tiles_x) * WG_TW;                                      \
+        _Pragma("unroll") for (int r = 0; r < NA; ++r) {                                                         \
+            const int i = tid + r * NTH;                                                                         \
+            const int c = i / WG_PX, p = i % WG_PX;                                                              \
+            const int gy = y0 + p / WG_TW, gx = x0 + p % WG_TW;                                                  \
+            const bool ok = i < 16 * WG_PX && gy < h && gx < w;                                                  \
+            const float tv = dyz[ok ? c * hw + (int64_t)gy * w + gx : 0];                                        \
+            va[r] = ok ? tv : 0.f;                                                                               \
+        }                                                                                                        \
+        _Pragma("unroll") for (int r = 0; r < NX; ++r) {                                                         \
+            const int i = tid + r * NTH;                                                                         \
+            const int c = i / IHW, rem = i - c * IHW;                                                            \
+            const int gy = y0 - R + rem / IW, gx = x0 - R + rem % IW;                                            \
+            const bool ok = i < 16 * IHW && gy >= 0 && gy < h && gx >= 0 && gx < w;                              \
+            const float tv = xz[ok ? c * hw + (int64_t)gy * w + gx : 0];                                         \
+            vx[r] = ok ? tv : 0.f;                                                                               \
+        }                                                                                                        \
+    }
+
+    int q = blockIdx.x;
+    if (q < total) LLDWT_W16_LOAD(q)
+    for (; q < total; q += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            const int i = tid + r * NTH;
+            if (i < 16 * WG_PX) la[(i / WG_PX) * WG_PSA + (i % WG_PX)] = va[r];
+        }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            const int i = tid + r * NTH;
+            if (i < 16 * IHW) lx[(i / IHW) * PSX + (i % IHW)] = vx[r];
+        }
+        __syncthreads();
+        const int qn = q + gridDim.x;
+        if (qn < total) LLDWT_W16_LOAD(qn)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 4
+        for (int s = 0; s < WG_PX / 4; ++s) {
+            const int p = 4 * s;
+            const int poff = (p / WG_TW) * IW + (p % WG_TW);
+            const float A = la[col * WG_PSA + p + kk];
+            bsum += A;
+            float B[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) B[j] = lx[bb + poff + j];
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B[j], acc[j], 0, 0, 0);
+        }
+    }
+#undef LLDWT_W16_LOAD
+    // D_tap[row = oc (4*kk + r)][col = ic] -> LDS in dW order, then one coalesced atomic per element: every workgroup of
+    // a plane adds to the same 256*KK addresses, and the L2 serialises atomics per cache line -- scattered lanes
+    // (stride KK floats) touched 64 lines per instruction and cost more than the GEMM itself.
+    float* dwp = a.dw + (int64_t)plane * 16 * 16 * KK;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int tap = a.tap_of[wave * K + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) smem[((4 * kk + r) * 16 + col) * KK + tap] = acc[j][r];
+    }
+    __syncthreads();
+    for (int i = tid; i < 256 * KK; i += NTH) atomicAdd(dwp + i, a.alpha * smem[i]);
+    if (a.db && wave == 0) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (kk == 0) atomicAdd(a.db + plane * 16 + col, a.alpha * bsum);
+    }
+}
+
+struct WThinArgs {
+    const float* a16;   // 16-channel operand (dY of conv1 / X of conv4)
+    const float* b1;    // 1-channel operand  (X of conv1 / dY of conv4)
+    float* dw;
+    float* db;
+    int batch, h, w;
+    float alpha;
+    int flip;           // conv4: mirrored tap offsets
+    int bias_mode;      // 0 none, 1 db[m] = sum A16[m] (conv1), 2 db[0] = sum B1 (conv4)
+    int8_t tap_of[25];
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
+    constexpr int KK = K * K, R = K / 2, NJ = (KK + 15) / 16;
+    constexpr int IH = WG_TH + 2 * R, IW = WG_TW + 2 * R, IHW = IH * IW;
+    constexpr int NA = 16 * WG_PX / 256, NB = (IHW + 255) / 256;
+    __shared__ float la[16 * WG_PSA];      // reused by the epilogue: [4 waves][16*KK] partial tiles
+    __shared__ float lb[IHW + 8];
+    static_assert(4 * 16 * KK <= 16 * WG_PSA, "epilogue scratch");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    const int plane = blockIdx.z;
+    const int h = a.h, w = a.w;
+    const int64_t hw = (int64_t)h * w;
+    const int tiles_x = (w + WG_TW - 1) / WG_TW, tiles_y = (h + WG_TH - 1) / WG_TH;
+    const int ntile = tiles_x * tiles_y, total = a.batch * ntile;
+    floatx4 acc[NJ];
+    int boff[NJ];
+    bool bval[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const int n = j * 16 + col;
+        bval[j] = n < KK;
+        int tdy = bval[j] ? n / K : 0, tdx = bval[j] ? n % K : 0;
+        if (a.flip) { tdy = K - 1 - tdy; tdx = K - 1 - tdx; }
+        boff[j] = tdy * IW + tdx + kk;
+    }
+    float bsum = 0.f, bsb = 0.f;
+    float va[NA], vb[NB];
+
+#define LLDWT_WT_LOAD(q_)                                                                                        \
+    {                                                                                                            \
+        const int b_ = (q_) / ntile, t_ = (q_) - b_ * ntile;                                                     \
+        const int64_t z_ = (int64_t)plane * a.batch + b_;                                                        \
+        const float* az = a.a16 + z_ * 16 * hw;                                                                  \
+        const float* bz = a.b1 + z_ * hw;                                                                        \
+        const int y0 = (t_ / tiles_x) * WG_TH, x0 = (t_ % tiles_x) * WG_TW;                                      \
+        _Pragma("unroll") for (int r = 0; r < NA; ++r) {                                                         \
+            const int i = tid + r * 256;                                                                         \
+            const int c = i / WG_PX, p = i % WG_PX;                                                              \
+            const int gy = y0 + p / WG_TW, gx = x0 + p % WG_TW;                                                  \
+            const bool ok = gy < h && gx < w;                                                                    \
+            const float tv = az[ok ? c * hw + (int64_t)gy * w + gx : 0];                                         \
+            va[r] = ok ? tv : 0.f;                                                                               \
+        }                                                                                                        \
+        _Pragma("unroll") for (int r = 0; r < NB; ++r) {                                                         \
+            const int i = tid + r * 256;                                                                         \
+            const int gy = y0 - R + i / IW, gx = x0 - R + i % IW;                                                \
+            const bool ok = i < IHW && gy >= 0 && gy < h && gx >= 0 && gx < w;                                   \
+            const float tv = bz[ok ? (int64_t)gy * w + gx : 0];                                                  \
+            vb[r] = ok ? tv : 0.f;                                                                               \
+        }                                                                                                        \
+    }
+
+    int q = blockIdx.x;
+    if (q < total) LLDWT_WT_LOAD(q)
+    for (; q < total; q += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            const int i = tid + r * 256;
+            la[(i / WG_PX) * WG_PSA + (i % WG_PX)] = va[r];
+        }
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            const int i = tid + r * 256;
+            if (i < IHW) {
+                lb[i] = vb[r];
+                const int ly = i / IW, lxx = i % IW;
+                if (ly >= R && ly < R + WG_TH && lxx >= R && lxx < R + WG_TW) bsb += vb[r];
+            }
+        }
+        __syncthreads();
+        const int qn = q + gridDim.x;
+        if (qn < total) LLDWT_WT_LOAD(qn)
+        __builtin_amdgcn_sched_barrier(0);
+        // the 4 waves split the chunk's 32 k-steps
+#pragma unroll
+        for (int s8 = 0; s8 < WG_PX / 16; ++s8) {
+            const int p = 4 * (wave * (WG_PX / 16) + s8);
+            const int poff = (p / WG_TW) * IW + (p % WG_TW);
+            const float A = la[col * WG_PSA + p + kk];
+            bsum += A;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float B = bval[j] ? lb[boff[j] + poff] : 0.f;
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, acc[j], 0, 0, 0);
+            }
+        }
+    }
+#undef LLDWT_WT_LOAD
+    // the 4 waves hold partial tiles over disjoint pixels: sum them in LDS, then one coalesced atomic per element
+    float* dwp = a.dw + (int64_t)plane * 16 * KK;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = j * 16 + col;
+        if (n < KK) {
+            const int tap = a.tap_of[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) la[wave * 16 * KK + (4 * kk + r) * KK + tap] = acc[j][r];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * KK; i += 256)
+        atomicAdd(dwp + i, a.alpha * ((la[i] + la[16 * KK + i]) + (la[2 * 16 * KK + i] + la[3 * 16 * KK + i])));
+    if (a.bias_mode == 1) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (kk == 0) atomicAdd(a.db + plane * 16 + col, a.alpha * bsum);
+    } else if (a.bias_mode == 2) {
+        bsb = wave_sum(bsb);
+        if (lane == 0) atomicAdd(a.db + plane, a.alpha * bsb);
     }
 }
 
@@ -226,27 +529,47 @@ __global__ void k_downsum2(const float* __restrict__ g, float* __restrict__ out,
 }
 
 template <int KS, int MT, int NT>
-static int launch_wgrad(const WgradArgs& a, int planes, hipStream_t st) {
+static int launch_wgrad(WgradArgs& a, int planes, int64_t chunks, hipStream_t st) {
     const lldwt_conv_desc& d = a.d;
     const int cout_g = d.cout / d.groups;
     const int n_tiles = (a.n_total + NT * 16 - 1) / (NT * 16);
     const int m_tiles = (cout_g + MT * 16 - 1) / (MT * 16);
     constexpr int R = KS / 2;
-    constexpr int PSX = (WG_TH + 2 * R) * (WG_TW + 2 * R) + 1;
+    constexpr int IHW = (WG_TH + 2 * R) * (WG_TW + 2 * R), PSX = IHW + 1;
     // distinct input channels per n-block: ceil(NT*16 / ntaps) + 1
     const int cin_g_ = d.cin / d.groups;
-    const int nic_max = min((NT * 16 + a.ntaps - 1) / a.ntaps + 1, cin_g_);
-    const size_t shmem = sizeof(float) * ((size_t)MT * 16 * WG_PSA + 1 + (size_t)nic_max * PSX);
-    auto kern = k_conv_wgrad<KS, MT, NT>;
+    a.nic_max = min((NT * 16 + a.ntaps - 1) / a.ntaps + 1, cin_g_);
+    const size_t shmem = sizeof(float) * ((size_t)MT * 16 * WG_PSA + 2 + (size_t)a.nic_max * PSX + a.nic_max + MT * 16);
     if (shmem > 160 * 1024) {
         set_error("conv2d_wgrad: tile needs %zu bytes of LDS", shmem);
         return LLDWT_EINVAL;
     }
+    auto kern = k_conv_wgrad<KS, MT, NT>;
     if (shmem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
         set_error("conv2d_wgrad: cannot reserve %zu bytes of LDS", shmem);
         return LLDWT_EHIP;
     }
+    // split K (images x 8x16 chunks) over blockIdx.y: about 8 workgroups per CU-slot, and a count that fills whole
+    // rounds of the chip -- workgroups take equal time, so 2052 of them on 512 slots would run a fifth round for 4
+    const int64_t out_tiles = (int64_t)n_tiles * m_tiles * d.groups * planes;
+    int per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, shmem) != hipSuccess || per_cu < 1) per_cu = 2;
+    const int64_t slots = (int64_t)lldwt_num_cus() * per_cu;
+    int64_t hi = chunks / 4;                       // every slice accumulates >= 4 chunks before its atomics
+    if (hi < 1) hi = 1;
+    if (hi > 65535) hi = 65535;
+    int64_t sp0 = cdiv(4 * slots, out_tiles);
+    if (sp0 > hi) sp0 = hi;
+    if (sp0 < 1) sp0 = 1;
+    int64_t best = sp0;
+    double best_eff = 0.0;
+    for (int64_t sp = sp0; sp >= 1 && sp >= sp0 - sp0 / 3; --sp) {
+        const int64_t tot = out_tiles * sp;
+        const double eff = (double)tot / (double)(cdiv(tot, slots) * slots);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+    }
+    a.zsplit = (int)best;
     dim3 grid((unsigned)(n_tiles * m_tiles * d.groups), (unsigned)a.zsplit, (unsigned)planes);
     hipLaunchKernelGGL(kern, grid, dim3(256), shmem, st, a);
     return check_launch("conv2d_wgrad");
@@ -294,22 +617,48 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
     const int cin_g = d->cin / d->groups, cout_g = d->cout / d->groups;
     a.n_w = cin_g * nt;
     a.n_total = a.n_w + (dbias ? 1 : 0);
-    // split K (images x 8x16 chunks) so that the grid fills the chip several times over: ~2048 workgroups
+    // lifting P-block shapes: dedicated kernels (see k_wgrad16 / k_wgrad_thin)
     {
-        const bool narrow_ = cout_g <= 16;
-        const int nt_ = narrow_ ? 16 : 4, mt_ = narrow_ ? 1 : 4;
-        const int64_t out_tiles = cdiv(a.n_total, nt_ * 16) * cdiv(cout_g, mt_ * 16) * d->groups * planes;
+        const bool plain = d->groups == 1 && !d->upsample2 && nt == KK && d->oc_block >= d->cout && d->oc_off == 0 &&
+                           d->ytot == d->cout && d->ic_block == 0 && (d->K == 3 || d->K == 5);
         const int64_t chunks = batch * cdiv(h, WG_TH) * cdiv(w_, WG_TW);
-        int64_t sp = cdiv(2048, out_tiles);
-        if (sp > chunks / 4) sp = chunks / 4;      // every slice accumulates >= 4 chunks before its atomics
-        if (sp < 1) sp = 1;
-        if (sp > 65535) sp = 65535;
-        a.zsplit = (int)sp;
+        int64_t slices = cdiv(1536, planes);
+        if (slices > chunks / 4) slices = chunks / 4;
+        if (slices < 1) slices = 1;
+        dim3 grid((unsigned)slices, 1, (unsigned)planes);
+        if (plain && d->cin == 16 && d->cout == 16) {
+            W16Args w;
+            w.x = x; w.dy = dy; w.dw = dw; w.db = dbias; w.batch = (int)batch; w.h = (int)h; w.w = (int)w_; w.alpha = alpha;
+            for (int t = 0; t < 25; ++t) w.tap_of[t] = t < KK ? a.tap_of[t] : 0;
+            if (d->K == 5) hipLaunchKernelGGL(k_wgrad16<5>, grid, dim3(320), 0, st, w);
+            else hipLaunchKernelGGL(k_wgrad16<3>, grid, dim3(192), 0, st, w);
+            return check_launch("conv2d_wgrad");
+        }
+        if (plain && ((d->cin == 1 && d->cout == 16) || (d->cin == 16 && d->cout == 1))) {
+            const bool c4 = d->cout == 1;
+            WThinArgs w;
+            w.a16 = c4 ? x : dy; w.b1 = c4 ? dy : x; w.dw = dw; w.db = dbias;
+            w.batch = (int)batch; w.h = (int)h; w.w = (int)w_; w.alpha = alpha; w.flip = c4 ? 1 : 0;
+            w.bias_mode = dbias ? (c4 ? 2 : 1) : 0;
+            for (int t = 0; t < 25; ++t) w.tap_of[t] = t < KK ? a.tap_of[t] : 0;
+            if (d->K == 5) hipLaunchKernelGGL(k_wgrad_thin<5>, grid, dim3(256), 0, st, w);
+            else hipLaunchKernelGGL(k_wgrad_thin<3>, grid, dim3(256), 0, st, w);
+            return check_launch("conv2d_wgrad");
+        }
     }
+    // tile shape: 16 x 256 for the lifting convs (cout/groups <= 16), otherwise 64 rows x 256 columns (3x3 / 5x5) or
+    // 64 x 128 (1x1, whose X patch is one LDS row per column).  Wide tiles matter: every n-block re-reads the dY chunk
+    // and every m-block the X patch, so the 64 x 64 tile of the first version was bound by L2 -> LDS traffic (measured
+    // 64 TFLOP/s on the 243 -> 243 tree conv).
+    const bool narrow = cout_g <= 16;
+    const int mt_ = narrow ? 1 : 4;
+    const int nt_ = narrow ? 16 : (a.n_total > 64 && d->K != 1 ? 16 : 4);
+    const int64_t chunks = batch * cdiv(h, WG_TH) * cdiv(w_, WG_TW);
     int r;
-    const bool narrow = cout_g <= 16;      // 16 x 256 tile for the lifting convs, 64 x 64 otherwise
 #define LLDWT_WG(KS_)                                                                                  \
-    r = narrow ? launch_wgrad<KS_, 1, 16>(a, (int)planes, st) : launch_wgrad<KS_, 4, 4>(a, (int)planes, st);
+    r = narrow ? launch_wgrad<KS_, 1, 16>(a, (int)planes, chunks, st)                                  \
+               : (nt_ == 4 ? launch_wgrad<KS_, 4, 4>(a, (int)planes, chunks, st)                       \
+                           : launch_wgrad<KS_, 4, 16>(a, (int)planes, chunks, st));
     if (d->K == 1) { LLDWT_WG(1) }
     else if (d->K == 3) { LLDWT_WG(3) }
     else { LLDWT_WG(5) }

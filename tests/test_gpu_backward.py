@@ -84,6 +84,32 @@ def test_conv_backward_residual_and_large():
     assert maxdiff(rd.grad[0].cpu(), rr.grad) < 1e-6
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (1, 16), (16, 1)])
+@pytest.mark.parametrize("K", [3, 5])
+@pytest.mark.parametrize("swap", [False, True])
+def test_wgrad_lifting_shapes(cin, cout, K, swap):
+    """The dedicated P-block weight-gradient kernels (16 -> 16 tap-tiled, 1 <-> 16 thin): ragged spatial size, several
+    K slices, alpha scaling, accumulation into a non-zero dW, and the (kh,kw)-swapped output of the row passes."""
+    ag, ops, gu = _mods()
+    g = torch.Generator().manual_seed(100 * cin + 10 * cout + K)
+    P, B, h, w = 2, 3, 29, 43
+    x = torch.rand(P, B, cin, h, w, generator=g) - 0.5
+    gy = torch.rand(P, B, cout, h, w, generator=g) - 0.5
+    dw0 = torch.rand(P, cout, cin, K, K, generator=g) - 0.5
+    db0 = torch.rand(P, cout, generator=g) - 0.5
+    alpha = -0.1
+    dw, db = gu.dev(dw0.clone()), gu.dev(db0.clone())
+    ops.conv2d_wgrad(gu.dev(x), gu.dev(gy), (P, cout, cin, K, K), K, dw=dw, db=db, alpha=alpha, swap_hw=swap)
+    for p in range(P):
+        wr = torch.zeros(cout, cin, K, K, requires_grad=True)
+        br = torch.zeros(cout, requires_grad=True)
+        F.conv2d(x[p], wr, br, padding=K // 2).backward(gy[p])
+        gw = wr.grad.transpose(2, 3) if swap else wr.grad
+        scale = max(1.0, float(gw.abs().max()))
+        assert maxdiff(dw[p].cpu(), dw0[p] + alpha * gw) < 2e-5 * scale, (cin, cout, K, swap)
+        assert maxdiff(db[p].cpu(), db0[p] + alpha * br.grad) < 2e-5 * max(1.0, float(br.grad.abs().max()))
+
+
 def _lift_stacks(sds, nblocks, gu):
     """oracle per-plane state dicts -> taps (4,P,3) and the 8 stacked tensors (nblocks,2,P,...) on the device."""
     taps = torch.stack([torch.stack([sd["preProcessingList.%d.weight" % j].reshape(3) for sd in sds], 0) for j in range(4)], 0)
