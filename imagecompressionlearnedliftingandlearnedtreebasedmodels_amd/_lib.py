@@ -66,6 +66,9 @@ SIGNATURES = {
                                          _p, _i64, _p, _p]),
     "lldwt_lift_bwd_pre": (_i, [View, View, _p, _i64, _i64, _i64, _p]),
     "lldwt_lift_bwd_fin": (_i, [_p, _p, _p, View, _i64, _i64, _i64, _i64, _p, _p, _i, _f, _f, _p]),
+    "lldwt_lift_step_bwd_ws_bytes": (_i64, [_i64, _i64, _i64, _i]),
+    "lldwt_lift_step_bwd": (_i, [View, View, View, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _i64] + [_p] * 8 +
+                            [_i, _i, _f, _f, _i, _i, _p, _i64, _p]),
     "lldwt_subband_mlp": (_i, [_p, _p, _i64, _i64, _i, _i64, _i] + [_p] * 8 + [_i, _p]),
     "lldwt_conv_packed_floats": (_i64, [C.POINTER(ConvDesc)]),
     "lldwt_conv_pack": (_i, [_p, _p, C.POINTER(ConvDesc), _i64, _p]),

@@ -6,6 +6,8 @@ HIP kernel behind the C-ABI (include/lldwt.h).  The reference gets its backward 
   * activations              = fused into the producing kernel's epilogue or lldwt_act_bwd
   * Gaussian rate            = closed-form d/dx, d/dsigma, d/dmu with both LowerBound gradient rules
 """
+import ctypes
+
 import torch
 
 from . import ops
@@ -234,6 +236,7 @@ class _LiftBackward:
         self.dtaps = torch.zeros_like(taps)
         self.dW = {k: torch.zeros_like(v) for k, v in W.items()}
         self.packs = {}
+        self.fwd_pack = _pack_forward(W, W["w1"].shape[0]) if meta["C"] == 16 else None     # (P,nblocks,2,total)
 
     def _pack(self, name, blk, u, vertical):
         key = (name, blk, u, vertical)
@@ -257,6 +260,18 @@ class _LiftBackward:
             t2 = base[(2 + C_) * n:(2 + 2 * C_) * n].view(self.P, B, C_, h, w)
             t3 = base[(2 + 2 * C_) * n:(2 + 3 * C_) * n].view(self.P, B, C_, h, w)
             view = lambda buf, off, sz, sy, sx: ops.View(G[buf].data_ptr() + 4 * off, sz, sy, sx)
+            if self.fwd_pack is not None:
+                # C == 16: the whole step backward is one C-ABI call (fused MFMA backward-data + dedicated wgrad kernels)
+                blk, u = op.block, op.is_u
+                nb_, tot = self.fwd_pack.shape[1], self.fwd_pack.shape[3]
+                pk = ctypes.c_void_p(self.fwd_pack.data_ptr() + 4 * (blk * 2 + u) * tot)
+                ops.lift_step_bwd(view(op.buf_dout, op.off_dout, op.sz_dout, op.sy_dout, op.sx_dout),
+                                  view(op.buf_din, op.off_din, op.sz_din, op.sy_din, op.sx_din),
+                                  view(op.buf_src, op.off_src, op.sz_src, op.sy_src, op.sx_src),
+                                  base, self.P, B, h, w, self.taps[op.tap], self.dtaps[op.tap], pk, nb_ * 2 * tot,
+                                  [self.dW[k][blk, u] for k in _W_KEYS], C_, K, rw, op.sign, bool(op.vertical),
+                                  m["linear"])
+                continue
             g = torch.empty(self.P, B, 1, h, w, device=srcv.device, dtype=torch.float32)
             ops.lift_bwd_pre(view(op.buf_dout, op.off_dout, op.sz_dout, op.sy_dout, op.sx_dout),
                              view(op.buf_din, op.off_din, op.sz_din, op.sy_din, op.sx_din), g, Z, h, w)

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lin = lds;                 // [CK][PS]
     float* lw = lds + G::IN_FLOATS;   // [ntaps][S][OCT][64]
+    int* s_icm = (int*)(lw + a.p.chunk_floats);   // [nchunk*CK] memory channel of input channel ic of this group, or -1
     const lldwt_conv_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WVN, wn = wave % WVN;
@@ -183,20 +184,31 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     }
     float xin[G::NIN];
     float4 wv[G::NWV];
+    // channel placement table: the runtime divisions happen once per workgroup instead of once per staged element
+    for (int ic = tid; ic < a.p.nchunk * CK; ic += G::NT) {
+        int v = -1;
+        if (ic < cin_g) {
+            const int icg = g * cin_g + ic;
+            v = (icg / icb) * ics + ico + icg % icb;
+        }
+        s_icm[ic] = v;
+    }
+    __syncthreads();
 
     // (macros, not lambdas: by-reference captures of the register arrays end up in scratch)
 #define LLDWT_STAGE_LOAD(CHUNK)                                                                             \
     {                                                                                                       \
         _Pragma("unroll") for (int r = 0; r < G::NIN; ++r) {                                                \
-            const int ic = (CHUNK) * CK + in_c[r];                                                          \
-            const int icg = g * cin_g + ic;                                                                 \
-            const int icm = (icg / icb) * ics + ico + icg % icb;                                            \
-            xin[r] = (in_off[r] >= 0 && ic < cin_g) ? xg[icm * hwi + in_off[r]] : 0.f;                      \
+            const int icm = s_icm[(CHUNK) * CK + in_c[r]];                                                  \
+            const bool ok = in_off[r] >= 0 && icm >= 0;     /* safe address + select: no branch per element */ \
+            const float xv = xg[ok ? icm * hwi + in_off[r] : 0];                                            \
+            xin[r] = ok ? xv : 0.f;                                                                         \
         }                                                                                                   \
         const float4* src = reinterpret_cast<const float4*>(pk + (int64_t)(CHUNK) * a.p.chunk_floats);     \
         _Pragma("unroll") for (int r = 0; r < G::NWV; ++r) {                                                \
             const int i = tid + r * G::NT;                                                                  \
-            wv[r] = (i < wvec) ? src[i] : float4{0.f, 0.f, 0.f, 0.f};                                       \
+            const float4 wq = src[i < wvec ? i : 0];                                                        \
+            wv[r] = (i < wvec) ? wq : float4{0.f, 0.f, 0.f, 0.f};                                           \
         }                                                                                                   \
     }
 #define LLDWT_STAGE_STORE()                                                                                 \
@@ -326,7 +338,7 @@ static int launch_cfg(const ConvArgs& a0, int64_t Z, hipStream_t st) {
     ConvArgs a = a0;
     a.tiles_x = (int)cdiv(a.w, G::TW);
     a.tiles_y = (int)cdiv(a.h, G::TH);
-    const size_t shmem = sizeof(float) * (G::IN_FLOATS + (size_t)a.p.chunk_floats);
+    const size_t shmem = sizeof(float) * (G::IN_FLOATS + (size_t)a.p.chunk_floats + (size_t)a.p.nchunk * CK);
     auto kern = k_conv_mfma<KS, WM, WN, WVM, WVN, TWS, CK, DENSE>;
     if (shmem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {

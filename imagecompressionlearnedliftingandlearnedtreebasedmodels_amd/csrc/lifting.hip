@@ -601,6 +601,215 @@ __global__ __launch_bounds__(256) void k_lift_bwd_fin(const float* __restrict__ 
 }
 
 
+// ---- backward-data of one P-block (C == 16) on the matrix cores ------------------------------------------------------
+// The reference gets this from autograd through P_block_v2.forward (P_block_v2.py:40-55).  With g = dL/dnet:
+//   dt3   = conv4^T(g)                         (1 -> 16, VALU)
+//   dpre2 = tanh'(t2) * conv3^T(dt3)           (16 -> 16, MFMA)         kernel bwd_c (also copies g, sets G[dst_in])
+//   dr    = tanh'(t1) * conv2^T(dpre2) + dt3   (16 -> 16, MFMA; "+ dt3" is the pre-activation residual)   kernel bwd_b
+//   dsk   = conv1^T(dr)                        (16 -> 1, VALU)          kernel bwd_a
+// conv^T = the same tile kernels with the weights read transposed and the taps mirrored from the FORWARD pack.
+template <int K>
+__device__ __forceinline__ void stage_w16T(float* __restrict__ wl, const float* __restrict__ Wp, int tid) {
+    // Wp: forward pack [ic][tap][oc]; wl[(tap'*4 + s)*64 + kk*16 + oc'] = W[oc = 4s+kk][ic = oc'][KK-1-tap']
+    constexpr int KK = K * K;
+    for (int i = tid; i < KK * 4 * 64; i += NT) {
+        const int l = i & 63, s = (i >> 6) & 3, tap = i >> 8;
+        const int oc = l & 15, kk = l >> 4;
+        wl[i] = Wp[(oc * KK + (KK - 1 - tap)) * 16 + 4 * s + kk];
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(NT) void k_lift_bwd_c_mfma(CView gout, lldwt_view gdin, float* __restrict__ g_out,
+                                                        const float* __restrict__ t2, float* __restrict__ dt3_out,
+                                                        float* __restrict__ dpre2_out, int batch, int h, int w,
+                                                        const float* __restrict__ packed, int64_t packed_plane_stride,
+                                                        int vertical, int linear) {
+    constexpr int C = 16, R = K / 2, R2 = 2 * R, KK = K * K;
+    constexpr int SH = TH + 2 * R2, SW = TW + 2 * R2;
+    constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;
+    constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_lds = lds;                                    // [SH][SW+1] gradient patch
+    float* t1 = s_lds + SH * (SW + 1);                     // [C] planes of dt3
+    float* wl = t1 + C * T1PS;                             // conv3^T weights [KK][4][64]
+    const PackOff o = pack_off(C, K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
+    const int64_t cs = (int64_t)h * w;
+    stage_w16T<K>(wl, pk + o.w3, tid);
+    for (int i = tid; i < SH * SW; i += NT) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int gy = y0 - R2 + ly, gx = x0 - R2 + lx;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const float t = gout.p[in ? z * gout.sz + (int64_t)gy * gout.sy + (int64_t)gx * gout.sx : 0];
+        const float v = in ? t : 0.f;
+        if (in && ly >= R2 && ly < R2 + TH && lx >= R2 && lx < R2 + TW) {
+            g_out[z * cs + (int64_t)gy * w + gx] = v;
+            gdin.p[z * gdin.sz + (int64_t)gy * gdin.sy + (int64_t)gx * gdin.sx] = v;   // the step passes dst through
+        }
+        s_lds[ly * (SW + 1) + lx] = v;
+    }
+    __syncthreads();
+    // dt3 = conv4^T(g) on the (TH+2R)x(TW+2R) region; zero outside the image
+    for (int i = tid; i < T1H * T1W; i += NT) {
+        const int ly = i / T1W, lx = i - ly * T1W;
+        const int gy = y0 - R + ly, gx = x0 - R + lx;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        if (in) {
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    const float v = s_lds[(ly + dy) * (SW + 1) + lx + dx];
+                    const float* wt = pk + o.w4 + (KK - 1 - (dy * K + dx));     // W4[ic][mirrored tap], wave-uniform
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = fmaf(wt[c * KK], v, acc[c]);
+                }
+        }
+        const bool centre = in && ly >= R && ly < R + TH && lx >= R && lx < R + TW;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            t1[c * T1PS + ly * T1W + lx] = acc[c];
+            if (centre) dt3_out[(z * C + c) * cs + (int64_t)gy * w + gx] = acc[c];
+        }
+    }
+    __syncthreads();
+    floatx4 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    conv16_mfma_ps<K, T1PS, T1W>(t1, wl, wave, lane, acc);
+    const int px = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t cb = (z * C + 4 * kk + r) * cs;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
+            if (gy < h && gx < w) {
+                const int64_t idx = cb + (int64_t)gy * w + gx;
+                const float tv = t2[idx];
+                dpre2_out[idx] = linear ? acc[n][r] : acc[n][r] * (1.f - tv * tv);
+            }
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(NT) void k_lift_bwd_b_mfma(const float* __restrict__ dpre2, const float* __restrict__ t1v,
+                                                        const float* __restrict__ dt3, float* __restrict__ dr_out,
+                                                        int batch, int h, int w, const float* __restrict__ packed,
+                                                        int64_t packed_plane_stride, int vertical, int linear) {
+    constexpr int C = 16, R = K / 2, KK = K * K;
+    constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;
+    constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
+    constexpr int NL = (T1H * T1W + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* t = lds;                                        // [C] planes of dpre2
+    float* wl = t + C * T1PS;                              // conv2^T weights
+    const PackOff o = pack_off(C, K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
+    const int64_t cs = (int64_t)h * w;
+    stage_w16T<K>(wl, pk + o.w2, tid);
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        const int i = tid + r * NT;
+        const int ly = i / T1W, lx = i - ly * T1W;
+        const int gy = y0 - R + ly, gx = x0 - R + lx;
+        const bool in = i < T1H * T1W && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const int64_t off = in ? (z * C) * cs + (int64_t)gy * w + gx : 0;
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = dpre2[off + c * cs];            // safe address + select: no branches
+        if (i < T1H * T1W) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[c * T1PS + ly * T1W + lx] = in ? v[c] : 0.f;
+        }
+    }
+    __syncthreads();
+    floatx4 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    conv16_mfma_ps<K, T1PS, T1W>(t, wl, wave, lane, acc);
+    const int px = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t cb = (z * C + 4 * kk + r) * cs;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
+            if (gy < h && gx < w) {
+                const int64_t idx = cb + (int64_t)gy * w + gx;
+                const float tv = t1v[idx];
+                dr_out[idx] = (linear ? acc[n][r] : acc[n][r] * (1.f - tv * tv)) + dt3[idx];
+            }
+        }
+    }
+    (void)KK;
+}
+
+// dsk = conv1^T(dr): 16 -> 1, VALU (mirror of kernel C)
+template <int C, int K>
+__global__ __launch_bounds__(NT) void k_lift_bwd_a(const float* __restrict__ dr, float* __restrict__ dsk, int batch, int h,
+                                                   int w, const float* __restrict__ packed, int64_t packed_plane_stride,
+                                                   int vertical) {
+    constexpr int R = K / 2, KK = K * K;
+    constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R, T1P = T1W + 1;
+    constexpr int NL = (T1H * T1W + NT - 1) / NT;
+    __shared__ float t[C][T1H][T1P];
+    const PackOff o = pack_off(C, K);
+    const int tid = threadIdx.x;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
+    const int64_t cs = (int64_t)h * w;
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        const int i = tid + r * NT;
+        const int ly = i / T1W, lx = i - ly * T1W;
+        const int gy = y0 - R + ly, gx = x0 - R + lx;
+        const bool in = i < T1H * T1W && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const int64_t off = in ? (z * C) * cs + (int64_t)gy * w + gx : 0;
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = dr[off + c * cs];
+        if (i < T1H * T1W) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[c][ly][lx] = in ? v[c] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int ly = tid / TW, lx = tid % TW;
+    float a0 = 0.f, a1 = 0.f;
+    for (int ic = 0; ic < C; ++ic) {
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const float wv = pk[o.w1 + (KK - 1 - (dy * K + dx)) * C + ic];     // W1[oc = ic][mirrored tap]
+                a0 = fmaf(wv, t[ic][ly + dy][lx + dx], a0);
+                a1 = fmaf(wv, t[ic][ly + TH / 2 + dy][lx + dx], a1);
+            }
+    }
+    const int gx = x0 + lx;
+    if (gx < w) {
+        const int gy0 = y0 + ly, gy1 = gy0 + TH / 2;
+        if (gy0 < h) dsk[z * cs + (int64_t)gy0 * w + gx] = a0;
+        if (gy1 < h) dsk[z * cs + (int64_t)gy1 * w + gx] = a1;
+    }
+}
+
 // where one step keeps its intermediates (training: a per-step slice of the caller's `saved` buffer)
 struct StepBufs {
     float* skip;   // (Z,h,w)
@@ -880,6 +1089,87 @@ extern "C" int lldwt_lift_bwd_fin(const float* g, const float* dsk, const float*
     hipLaunchKernelGGL(k_lift_bwd_fin, grid, dim3(256), 0, (hipStream_t)stream, g, dsk, srcv, g_src, (int)batch, (int)h,
                        (int)w, taps, dtaps, vertical, sign, res_weight);
     return check_launch("lift_bwd_fin");
+}
+
+extern "C" int64_t lldwt_lift_step_bwd_ws_bytes(int64_t Z, int64_t h, int64_t w, int C) {
+    return (int64_t)sizeof(float) * Z * h * w * (2 + 3 * (int64_t)C);     // g | dsk | dt3 | dpre2 | dr
+}
+
+template <int K>
+static int launch_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, float* g, float* dsk, float* dt3, float* dpre2,
+                           float* dr, const float* t1, const float* t2, int64_t Z, int64_t batch, int64_t h, int64_t w,
+                           const float* packed, int64_t pstride, int vertical, int linear, hipStream_t st) {
+    constexpr int R = K / 2, R2 = 2 * R, KK = K * K;
+    constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;
+    constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
+    constexpr size_t sh_c = sizeof(float) * ((TH + 2 * R2) * (TW + 2 * R2 + 1) + 16 * T1PS + KK * 4 * 64);
+    constexpr size_t sh_b = sizeof(float) * (16 * T1PS + KK * 4 * 64);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)k_lift_bwd_c_mfma<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_c);
+        hipFuncSetAttribute((const void*)k_lift_bwd_b_mfma<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)cdiv(w, TW), (unsigned)cdiv(h, TH), (unsigned)Z), block(NT);
+    hipLaunchKernelGGL((k_lift_bwd_c_mfma<K>), grid, block, sh_c, st, cv(g_dst_out), g_dst_in, g, t2, dt3, dpre2, (int)batch,
+                       (int)h, (int)w, packed, pstride, vertical, linear);
+    hipLaunchKernelGGL((k_lift_bwd_b_mfma<K>), grid, block, sh_b, st, dpre2, t1, dt3, dr, (int)batch, (int)h, (int)w, packed,
+                       pstride, vertical, linear);
+    hipLaunchKernelGGL((k_lift_bwd_a<16, K>), grid, block, 0, st, dr, dsk, (int)batch, (int)h, (int)w, packed, pstride,
+                       vertical);
+    return check_launch("lift_step_bwd");
+}
+
+extern "C" int lldwt_lift_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_src, const float* saved_step,
+                                   int64_t planes, int64_t batch, int64_t h, int64_t w, const float* taps, float* dtaps,
+                                   const float* packed, int64_t packed_plane_stride, float* dw1, float* db1, float* dw2,
+                                   float* db2, float* dw3, float* db3, float* dw4, float* db4, int C, int K,
+                                   float res_weight, float sign, int vertical, int linear, void* ws, int64_t ws_bytes,
+                                   void* stream) {
+    LLDWT_REQUIRE(g_dst_out.p && g_dst_in.p && g_src.p && saved_step && taps && dtaps && packed && ws,
+                  "lift_step_bwd: null pointer");
+    LLDWT_REQUIRE(dw1 && db1 && dw2 && db2 && dw3 && db3 && dw4 && db4, "lift_step_bwd: null gradient pointer");
+    LLDWT_REQUIRE(planes > 0 && batch > 0 && h > 0 && w > 0 && planes * batch <= 65535, "lift_step_bwd: bad dims");
+    LLDWT_REQUIRE(C == 16 && (K == 3 || K == 5), "lift_step_bwd: built for C=16, K in {3,5} (got C=%d K=%d)", C, K);
+    const int64_t Z = planes * batch, n = Z * h * w;
+    if (ws_bytes < lldwt_lift_step_bwd_ws_bytes(Z, h, w, C)) {
+        set_error("lift_step_bwd: workspace %ld < %ld bytes", (long)ws_bytes, (long)lldwt_lift_step_bwd_ws_bytes(Z, h, w, C));
+        return LLDWT_EWS;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // saved layout of the forward step: [srcv | skip | t1 | t2 | t3]
+    const float* srcv = saved_step;
+    const float* skip = saved_step + n;
+    const float* t1 = skip + n;
+    const float* t2 = t1 + n * C;
+    const float* t3 = t2 + n * C;
+    float* g = (float*)ws;
+    float* dsk = g + n;
+    float* dt3 = dsk + n;
+    float* dpre2 = dt3 + n * C;
+    float* dr = dpre2 + n * C;
+    int r = K == 5 ? launch_step_bwd<5>(g_dst_out, g_dst_in, g, dsk, dt3, dpre2, dr, t1, t2, Z, batch, h, w, packed,
+                                        packed_plane_stride, vertical, linear, st)
+                   : launch_step_bwd<3>(g_dst_out, g_dst_in, g, dsk, dt3, dpre2, dr, t1, t2, Z, batch, h, w, packed,
+                                        packed_plane_stride, vertical, linear, st);
+    if (r) return r;
+    // weight gradients (scaled by sign*res_weight: net enters dst as sign*rw*net); row passes store (kh,kw) swapped
+    const float alpha = sign * res_weight;
+    const int swap = vertical ? 0 : 1;
+    lldwt_conv_desc d;
+    auto desc = [&](int cin, int cout) {
+        d.cin = cin; d.cout = cout; d.K = K; d.groups = 1; d.act = LLDWT_ACT_NONE; d.upsample2 = 0; d.transposed = 0;
+        d.tap_mask = (1u << (K * K)) - 1u; d.oc_block = cout; d.oc_stride = 0; d.oc_off = 0; d.ytot = cout;
+        d.ic_block = 0; d.ic_stride = 0; d.ic_off = 0; d.xtot = 0; d.epi = 0;
+    };
+    desc(C, 1);
+    if ((r = lldwt_conv2d_wgrad_ex(t3, g, dw4, db4, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    desc(C, C);
+    if ((r = lldwt_conv2d_wgrad_ex(t2, dt3, dw3, db3, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    if ((r = lldwt_conv2d_wgrad_ex(t1, dpre2, dw2, db2, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    desc(1, C);
+    if ((r = lldwt_conv2d_wgrad_ex(skip, dr, dw1, db1, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    return lldwt_lift_bwd_fin(g, dsk, srcv, g_src, Z, batch, h, w, taps, dtaps, vertical, sign, res_weight, stream);
 }
 
 // workspace: [Lrow | Hrow | tmpL | tmpH] (each Z*(H/2)*W) + 2 LL ping-pong (Z*(H/2)*(W/2)) + step ws

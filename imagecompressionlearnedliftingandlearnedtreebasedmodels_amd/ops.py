@@ -453,6 +453,20 @@ def lift_bwd_fin(g, dsk, srcv, g_src, Z, batch, h, w, taps, dtaps, vertical, sig
                                          int(vertical), float(sign), float(rw), _stream()), "lift_bwd_fin")
 
 
+def lift_step_bwd(g_dst_out, g_dst_in, g_src, saved_step, P, B, h, w, taps, dtaps, packed, packed_plane_stride, dW, Cc, K,
+                  rw, sign, vertical, linear):
+    """Whole backward of one lifting step (include/lldwt.h lldwt_lift_step_bwd).  g_*: lldwt_views over the gradient
+    buffers; packed: forward pack of this step's block (pointer already offset to the block); dW: the 8 gradient
+    tensors (w1,b1,...,w4,b4) of the block, each (P,...), accumulated in place."""
+    lib = _lib.load()
+    nb = lib.lldwt_lift_step_bwd_ws_bytes(P * B, h, w, Cc)
+    ws = workspace(nb, taps.device)
+    check(lib.lldwt_lift_step_bwd(g_dst_out, g_dst_in, g_src, _chk(saved_step), P, B, h, w, _chk(taps), _chk(dtaps),
+                                  packed, packed_plane_stride, *[_chk(t) for t in dW], Cc, K, float(rw), float(sign),
+                                  int(bool(vertical)), int(bool(linear)), C.c_void_p(ws.data_ptr()), nb, _stream()),
+          "lift_step_bwd")
+
+
 def ew_mul(a, b, scale=1.0):
     out = torch.empty_like(a)
     check(_lib.load().lldwt_ew_mul(_chk(a), _chk(b), _chk(out), a.numel(), float(scale), _stream()), "ew_mul")

@@ -142,6 +142,20 @@ int lldwt_lift_bwd_fin(const float* g, const float* dsk, const float* srcv, lldw
                        int64_t h, int64_t w, const float* taps, float* dtaps, int vertical, float sign, float res_weight,
                        void* stream);
 
+/* Whole backward of one lifting step with C == 16 (replaces autograd through wavelet_forward_v2.py:60-74 /
+ * wavelet_inverse_v2.py:76-90 + P_block_v2.py:40-55): fused backward-data kernels on the matrix cores, the four
+ * weight gradients (accumulated, scaled by sign*res_weight, row passes in (kw,kh) order like the weights' use), the
+ * skip-filter transpose and its tap gradients.  saved_step: this step's slice of the forward `saved` buffer
+ * [src | skip | t1 | t2 | t3]; packed/packed_plane_stride: the FORWARD pack of this step's P/U block
+ * (lldwt_pack_pblock); dw1..db4: (planes, ...) gradients of that block, accumulated; taps/dtaps: (planes,3) of this
+ * step's skip filter.  ws: lldwt_lift_step_bwd_ws_bytes. */
+int64_t lldwt_lift_step_bwd_ws_bytes(int64_t Z, int64_t h, int64_t w, int C);
+int lldwt_lift_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_src, const float* saved_step,
+                        int64_t planes, int64_t batch, int64_t h, int64_t w, const float* taps, float* dtaps,
+                        const float* packed, int64_t packed_plane_stride, float* dw1, float* db1, float* dw2, float* db2,
+                        float* dw3, float* db3, float* dw4, float* db4, int C, int K, float res_weight, float sign,
+                        int vertical, int linear, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * SubbandAutoEncoder (lifting_dwt_nets.py:99-110): per-coefficient scalar MLP 1 -> Hd -> Hd -> Hd -> 1, tanh
  * between, grouped 1x1 convs (groups == channels).  x,y: (Z,C,h,w).  Parameters per plane, PyTorch layouts:
