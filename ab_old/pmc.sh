@@ -1,8 +1,6 @@
 #!/bin/bash
 set -e
 R=$GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_backward.py -q -x -k "wgrad or conv_backward" > gpurun_out/t1.log 2>&1
-python tools_bench_bwd.py --iters 5 > gpurun_out/bwd_cur.json 2> gpurun_out/bwd_cur.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM -d $R/gpurun_out/pmc_w1 -o w1 --output-format csv -- python3 $R/tools_bench_bwd.py --only plc_243 --iters 2 > $R/gpurun_out/pmc_w1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS -d $R/gpurun_out/pmc_w2 -o w2 --output-format csv -- python3 $R/tools_bench_bwd.py --only plc_243 --iters 2 > $R/gpurun_out/pmc_w2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM -d $R/gpurun_out/pmc_w1 -o w1 --output-format csv -- python3 $R/tools_bench_bwd.py --only "$1" --iters 2 > $R/gpurun_out/pmc_w1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS -d $R/gpurun_out/pmc_w2 -o w2 --output-format csv -- python3 $R/tools_bench_bwd.py --only "$1" --iters 2 > $R/gpurun_out/pmc_w2.log 2>&1

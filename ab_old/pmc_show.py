@@ -1,0 +1,11 @@
+import csv,collections,sys
+pat=sys.argv[1:]
+for f in ['gpurun_out/pmc_w1/w1_counter_collection.csv','gpurun_out/pmc_w2/w2_counter_collection.csv']:
+    agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
+    for r in csv.DictReader(open('/root/repo/'+f)):
+        k=r['Kernel_Name'][:70]
+        agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
+    for k,v in agg.items():
+        if any(p in k for p in pat):
+            print(k)
+            for c,x in sorted(v.items()): print('   ',c,f'{x:.4g}')

@@ -267,10 +267,12 @@ struct W16Args {
 template <int K>
 __global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
     constexpr int NTH = K * 64, KK = K * K, R = K / 2;
-    constexpr int IH = WG_TH + 2 * R, IW = WG_TW + 2 * R, IHW = IH * IW, PSX = IHW + 1;
-    constexpr int NA = (16 * WG_PX + NTH - 1) / NTH, NX = (16 * IHW + NTH - 1) / NTH;
+    constexpr int IH = WG_TH + 2 * R, IW = WG_TW + 2 * R, IHW = IH * IW;
+    constexpr int PSX = IHW + 2;                       // even (8-byte aligned rows for ds_write_b64), == 18 / 22 (mod 32)
+    constexpr int NVR = (IW + 3) / 4;                  // dwordx4 loads per X patch row
+    constexpr int NAV = (16 * WG_PX / 4 + NTH - 1) / NTH, NXV = (16 * IH * NVR + NTH - 1) / NTH;
     constexpr int NSM = 16 * WG_PSA + 16 * PSX > 256 * KK ? 16 * WG_PSA + 16 * PSX : 256 * KK;
-    __shared__ float smem[NSM];
+    __shared__ __attribute__((aligned(16))) float smem[NSM];
     float* la = smem;                 // [16][WG_PSA]
     float* lx = smem + 16 * WG_PSA;   // [16][PSX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -285,8 +287,22 @@ __global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
     for (int j = 0; j < K; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     const int bb = col * PSX + wave * IW + kk;
-    float va[NA], vx[NX];
+    floatx4 va[NAV], vx[NXV];
 
+    // row segments of 4 pixels: one dwordx4 load when the segment lies inside the image (safe address + select); segments
+    // that straddle the image border (left/right edge tiles only) take the per-pixel path
+#define LLDWT_W16_VEC(dst_, base_, c_, gy_, gx_, live_)                                                          \
+    {                                                                                                            \
+        const bool row_ = (live_) && (gy_) >= 0 && (gy_) < h;                                                    \
+        const bool ok4_ = row_ && (gx_) >= 0 && (gx_) + 3 < w;                                                   \
+        const int64_t off_ = (c_) * hw + (int64_t)(gy_) * w + (gx_);                                             \
+        const f4u t4_ = *reinterpret_cast<const f4u*>(base_ + (ok4_ ? off_ : 0));                                \
+        dst_ = ok4_ ? floatx4{t4_.x, t4_.y, t4_.z, t4_.w} : floatx4{0.f, 0.f, 0.f, 0.f};                         \
+        if (row_ && !ok4_ && (gx_) + 3 >= 0 && (gx_) < w) {                                                      \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                     \
+                if ((gx_) + e_ >= 0 && (gx_) + e_ < w) dst_[e_] = base_[off_ + e_];                              \
+        }                                                                                                        \
+    }
 #define LLDWT_W16_LOAD(q_)                                                                                       \
     {                                                                                                            \
         const int b_ = (q_) / ntile, t_ = (q_) - b_ * ntile;                                                     \
@@ -294,21 +310,17 @@ __global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
         const float* dyz = a.dy + z_ * 16 * hw;                                                                  \
         const float* xz = a.x + z_ * 16 * hw;                                                                    \
         const int y0 = (t_ / tiles_x) * WG_TH, x0 = (t_ % tiles_x) * WG_TW;                                      \
-        _Pragma("unroll") for (int r = 0; r < NA; ++r) {                                                         \
+        _Pragma("unroll") for (int r = 0; r < NAV; ++r) {                                                        \
             const int i = tid + r * NTH;                                                                         \
-            const int c = i / WG_PX, p = i % WG_PX;                                                              \
-            const int gy = y0 + p / WG_TW, gx = x0 + p % WG_TW;                                                  \
-            const bool ok = i < 16 * WG_PX && gy < h && gx < w;                                                  \
-            const float tv = dyz[ok ? c * hw + (int64_t)gy * w + gx : 0];                                        \
-            va[r] = ok ? tv : 0.f;                                                                               \
+            const int c = i / (WG_PX / 4), rq = i % (WG_PX / 4);                                                 \
+            const int gy = y0 + rq / (WG_TW / 4), gx = x0 + 4 * (rq % (WG_TW / 4));                              \
+            LLDWT_W16_VEC(va[r], dyz, c, gy, gx, i < 16 * WG_PX / 4)                                             \
         }                                                                                                        \
-        _Pragma("unroll") for (int r = 0; r < NX; ++r) {                                                         \
+        _Pragma("unroll") for (int r = 0; r < NXV; ++r) {                                                        \
             const int i = tid + r * NTH;                                                                         \
-            const int c = i / IHW, rem = i - c * IHW;                                                            \
-            const int gy = y0 - R + rem / IW, gx = x0 - R + rem % IW;                                            \
-            const bool ok = i < 16 * IHW && gy >= 0 && gy < h && gx >= 0 && gx < w;                              \
-            const float tv = xz[ok ? c * hw + (int64_t)gy * w + gx : 0];                                         \
-            vx[r] = ok ? tv : 0.f;                                                                               \
+            const int c = i / (IH * NVR), rem = i - c * (IH * NVR);                                              \
+            const int gy = y0 - R + rem / NVR, gx = x0 - R + 4 * (rem % NVR);                                    \
+            LLDWT_W16_VEC(vx[r], xz, c, gy, gx, i < 16 * IH * NVR)                                               \
         }                                                                                                        \
     }
 
@@ -317,14 +329,24 @@ __global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
     for (; q < total; q += gridDim.x) {
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < NA; ++r) {
+        for (int r = 0; r < NAV; ++r) {
             const int i = tid + r * NTH;
-            if (i < 16 * WG_PX) la[(i / WG_PX) * WG_PSA + (i % WG_PX)] = va[r];
+            if (i < 16 * WG_PX / 4) {
+                float2* d2 = reinterpret_cast<float2*>(la + (i / (WG_PX / 4)) * WG_PSA + 4 * (i % (WG_PX / 4)));
+                d2[0] = float2{va[r][0], va[r][1]};
+                d2[1] = float2{va[r][2], va[r][3]};
+            }
         }
 #pragma unroll
-        for (int r = 0; r < NX; ++r) {
+        for (int r = 0; r < NXV; ++r) {
             const int i = tid + r * NTH;
-            if (i < 16 * IHW) lx[(i / IHW) * PSX + (i % IHW)] = vx[r];
+            if (i < 16 * IH * NVR) {
+                const int c = i / (IH * NVR), rem = i - c * (IH * NVR);
+                const int lxx = 4 * (rem % NVR);
+                float2* d2 = reinterpret_cast<float2*>(lx + c * PSX + (rem / NVR) * IW + lxx);
+                if (lxx + 1 < IW) d2[0] = float2{vx[r][0], vx[r][1]};
+                if (lxx + 3 < IW) d2[1] = float2{vx[r][2], vx[r][3]};
+            }
         }
         __syncthreads();
         const int qn = q + gridDim.x;
@@ -380,8 +402,8 @@ template <int K>
 __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
     constexpr int KK = K * K, R = K / 2, NJ = (KK + 15) / 16;
     constexpr int IH = WG_TH + 2 * R, IW = WG_TW + 2 * R, IHW = IH * IW;
-    constexpr int NA = 16 * WG_PX / 256, NB = (IHW + 255) / 256;
-    __shared__ float la[16 * WG_PSA];      // reused by the epilogue: [4 waves][16*KK] partial tiles
+    constexpr int NAV = 16 * WG_PX / 4 / 256, NB = (IHW + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float la[16 * WG_PSA];      // reused by the epilogue: [4 waves][16*KK] partial tiles
     __shared__ float lb[IHW + 8];
     static_assert(4 * 16 * KK <= 16 * WG_PSA, "epilogue scratch");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -404,7 +426,8 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
         boff[j] = tdy * IW + tdx + kk;
     }
     float bsum = 0.f, bsb = 0.f;
-    float va[NA], vb[NB];
+    floatx4 va[NAV];
+    float vb[NB];
 
 #define LLDWT_WT_LOAD(q_)                                                                                        \
     {                                                                                                            \
@@ -413,13 +436,11 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
         const float* az = a.a16 + z_ * 16 * hw;                                                                  \
         const float* bz = a.b1 + z_ * hw;                                                                        \
         const int y0 = (t_ / tiles_x) * WG_TH, x0 = (t_ % tiles_x) * WG_TW;                                      \
-        _Pragma("unroll") for (int r = 0; r < NA; ++r) {                                                         \
+        _Pragma("unroll") for (int r = 0; r < NAV; ++r) {                                                        \
             const int i = tid + r * 256;                                                                         \
-            const int c = i / WG_PX, p = i % WG_PX;                                                              \
-            const int gy = y0 + p / WG_TW, gx = x0 + p % WG_TW;                                                  \
-            const bool ok = gy < h && gx < w;                                                                    \
-            const float tv = az[ok ? c * hw + (int64_t)gy * w + gx : 0];                                         \
-            va[r] = ok ? tv : 0.f;                                                                               \
+            const int c = i / (WG_PX / 4), rq = i % (WG_PX / 4);                                                 \
+            const int gy = y0 + rq / (WG_TW / 4), gx = x0 + 4 * (rq % (WG_TW / 4));                              \
+            LLDWT_W16_VEC(va[r], az, c, gy, gx, true)                                                            \
         }                                                                                                        \
         _Pragma("unroll") for (int r = 0; r < NB; ++r) {                                                         \
             const int i = tid + r * 256;                                                                         \
@@ -435,9 +456,11 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
     for (; q < total; q += gridDim.x) {
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < NA; ++r) {
+        for (int r = 0; r < NAV; ++r) {
             const int i = tid + r * 256;
-            la[(i / WG_PX) * WG_PSA + (i % WG_PX)] = va[r];
+            float2* d2 = reinterpret_cast<float2*>(la + (i / (WG_PX / 4)) * WG_PSA + 4 * (i % (WG_PX / 4)));
+            d2[0] = float2{va[r][0], va[r][1]};
+            d2[1] = float2{va[r][2], va[r][3]};
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
@@ -467,6 +490,7 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
         }
     }
 #undef LLDWT_WT_LOAD
+#undef LLDWT_W16_VEC
     // the 4 waves hold partial tiles over disjoint pixels: sum them in LDS, then one coalesced atomic per element
     float* dwp = a.dw + (int64_t)plane * 16 * KK;
     __syncthreads();
@@ -482,13 +506,18 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
     __syncthreads();
     for (int i = tid; i < 16 * KK; i += 256)
         atomicAdd(dwp + i, a.alpha * ((la[i] + la[16 * KK + i]) + (la[2 * 16 * KK + i] + la[3 * 16 * KK + i])));
+    // bias: one atomic instruction per workgroup (every workgroup of a plane hits the same cache line)
     if (a.bias_mode == 1) {
         bsum += __shfl_xor(bsum, 16, 64);
         bsum += __shfl_xor(bsum, 32, 64);
-        if (kk == 0) atomicAdd(a.db + plane * 16 + col, a.alpha * bsum);
+        if (kk == 0) lb[wave * 16 + col] = bsum;
+        __syncthreads();
+        if (tid < 16) atomicAdd(a.db + plane * 16 + tid, a.alpha * ((lb[tid] + lb[16 + tid]) + (lb[32 + tid] + lb[48 + tid])));
     } else if (a.bias_mode == 2) {
         bsb = wave_sum(bsb);
-        if (lane == 0) atomicAdd(a.db + plane, a.alpha * bsb);
+        if (lane == 0) lb[wave] = bsb;
+        __syncthreads();
+        if (tid == 0) atomicAdd(a.db + plane, a.alpha * ((lb[0] + lb[1]) + (lb[2] + lb[3])));
     }
 }
 
@@ -622,16 +651,28 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
         const bool plain = d->groups == 1 && !d->upsample2 && nt == KK && d->oc_block >= d->cout && d->oc_off == 0 &&
                            d->ytot == d->cout && d->ic_block == 0 && (d->K == 3 || d->K == 5);
         const int64_t chunks = batch * cdiv(h, WG_TH) * cdiv(w_, WG_TW);
-        int64_t slices = cdiv(1536, planes);
-        if (slices > chunks / 4) slices = chunks / 4;
-        if (slices < 1) slices = 1;
-        dim3 grid((unsigned)slices, 1, (unsigned)planes);
+        // one resident round: as many workgroups as the chip holds at once (equal-time workgroups, so a partial second
+        // round would idle most CUs), at least 4 chunks each; the memory-bound thin kernel stops at 4 per CU (more
+        // workgroups only add contention on the few cache lines of its output)
+        auto slices_for = [&](const void* kern, int threads, int cap_per_cu) {
+            int per_cu = 2;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+            if (per_cu > cap_per_cu) per_cu = cap_per_cu;
+            int64_t sl = (int64_t)lldwt_num_cus() * per_cu / planes;
+            if (sl > chunks / 4) sl = chunks / 4;
+            return sl < 1 ? (int64_t)1 : sl;
+        };
         if (plain && d->cin == 16 && d->cout == 16) {
             W16Args w;
             w.x = x; w.dy = dy; w.dw = dw; w.db = dbias; w.batch = (int)batch; w.h = (int)h; w.w = (int)w_; w.alpha = alpha;
             for (int t = 0; t < 25; ++t) w.tap_of[t] = t < KK ? a.tap_of[t] : 0;
-            if (d->K == 5) hipLaunchKernelGGL(k_wgrad16<5>, grid, dim3(320), 0, st, w);
-            else hipLaunchKernelGGL(k_wgrad16<3>, grid, dim3(192), 0, st, w);
+            if (d->K == 5) {
+                dim3 grid((unsigned)slices_for((const void*)k_wgrad16<5>, 320, 8), 1, (unsigned)planes);
+                hipLaunchKernelGGL(k_wgrad16<5>, grid, dim3(320), 0, st, w);
+            } else {
+                dim3 grid((unsigned)slices_for((const void*)k_wgrad16<3>, 192, 8), 1, (unsigned)planes);
+                hipLaunchKernelGGL(k_wgrad16<3>, grid, dim3(192), 0, st, w);
+            }
             return check_launch("conv2d_wgrad");
         }
         if (plain && ((d->cin == 1 && d->cout == 16) || (d->cin == 16 && d->cout == 1))) {
@@ -641,8 +682,13 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
             w.batch = (int)batch; w.h = (int)h; w.w = (int)w_; w.alpha = alpha; w.flip = c4 ? 1 : 0;
             w.bias_mode = dbias ? (c4 ? 2 : 1) : 0;
             for (int t = 0; t < 25; ++t) w.tap_of[t] = t < KK ? a.tap_of[t] : 0;
-            if (d->K == 5) hipLaunchKernelGGL(k_wgrad_thin<5>, grid, dim3(256), 0, st, w);
-            else hipLaunchKernelGGL(k_wgrad_thin<3>, grid, dim3(256), 0, st, w);
+            if (d->K == 5) {
+                dim3 grid((unsigned)slices_for((const void*)k_wgrad_thin<5>, 256, 4), 1, (unsigned)planes);
+                hipLaunchKernelGGL(k_wgrad_thin<5>, grid, dim3(256), 0, st, w);
+            } else {
+                dim3 grid((unsigned)slices_for((const void*)k_wgrad_thin<3>, 256, 4), 1, (unsigned)planes);
+                hipLaunchKernelGGL(k_wgrad_thin<3>, grid, dim3(256), 0, st, w);
+            }
             return check_launch("conv2d_wgrad");
         }
     }
