@@ -152,6 +152,104 @@ __global__ __launch_bounds__(256) void k_cdf97_fwd_level(V3 in, V3 ll, V3 lh, V3
     }
 }
 
+// Fast variant of the forward level for rows of contiguous pixels, w % 4 == 0 and h, w >= CIN (every level of a 512^2
+// or larger image but the deepest ones).  Same arithmetic as k_cdf97_fwd_level (the zero taps of the table are skipped),
+// organised for the memory pipe:
+//   * the input patch arrives as dwordx4 loads (the patch starts at a multiple of 4 pixels, so a vector never straddles
+//     the periodic wrap) and is de-interleaved into even / odd columns in LDS: the stride-2 reads of the width pass
+//     become unit-stride (they were 2-way bank conflicts);
+//   * every thread produces two adjacent outputs, reading and writing LDS as 8-byte words.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };
+constexpr float DEC_LO[10] = {0.0f, 0.037828455507264f, -0.023849465019557f, -0.110624404418437f, 0.377402855612831f,
+                              0.852698679008894f, 0.377402855612831f, -0.110624404418437f, -0.023849465019557f,
+                              0.037828455507264f};
+constexpr float DEC_HI[10] = {0.0f, -0.064538882628697f, 0.040689417609164f, 0.418092273221617f, -0.788485616405583f,
+                              0.418092273221617f, 0.040689417609164f, -0.064538882628697f, 0.0f, 0.0f};
+constexpr int CHP = CIN / 2 + 2;           // pitch of the even / odd column planes (38: even, rows 8-byte aligned)
+constexpr int CLP = CT + 2;                // pitch of the width-pass outputs (34)
+
+__global__ __launch_bounds__(256) void k_cdf97_fwd_level_v(V3 in, V3 ll, V3 lh, V3 hl, V3 vhh, int h, int w) {
+    __shared__ __attribute__((aligned(16))) float se[CIN][CHP], so[CIN][CHP];
+    __shared__ __attribute__((aligned(16))) float sL[CIN][CLP], sH[CIN][CLP];
+    const int64_t z = blockIdx.z;
+    const int ky0 = blockIdx.y * CT, kx0 = blockIdx.x * CT;
+    const int tid = threadIdx.x;
+    const float* inz = in.p + z * in.sz;
+    constexpr int VR = CIN / 4;                        // vectors per patch row (18)
+    constexpr int NLV = (CIN * VR + 255) / 256;        // 6
+    f4u v[NLV];
+#pragma unroll
+    for (int r = 0; r < NLV; ++r) {
+        const int i = tid + r * 256;
+        const int ly = i / VR, vx = i - ly * VR;
+        int gy = 2 * ky0 - 4 + ly, gx = 2 * kx0 - 4 + 4 * vx;
+        gy += gy < 0 ? h : (gy >= h ? -h : 0);
+        gx += gx < 0 ? w : (gx >= w ? -w : 0);
+        v[r] = *reinterpret_cast<const f4u*>(inz + (i < CIN * VR ? (int64_t)gy * in.sy + gx : 0));
+    }
+#pragma unroll
+    for (int r = 0; r < NLV; ++r) {
+        const int i = tid + r * 256;
+        if (i < CIN * VR) {
+            const int ly = i / VR, vx = i - ly * VR;
+            *reinterpret_cast<floatx2*>(&se[ly][2 * vx]) = floatx2{v[r].x, v[r].z};
+            *reinterpret_cast<floatx2*>(&so[ly][2 * vx]) = floatx2{v[r].y, v[r].w};
+        }
+    }
+    __syncthreads();
+    // width pass, two adjacent outputs per thread: lo/hi[ly][c] = sum_m dec[m] * patch[ly][2c + 9 - m];
+    // column 2c+9-m is even column c+4-(m-1)/2 for odd m, odd column c+4-m/2 for even m
+    for (int i = tid; i < CIN * (CT / 2); i += 256) {
+        const int ly = i / (CT / 2), c = 2 * (i - ly * (CT / 2));
+        float e[6], o[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const floatx2 te = *reinterpret_cast<const floatx2*>(&se[ly][c + 2 * k]);
+            const floatx2 to = *reinterpret_cast<const floatx2*>(&so[ly][c + 2 * k]);
+            e[2 * k] = te[0]; e[2 * k + 1] = te[1];
+            o[2 * k] = to[0]; o[2 * k + 1] = to[1];
+        }
+        floatx2 a = {0.f, 0.f}, d = {0.f, 0.f};
+#pragma unroll
+        for (int m = 1; m < 10; ++m) {
+            const int k = (m & 1) ? 4 - (m - 1) / 2 : 4 - m / 2;
+            const floatx2 x = (m & 1) ? floatx2{e[k], e[k + 1]} : floatx2{o[k], o[k + 1]};
+            a = __builtin_elementwise_fma(floatx2{DEC_LO[m], DEC_LO[m]}, x, a);
+            if (DEC_HI[m] != 0.f) d = __builtin_elementwise_fma(floatx2{DEC_HI[m], DEC_HI[m]}, x, d);
+        }
+        *reinterpret_cast<floatx2*>(&sL[ly][c]) = a;
+        *reinterpret_cast<floatx2*>(&sH[ly][c]) = d;
+    }
+    __syncthreads();
+    // height pass, two adjacent columns per thread
+    const int hh = h / 2, wh = w / 2;
+    for (int i = tid; i < CT * (CT / 2); i += 256) {
+        const int r = i / (CT / 2), c = 2 * (i - r * (CT / 2));
+        const int ky = ky0 + r, kx = kx0 + c;
+        if (ky >= hh || kx >= wh) continue;
+        floatx2 a0 = {0.f, 0.f}, d0 = {0.f, 0.f}, a1 = {0.f, 0.f}, d1 = {0.f, 0.f};
+#pragma unroll
+        for (int m = 1; m < 10; ++m) {
+            const floatx2 vl = *reinterpret_cast<const floatx2*>(&sL[2 * r + 9 - m][c]);
+            const floatx2 vh = *reinterpret_cast<const floatx2*>(&sH[2 * r + 9 - m][c]);
+            const floatx2 cl = {DEC_LO[m], DEC_LO[m]}, ch = {DEC_HI[m], DEC_HI[m]};
+            a0 = __builtin_elementwise_fma(cl, vl, a0);
+            a1 = __builtin_elementwise_fma(cl, vh, a1);
+            if (DEC_HI[m] != 0.f) {
+                d0 = __builtin_elementwise_fma(ch, vl, d0);
+                d1 = __builtin_elementwise_fma(ch, vh, d1);
+            }
+        }
+        const int64_t o = (int64_t)ky * ll.sy + kx;                          // the four outputs share row/col strides
+        *reinterpret_cast<f2u*>(ll.p + z * ll.sz + o) = f2u{a0[0], a0[1]};   // low width, low height
+        *reinterpret_cast<f2u*>(lh.p + z * lh.sz + o) = f2u{d0[0], d0[1]};   // low width, high height
+        *reinterpret_cast<f2u*>(hl.p + z * hl.sz + o) = f2u{a1[0], a1[1]};
+        *reinterpret_cast<f2u*>(vhh.p + z * vhh.sz + o) = f2u{d1[0], d1[1]};
+    }
+}
+
 // inverse: a workgroup reconstructs a (2CT)^2 output tile from (CT+4)^2 patches of the 4 subbands
 constexpr int CS = CT + 4;
 __global__ __launch_bounds__(256) void k_cdf97_inv_level(V3 ll, V3 lh, V3 hl, V3 vhh, V3 out, int h, int w) {
@@ -229,6 +327,113 @@ __global__ __launch_bounds__(256) void k_cdf97_inv_level(V3 ll, V3 lh, V3 hl, V3
     }
 }
 
+// Fast variant of the inverse level (contiguous rows, subband edges >= CS and even): dwordx2 loads of the four subband
+// patches, 8-byte LDS words, each thread reconstructs an (even, odd) row pair of two columns in the height pass and four
+// consecutive pixels in the width pass (both parities share their five input rows / columns); zero taps are skipped.
+constexpr float REC_LO[10] = {0.0f, -0.064538882628697f, -0.040689417609164f, 0.418092273221617f, 0.788485616405583f,
+                              0.418092273221617f, -0.040689417609164f, -0.064538882628697f, 0.0f, 0.0f};
+constexpr float REC_HI[10] = {0.0f, -0.037828455507264f, -0.023849465019557f, 0.110624404418437f, 0.377402855612831f,
+                              -0.852698679008894f, 0.377402855612831f, 0.110624404418437f, -0.023849465019557f,
+                              -0.037828455507264f};
+constexpr int CSP = CS + 2;                // 38: even pitch
+
+__global__ __launch_bounds__(256) void k_cdf97_inv_level_v(V3 ll, V3 lh, V3 hl, V3 vhh, V3 out, int h, int w) {
+    __shared__ __attribute__((aligned(16))) float s4[4][CS][CSP];
+    __shared__ __attribute__((aligned(16))) float sLw[2 * CT][CSP], sHw[2 * CT][CSP];
+    const int64_t z = blockIdx.z;
+    const int y0 = blockIdx.y * 2 * CT, x0 = blockIdx.x * 2 * CT;
+    const int hh = h / 2, wh = w / 2;
+    const int tid = threadIdx.x;
+    const float* sp[4] = {ll.p + z * ll.sz, lh.p + z * lh.sz, hl.p + z * hl.sz, vhh.p + z * vhh.sz};
+    constexpr int VR = CS / 2;                          // float2 per patch row (18)
+    constexpr int NLV = (CS * VR + 255) / 256;          // 3
+    f2u v[4][NLV];
+#pragma unroll
+    for (int r = 0; r < NLV; ++r) {
+        const int i = tid + r * 256;
+        const int lk = i / VR, vx = i - lk * VR;
+        int gy = y0 / 2 - 2 + lk, gx = x0 / 2 - 2 + 2 * vx;
+        gy += gy < 0 ? hh : (gy >= hh ? -hh : 0);
+        gx += gx < 0 ? wh : (gx >= wh ? -wh : 0);
+        const int64_t off = i < CS * VR ? (int64_t)gy * ll.sy + gx : 0;      // the four subbands share the row stride
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[b][r] = *reinterpret_cast<const f2u*>(sp[b] + off);
+    }
+#pragma unroll
+    for (int r = 0; r < NLV; ++r) {
+        const int i = tid + r * 256;
+        if (i < CS * VR) {
+            const int lk = i / VR, vx = i - lk * VR;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) *reinterpret_cast<floatx2*>(&s4[b][lk][2 * vx]) = floatx2{v[b][r].x, v[b][r].y};
+        }
+    }
+    __syncthreads();
+    // height synthesis: rows dn = 2j + par, base row j + 4; taps t = 2u + par at input row base - u
+    for (int i = tid; i < CT * VR; i += 256) {
+        const int j = i / VR, lc = 2 * (i - j * VR);
+        floatx2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, b0 = {0.f, 0.f}, b1 = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int lk = j + 4 - u;
+            const floatx2 q0 = *reinterpret_cast<const floatx2*>(&s4[0][lk][lc]);
+            const floatx2 q1 = *reinterpret_cast<const floatx2*>(&s4[1][lk][lc]);
+            const floatx2 q2 = *reinterpret_cast<const floatx2*>(&s4[2][lk][lc]);
+            const floatx2 q3 = *reinterpret_cast<const floatx2*>(&s4[3][lk][lc]);
+            if (REC_LO[2 * u] != 0.f) {
+                const floatx2 c = {REC_LO[2 * u], REC_LO[2 * u]};
+                a0 = __builtin_elementwise_fma(q0, c, a0);
+                b0 = __builtin_elementwise_fma(q2, c, b0);
+            }
+            if (REC_HI[2 * u] != 0.f) {
+                const floatx2 c = {REC_HI[2 * u], REC_HI[2 * u]};
+                a0 = __builtin_elementwise_fma(q1, c, a0);
+                b0 = __builtin_elementwise_fma(q3, c, b0);
+            }
+            if (REC_LO[2 * u + 1] != 0.f) {
+                const floatx2 c = {REC_LO[2 * u + 1], REC_LO[2 * u + 1]};
+                a1 = __builtin_elementwise_fma(q0, c, a1);
+                b1 = __builtin_elementwise_fma(q2, c, b1);
+            }
+            if (REC_HI[2 * u + 1] != 0.f) {
+                const floatx2 c = {REC_HI[2 * u + 1], REC_HI[2 * u + 1]};
+                a1 = __builtin_elementwise_fma(q1, c, a1);
+                b1 = __builtin_elementwise_fma(q3, c, b1);
+            }
+        }
+        *reinterpret_cast<floatx2*>(&sLw[2 * j][lc]) = a0;
+        *reinterpret_cast<floatx2*>(&sLw[2 * j + 1][lc]) = a1;
+        *reinterpret_cast<floatx2*>(&sHw[2 * j][lc]) = b0;
+        *reinterpret_cast<floatx2*>(&sHw[2 * j + 1][lc]) = b1;
+    }
+    __syncthreads();
+    // width synthesis: four consecutive pixels dm = 4q .. 4q+3 from columns 2q .. 2q+5 of both half-rows
+    float* oz = out.p + z * out.sz;
+    for (int i = tid; i < 2 * CT * (CT / 2); i += 256) {
+        const int dn = i / (CT / 2), q = i - dn * (CT / 2);
+        const int gy = y0 + dn, gx = x0 + 4 * q;
+        if (gy >= h || gx >= w) continue;
+        float L[6], H[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const floatx2 tl = *reinterpret_cast<const floatx2*>(&sLw[dn][2 * q + 2 * k]);
+            const floatx2 th = *reinterpret_cast<const floatx2*>(&sHw[dn][2 * q + 2 * k]);
+            L[2 * k] = tl[0]; L[2 * k + 1] = tl[1];
+            H[2 * k] = th[0]; H[2 * k + 1] = th[1];
+        }
+        floatx2 ev = {0.f, 0.f}, od = {0.f, 0.f};        // (pixel 0, pixel 2) and (pixel 1, pixel 3)
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const floatx2 xl = {L[4 - u], L[5 - u]}, xh = {H[4 - u], H[5 - u]};
+            if (REC_LO[2 * u] != 0.f) ev = __builtin_elementwise_fma(xl, floatx2{REC_LO[2 * u], REC_LO[2 * u]}, ev);
+            if (REC_HI[2 * u] != 0.f) ev = __builtin_elementwise_fma(xh, floatx2{REC_HI[2 * u], REC_HI[2 * u]}, ev);
+            if (REC_LO[2 * u + 1] != 0.f) od = __builtin_elementwise_fma(xl, floatx2{REC_LO[2 * u + 1], REC_LO[2 * u + 1]}, od);
+            if (REC_HI[2 * u + 1] != 0.f) od = __builtin_elementwise_fma(xh, floatx2{REC_HI[2 * u + 1], REC_HI[2 * u + 1]}, od);
+        }
+        *reinterpret_cast<f4u*>(oz + (int64_t)gy * out.sy + gx) = f4u{ev[0], od[0], ev[1], od[1]};
+    }
+}
+
 static inline dim3 grid2d(int64_t h, int64_t w, int64_t Z) {
     return dim3((unsigned)cdiv(w, 256), (unsigned)(h < 2048 ? h : 2048), (unsigned)Z);
 }
@@ -277,7 +482,10 @@ extern "C" int lldwt_cdf97_forward_ex(const float* x, float* ll, float* const* y
         V3 vLL{llout, sub, wh, 1}, vLH{y, 3 * sub, wh, 1}, vHL{y + sub, 3 * sub, wh, 1}, vHH{y + 2 * sub, 3 * sub, wh, 1};
         if (!adj) {       // fused level: one read of the input, one write of the four subbands
             dim3 grid((unsigned)cdiv(wh, CT), (unsigned)cdiv(hh, CT), (unsigned)Z);
-            hipLaunchKernelGGL(k_cdf97_fwd_level, grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
+            if (h >= CIN && w >= CIN && w % 4 == 0 && in.sx == 1)
+                hipLaunchKernelGGL(k_cdf97_fwd_level_v, grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
+            else
+                hipLaunchKernelGGL(k_cdf97_fwd_level, grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
         } else {
             hipLaunchKernelGGL(k_afb, grid2d(h, wh, Z), dim3(256), 0, st, in, lw, hw_, (int)h, (int)w, 1, adj);
             hipLaunchKernelGGL(k_afb, grid2d(hh, wh, Z), dim3(256), 0, st, lw, vLL, vLH, (int)h, (int)wh, 0, adj);
@@ -313,7 +521,10 @@ extern "C" int lldwt_cdf97_inverse_ex(const float* ll, const float* const* yh, f
         V3 vo{out, h * w, w, 1};
         if (!adj) {
             dim3 grid((unsigned)cdiv(w, 2 * CT), (unsigned)cdiv(h, 2 * CT), (unsigned)Z);
-            hipLaunchKernelGGL(k_cdf97_inv_level, grid, dim3(256), 0, st, vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
+            if (hh >= CS && wh >= CS && wh % 2 == 0)
+                hipLaunchKernelGGL(k_cdf97_inv_level_v, grid, dim3(256), 0, st, vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
+            else
+                hipLaunchKernelGGL(k_cdf97_inv_level, grid, dim3(256), 0, st, vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
         } else {
             hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vLL, vLH, lw, (int)h, (int)wh, 0, adj);
             hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vHL, vHH, hw_, (int)h, (int)wh, 0, adj);

@@ -234,3 +234,13 @@ def test_cdf97_vs_pywt_and_round_trip():
     assert maxdiff(ops.cdf97_inverse(ll, yh), big) < 5e-5
     oll, oyh = cdf97.dwt_forward(big[0].cpu(), 4)
     assert maxdiff(ll[0].cpu(), oll) < 5e-5
+    for i in range(4):
+        assert maxdiff(yh[i][0].cpu(), oyh[i]) < 5e-5, i
+    # ragged tiles of the fused level kernels (subband sizes that are not multiples of the 32x32 tile), non-square
+    rag = torch.rand(1, 2, 1, 144, 200, device=gu.DEV) - 0.5
+    ll, yh = ops.cdf97_forward(rag, 3)
+    oll, oyh = cdf97.dwt_forward(rag[0].cpu(), 3)
+    assert maxdiff(ll[0].cpu(), oll) < 5e-5
+    for i in range(3):
+        assert maxdiff(yh[i][0].cpu(), oyh[i]) < 5e-5, i
+    assert maxdiff(ops.cdf97_inverse(ll, yh), rag) < 5e-5
