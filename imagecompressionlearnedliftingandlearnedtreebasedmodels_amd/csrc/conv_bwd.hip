@@ -121,17 +121,27 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
 
     // one row segment of 4 pixels: a single dwordx4 load when it lies inside the image (safe address + select, no
     // branch per element); the ragged right edge (w % 4 != 0) takes the per-pixel path
-#define LLDWT_WG_LOAD4(dst_, base_, choff_, cstride_, wrow_, iv_)                                                \
+    // (two phases: ISSUE4 only issues the load -- from a safe address when the segment is not fully inside -- and FIX4,
+    //  run after all loads of the batch are in flight, zeroes / patches it: a branch between two loads would make the
+    //  compiler wait for the first one)
+#define LLDWT_WG_ISSUE4(raw_, base_, choff_, cstride_, wrow_, iv_)                                               \
+    {                                                                                                            \
+        const int c_ = (iv_) / (WG_PX / 4), rq_ = (iv_) % (WG_PX / 4);                                           \
+        const int gy_ = y0 + rq_ / (WG_TW / 4), gx_ = x0 + 4 * (rq_ % (WG_TW / 4));                              \
+        const int co_ = choff_[c_];                                                                              \
+        const bool ok4_ = co_ >= 0 && gy_ < h && gx_ + 3 < w;                                                    \
+        raw_ = *reinterpret_cast<const f4u*>(base_ + (ok4_ ? co_ * (cstride_) + (int64_t)gy_ * (wrow_) + gx_ : 0)); \
+    }
+#define LLDWT_WG_FIX4(dst_, raw_, base_, choff_, cstride_, wrow_, iv_)                                           \
     {                                                                                                            \
         const int c_ = (iv_) / (WG_PX / 4), rq_ = (iv_) % (WG_PX / 4);                                           \
         const int gy_ = y0 + rq_ / (WG_TW / 4), gx_ = x0 + 4 * (rq_ % (WG_TW / 4));                              \
         const int co_ = choff_[c_];                                                                              \
         const bool row_ = co_ >= 0 && gy_ < h;                                                                   \
         const bool ok4_ = row_ && gx_ + 3 < w;                                                                   \
-        const int64_t off_ = co_ * (cstride_) + (int64_t)gy_ * (wrow_) + gx_;                                    \
-        const f4u t4_ = *reinterpret_cast<const f4u*>(base_ + (ok4_ ? off_ : 0));                                \
-        dst_ = ok4_ ? floatx4{t4_.x, t4_.y, t4_.z, t4_.w} : floatx4{0.f, 0.f, 0.f, 0.f};                         \
+        dst_ = ok4_ ? floatx4{raw_.x, raw_.y, raw_.z, raw_.w} : floatx4{0.f, 0.f, 0.f, 0.f};                     \
         if (row_ && !ok4_ && gx_ < w) {                                                                          \
+            const int64_t off_ = co_ * (cstride_) + (int64_t)gy_ * (wrow_) + gx_;                                \
             _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_)                                                     \
                 if (gx_ + e_ < w) dst_[e_] = base_[off_ + e_];                                                   \
         }                                                                                                        \
@@ -169,28 +179,33 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
         __syncthreads();
         // stage dY: MT*16 channels x 128 px (zero outside the image / beyond cout_g); all loads of a thread are issued
         // before its first LDS store (a load -> store loop waits vmcnt(0) per element and serialises the latency)
-        {
-            floatx4 v4[NV];
+        f4u ra[NV];
 #pragma unroll
-            for (int r = 0; r < NV; ++r) LLDWT_WG_LOAD4(v4[r], dyz, s_aoff, hw, w, tid + r * 256)
-#pragma unroll
-            for (int r = 0; r < NV; ++r) LLDWT_WG_STORE4(la, WG_PSA, v4[r], tid + r * 256)
+        for (int r = 0; r < NV; ++r) LLDWT_WG_ISSUE4(ra[r], dyz, s_aoff, hw, w, tid + r * 256)
+#define LLDWT_WG_FINISH_A()                                                                                      \
+        _Pragma("unroll") for (int r = 0; r < NV; ++r) {                                                         \
+            floatx4 v4_;                                                                                         \
+            LLDWT_WG_FIX4(v4_, ra[r], dyz, s_aoff, hw, w, tid + r * 256)                                         \
+            LLDWT_WG_STORE4(la, WG_PSA, v4_, tid + r * 256)                                                      \
         }
         if (xvec) {
             // 1x1: nic channels x 128 px, rows of 16 contiguous pixels (PSX = 129: scalar LDS stores)
             for (int i0 = 0; i0 < nic * (WG_PX / 4); i0 += 8 * 256) {
-                floatx4 v4[8];
+                f4u rx[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int iv = i0 + tid + r * 256;
-                    if (iv < nic * (WG_PX / 4)) LLDWT_WG_LOAD4(v4[r], xz, s_xoff, hwi, wi, iv)
+                    LLDWT_WG_ISSUE4(rx[r], xz, s_xoff, hwi, wi, (iv < nic * (WG_PX / 4) ? iv : 0))
                 }
+                if (i0 == 0) { LLDWT_WG_FINISH_A() }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int iv = i0 + tid + r * 256;
                     if (iv < nic * (WG_PX / 4)) {
+                        floatx4 v4_;
+                        LLDWT_WG_FIX4(v4_, rx[r], xz, s_xoff, hwi, wi, iv)
                         float* q_ = lx + (iv / (WG_PX / 4)) * PSX + 4 * (iv % (WG_PX / 4));
-                        q_[0] = v4[r][0]; q_[1] = v4[r][1]; q_[2] = v4[r][2]; q_[3] = v4[r][3];
+                        q_[0] = v4_[0]; q_[1] = v4_[1]; q_[2] = v4_[2]; q_[3] = v4_[3];
                     }
                 }
             }
@@ -200,10 +215,12 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) LLDWT_WG_LOAD_X(v[r], i0 + tid + r * 256)
+                if (i0 == 0) { LLDWT_WG_FINISH_A() }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) LLDWT_WG_STORE_X(v[r], i0 + tid + r * 256)
             }
         }
+#undef LLDWT_WG_FINISH_A
         __syncthreads();
 #pragma unroll 4
         for (int s = 0; s < WG_PX / 4; ++s) {
@@ -287,40 +304,48 @@ __global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
     for (int j = 0; j < K; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     const int bb = col * PSX + wave * IW + kk;
-    floatx4 va[NAV], vx[NXV];
+    f4u ra[NAV], rx[NXV];        // raw prefetched vectors (fixed up at store time)
 
     // row segments of 4 pixels: one dwordx4 load when the segment lies inside the image (safe address + select); segments
     // that straddle the image border (left/right edge tiles only) take the per-pixel path
-#define LLDWT_W16_VEC(dst_, base_, c_, gy_, gx_, live_)                                                          \
+#define LLDWT_W16_ISSUE(raw_, base_, c_, gy_, gx_, live_)                                                        \
+    {                                                                                                            \
+        const bool ok4_ = (live_) && (gy_) >= 0 && (gy_) < h && (gx_) >= 0 && (gx_) + 3 < w;                     \
+        raw_ = *reinterpret_cast<const f4u*>(base_ + (ok4_ ? (c_) * hw + (int64_t)(gy_) * w + (gx_) : 0));       \
+    }
+#define LLDWT_W16_FIX(dst_, raw_, base_, c_, gy_, gx_, live_)                                                    \
     {                                                                                                            \
         const bool row_ = (live_) && (gy_) >= 0 && (gy_) < h;                                                    \
         const bool ok4_ = row_ && (gx_) >= 0 && (gx_) + 3 < w;                                                   \
-        const int64_t off_ = (c_) * hw + (int64_t)(gy_) * w + (gx_);                                             \
-        const f4u t4_ = *reinterpret_cast<const f4u*>(base_ + (ok4_ ? off_ : 0));                                \
-        dst_ = ok4_ ? floatx4{t4_.x, t4_.y, t4_.z, t4_.w} : floatx4{0.f, 0.f, 0.f, 0.f};                         \
+        dst_ = ok4_ ? floatx4{raw_.x, raw_.y, raw_.z, raw_.w} : floatx4{0.f, 0.f, 0.f, 0.f};                     \
         if (row_ && !ok4_ && (gx_) + 3 >= 0 && (gx_) < w) {                                                      \
+            const int64_t off_ = (c_) * hw + (int64_t)(gy_) * w + (gx_);                                         \
             _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                     \
                 if ((gx_) + e_ >= 0 && (gx_) + e_ < w) dst_[e_] = base_[off_ + e_];                              \
         }                                                                                                        \
     }
-#define LLDWT_W16_LOAD(q_)                                                                                       \
-    {                                                                                                            \
+#define LLDWT_W16_COORDS(q_)                                                                                     \
         const int b_ = (q_) / ntile, t_ = (q_) - b_ * ntile;                                                     \
         const int64_t z_ = (int64_t)plane * a.batch + b_;                                                        \
         const float* dyz = a.dy + z_ * 16 * hw;                                                                  \
         const float* xz = a.x + z_ * 16 * hw;                                                                    \
-        const int y0 = (t_ / tiles_x) * WG_TH, x0 = (t_ % tiles_x) * WG_TW;                                      \
+        const int y0 = (t_ / tiles_x) * WG_TH, x0 = (t_ % tiles_x) * WG_TW;
+#define LLDWT_W16_A(i_) const int c = (i_) / (WG_PX / 4), rq = (i_) % (WG_PX / 4);                               \
+                        const int gy = y0 + rq / (WG_TW / 4), gx = x0 + 4 * (rq % (WG_TW / 4));
+#define LLDWT_W16_X(i_) const int c = (i_) / (IH * NVR), rem = (i_) - c * (IH * NVR);                            \
+                        const int gy = y0 - R + rem / NVR, gx = x0 - R + 4 * (rem % NVR);
+#define LLDWT_W16_LOAD(q_)                                                                                       \
+    {                                                                                                            \
+        LLDWT_W16_COORDS(q_)                                                                                     \
         _Pragma("unroll") for (int r = 0; r < NAV; ++r) {                                                        \
             const int i = tid + r * NTH;                                                                         \
-            const int c = i / (WG_PX / 4), rq = i % (WG_PX / 4);                                                 \
-            const int gy = y0 + rq / (WG_TW / 4), gx = x0 + 4 * (rq % (WG_TW / 4));                              \
-            LLDWT_W16_VEC(va[r], dyz, c, gy, gx, i < 16 * WG_PX / 4)                                             \
+            LLDWT_W16_A(i)                                                                                       \
+            LLDWT_W16_ISSUE(ra[r], dyz, c, gy, gx, i < 16 * WG_PX / 4)                                           \
         }                                                                                                        \
         _Pragma("unroll") for (int r = 0; r < NXV; ++r) {                                                        \
             const int i = tid + r * NTH;                                                                         \
-            const int c = i / (IH * NVR), rem = i - c * (IH * NVR);                                              \
-            const int gy = y0 - R + rem / NVR, gx = x0 - R + 4 * (rem % NVR);                                    \
-            LLDWT_W16_VEC(vx[r], xz, c, gy, gx, i < 16 * IH * NVR)                                               \
+            LLDWT_W16_X(i)                                                                                       \
+            LLDWT_W16_ISSUE(rx[r], xz, c, gy, gx, i < 16 * IH * NVR)                                             \
         }                                                                                                        \
     }
 
@@ -328,24 +353,32 @@ __global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
     if (q < total) LLDWT_W16_LOAD(q)
     for (; q < total; q += gridDim.x) {
         __syncthreads();
+        {
+            LLDWT_W16_COORDS(q)
 #pragma unroll
-        for (int r = 0; r < NAV; ++r) {
-            const int i = tid + r * NTH;
-            if (i < 16 * WG_PX / 4) {
-                float2* d2 = reinterpret_cast<float2*>(la + (i / (WG_PX / 4)) * WG_PSA + 4 * (i % (WG_PX / 4)));
-                d2[0] = float2{va[r][0], va[r][1]};
-                d2[1] = float2{va[r][2], va[r][3]};
+            for (int r = 0; r < NAV; ++r) {
+                const int i = tid + r * NTH;
+                LLDWT_W16_A(i)
+                floatx4 v4;
+                LLDWT_W16_FIX(v4, ra[r], dyz, c, gy, gx, i < 16 * WG_PX / 4)
+                if (i < 16 * WG_PX / 4) {
+                    float2* d2 = reinterpret_cast<float2*>(la + c * WG_PSA + 4 * rq);
+                    d2[0] = float2{v4[0], v4[1]};
+                    d2[1] = float2{v4[2], v4[3]};
+                }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < NXV; ++r) {
-            const int i = tid + r * NTH;
-            if (i < 16 * IH * NVR) {
-                const int c = i / (IH * NVR), rem = i - c * (IH * NVR);
-                const int lxx = 4 * (rem % NVR);
-                float2* d2 = reinterpret_cast<float2*>(lx + c * PSX + (rem / NVR) * IW + lxx);
-                if (lxx + 1 < IW) d2[0] = float2{vx[r][0], vx[r][1]};
-                if (lxx + 3 < IW) d2[1] = float2{vx[r][2], vx[r][3]};
+            for (int r = 0; r < NXV; ++r) {
+                const int i = tid + r * NTH;
+                LLDWT_W16_X(i)
+                floatx4 v4;
+                LLDWT_W16_FIX(v4, rx[r], xz, c, gy, gx, i < 16 * IH * NVR)
+                if (i < 16 * IH * NVR) {
+                    const int lxx = 4 * (rem % NVR);
+                    float2* d2 = reinterpret_cast<float2*>(lx + c * PSX + (rem / NVR) * IW + lxx);
+                    if (lxx + 1 < IW) d2[0] = float2{v4[0], v4[1]};
+                    if (lxx + 3 < IW) d2[1] = float2{v4[2], v4[3]};
+                }
             }
         }
         __syncthreads();
@@ -366,6 +399,9 @@ __global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
         }
     }
 #undef LLDWT_W16_LOAD
+#undef LLDWT_W16_COORDS
+#undef LLDWT_W16_A
+#undef LLDWT_W16_X
     // D_tap[row = oc (4*kk + r)][col = ic] -> LDS in dW order, then one coalesced atomic per element: every workgroup of
     // a plane adds to the same 256*KK addresses, and the L2 serialises atomics per cache line -- scattered lanes
     // (stride KK floats) touched 64 lines per instruction and cost more than the GEMM itself.
@@ -426,21 +462,23 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
         boff[j] = tdy * IW + tdx + kk;
     }
     float bsum = 0.f, bsb = 0.f;
-    floatx4 va[NAV];
+    f4u ra[NAV];                 // raw prefetched vectors (fixed up at store time)
     float vb[NB];
 
-#define LLDWT_WT_LOAD(q_)                                                                                        \
-    {                                                                                                            \
+#define LLDWT_WT_COORDS(q_)                                                                                      \
         const int b_ = (q_) / ntile, t_ = (q_) - b_ * ntile;                                                     \
         const int64_t z_ = (int64_t)plane * a.batch + b_;                                                        \
         const float* az = a.a16 + z_ * 16 * hw;                                                                  \
         const float* bz = a.b1 + z_ * hw;                                                                        \
-        const int y0 = (t_ / tiles_x) * WG_TH, x0 = (t_ % tiles_x) * WG_TW;                                      \
+        const int y0 = (t_ / tiles_x) * WG_TH, x0 = (t_ % tiles_x) * WG_TW;
+#define LLDWT_WT_LOAD(q_)                                                                                        \
+    {                                                                                                            \
+        LLDWT_WT_COORDS(q_)                                                                                      \
         _Pragma("unroll") for (int r = 0; r < NAV; ++r) {                                                        \
             const int i = tid + r * 256;                                                                         \
             const int c = i / (WG_PX / 4), rq = i % (WG_PX / 4);                                                 \
             const int gy = y0 + rq / (WG_TW / 4), gx = x0 + 4 * (rq % (WG_TW / 4));                              \
-            LLDWT_W16_VEC(va[r], az, c, gy, gx, true)                                                            \
+            LLDWT_W16_ISSUE(ra[r], az, c, gy, gx, true)                                                          \
         }                                                                                                        \
         _Pragma("unroll") for (int r = 0; r < NB; ++r) {                                                         \
             const int i = tid + r * 256;                                                                         \
@@ -455,12 +493,20 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
     if (q < total) LLDWT_WT_LOAD(q)
     for (; q < total; q += gridDim.x) {
         __syncthreads();
+        {
+            LLDWT_WT_COORDS(q)
+            (void)bz;
 #pragma unroll
-        for (int r = 0; r < NAV; ++r) {
-            const int i = tid + r * 256;
-            float2* d2 = reinterpret_cast<float2*>(la + (i / (WG_PX / 4)) * WG_PSA + 4 * (i % (WG_PX / 4)));
-            d2[0] = float2{va[r][0], va[r][1]};
-            d2[1] = float2{va[r][2], va[r][3]};
+            for (int r = 0; r < NAV; ++r) {
+                const int i = tid + r * 256;
+                const int c = i / (WG_PX / 4), rq = i % (WG_PX / 4);
+                const int gy = y0 + rq / (WG_TW / 4), gx = x0 + 4 * (rq % (WG_TW / 4));
+                floatx4 v4;
+                LLDWT_W16_FIX(v4, ra[r], az, c, gy, gx, true)
+                float2* d2 = reinterpret_cast<float2*>(la + c * WG_PSA + 4 * rq);
+                d2[0] = float2{v4[0], v4[1]};
+                d2[1] = float2{v4[2], v4[3]};
+            }
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
@@ -490,7 +536,9 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
         }
     }
 #undef LLDWT_WT_LOAD
-#undef LLDWT_W16_VEC
+#undef LLDWT_WT_COORDS
+#undef LLDWT_W16_ISSUE
+#undef LLDWT_W16_FIX
     // the 4 waves hold partial tiles over disjoint pixels: sum them in LDS, then one coalesced atomic per element
     float* dwp = a.dw + (int64_t)plane * 16 * KK;
     __syncthreads();

@@ -280,27 +280,212 @@ __device__ __forceinline__ void stage_w16(float* __restrict__ wl, const float* _
     }
 }
 
-// acc[n] += conv over the 16-channel LDS tile t (planes of stride PS, rows of PITCH) for this wave's 8 pixel tiles
+// ---- latency-friendly staging: every global load of a thread is issued before its first LDS store ------------------------
+// (a load -> store loop waits vmcnt(0) per element; the first version of kernel B spent more time in ~24 serialised
+// round trips than in its 800 MFMAs).  Rows come in as dwordx4, the weights as dwordx4 in their final lane order.
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
+template <int K>
+struct Tile16 {
+    static constexpr int R = K / 2, T1H = TH + 2 * R, T1W = TW + 2 * R;
+    static constexpr int NVR = (T1W + 3) / 4;                 // vectors per tile row
+    static constexpr int NV = 16 * T1H * NVR;                 // vectors per 16-channel tile
+    static constexpr int NVT = (NV + NT - 1) / NT;            // per thread
+    static constexpr int NWV = (K * K * 64 + NT - 1) / NT;    // weight vectors per thread (KK*4*64 floats)
+};
+
+// 16-channel tile with halo R of a dense (Z,16,h,w) tensor; zero outside the image.  Two phases so that every load is in
+// flight before anything consumes one: tile16_issue only issues the dwordx4 loads (from a safe address when the vector is
+// not fully inside the image); tile16_fix, called once the other loads of the prologue have been issued too, zeroes the
+// outside vectors and patches the ones that straddle the left / right border pixel by pixel.
+template <int K>
+__device__ __forceinline__ void tile16_issue(f4u (&v)[Tile16<K>::NVT], const float* __restrict__ base, int64_t cs, int y0,
+                                             int x0, int h, int w, int tid) {
+    using G = Tile16<K>;
+#pragma unroll
+    for (int r = 0; r < G::NVT; ++r) {
+        const int i = tid + r * NT;
+        const int c = i / (G::T1H * G::NVR), rem = i - c * (G::T1H * G::NVR);
+        const int gy = y0 - G::R + rem / G::NVR, gx = x0 - G::R + 4 * (rem % G::NVR);
+        const bool ok4 = i < G::NV && gy >= 0 && gy < h && gx >= 0 && gx + 3 < w;
+        // 32-bit element offset from a wave-uniform base (one image's 16 channels fit): SGPR base + VGPR offset addressing,
+        // no 64-bit multiplies per load
+        const unsigned off = ok4 ? (unsigned)(c * (int)cs + gy * w + gx) : 0u;
+        v[r] = *reinterpret_cast<const f4u*>(base + off);
+    }
+}
+template <int K>
+__device__ __forceinline__ void tile16_fix(floatx4 (&o)[Tile16<K>::NVT], const f4u (&v)[Tile16<K>::NVT],
+                                           const float* __restrict__ base, int64_t cs, int y0, int x0, int h, int w, int tid) {
+    using G = Tile16<K>;
+#pragma unroll
+    for (int r = 0; r < G::NVT; ++r) {
+        const int i = tid + r * NT;
+        const int c = i / (G::T1H * G::NVR), rem = i - c * (G::T1H * G::NVR);
+        const int gy = y0 - G::R + rem / G::NVR, gx = x0 - G::R + 4 * (rem % G::NVR);
+        const bool row = i < G::NV && gy >= 0 && gy < h;
+        const bool ok4 = row && gx >= 0 && gx + 3 < w;
+        o[r] = ok4 ? floatx4{v[r].x, v[r].y, v[r].z, v[r].w} : floatx4{0.f, 0.f, 0.f, 0.f};
+        if (row && !ok4 && gx + 3 >= 0 && gx < w) {           // vector straddles the left / right image border
+            const int off = c * (int)cs + gy * w + gx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (gx + e >= 0 && gx + e < w) o[r][e] = base[off + e];
+        }
+    }
+}
+#define LLDWT_TILE16(K_, tv_, base_, cs_, y0_, x0_, h_, w_, tid_)  /* declare + issue; LLDWT_TILE16_FIX completes */ \
+    f4u tv_##_raw[Tile16<K_>::NVT];                                                                               \
+    floatx4 tv_[Tile16<K_>::NVT];                                                                                 \
+    tile16_issue<K_>(tv_##_raw, base_, cs_, y0_, x0_, h_, w_, tid_);
+#define LLDWT_TILE16_FIX(K_, tv_, base_, cs_, y0_, x0_, h_, w_, tid_) \
+    tile16_fix<K_>(tv_, tv_##_raw, base_, cs_, y0_, x0_, h_, w_, tid_);
+
+// -> LDS planes of stride PS, rows of PITCH floats
+template <int K, int PS, int PITCH>
+__device__ __forceinline__ void tile16_store(float* __restrict__ t, const floatx4 (&v)[Tile16<K>::NVT], int tid) {
+    using G = Tile16<K>;
+#pragma unroll
+    for (int r = 0; r < G::NVT; ++r) {
+        const int i = tid + r * NT;
+        if (i < G::NV) {
+            const int c = i / (G::T1H * G::NVR), rem = i - c * (G::T1H * G::NVR);
+            const int lx = 4 * (rem % G::NVR);
+            float* d = t + c * PS + (rem / G::NVR) * PITCH + lx;
+            if constexpr (PS % 2 == 0 && PITCH % 2 == 0) {
+                if (lx + 1 < G::T1W) *reinterpret_cast<float2*>(d) = float2{v[r][0], v[r][1]};
+                if (lx + 3 < G::T1W) *reinterpret_cast<float2*>(d + 2) = float2{v[r][2], v[r][3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (lx + e < G::T1W) d[e] = v[r][e];
+            }
+        }
+    }
+}
+
+// fix + store fused per vector (keeps only the raw registers live across the call)
+template <int K, int PS, int PITCH>
+__device__ __forceinline__ void tile16_fix_store(float* __restrict__ t, const f4u (&v)[Tile16<K>::NVT],
+                                                 const float* __restrict__ base, int64_t cs, int y0, int x0, int h, int w,
+                                                 int tid) {
+    using G = Tile16<K>;
+#pragma unroll
+    for (int r = 0; r < G::NVT; ++r) {
+        const int i = tid + r * NT;
+        const int c = i / (G::T1H * G::NVR), rem = i - c * (G::T1H * G::NVR);
+        const int lx = 4 * (rem % G::NVR);
+        const int gy = y0 - G::R + rem / G::NVR, gx = x0 - G::R + lx;
+        const bool row = i < G::NV && gy >= 0 && gy < h;
+        const bool ok4 = row && gx >= 0 && gx + 3 < w;
+        floatx4 o = ok4 ? floatx4{v[r].x, v[r].y, v[r].z, v[r].w} : floatx4{0.f, 0.f, 0.f, 0.f};
+        if (row && !ok4 && gx + 3 >= 0 && gx < w) {
+            const int off = c * (int)cs + gy * w + gx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (gx + e >= 0 && gx + e < w) o[e] = base[off + e];
+        }
+        if (i < G::NV) {
+            float* d = t + c * PS + (rem / G::NVR) * PITCH + lx;
+            if constexpr (PS % 2 == 0 && PITCH % 2 == 0) {
+                if (lx + 1 < G::T1W) *reinterpret_cast<float2*>(d) = float2{o[0], o[1]};
+                if (lx + 3 < G::T1W) *reinterpret_cast<float2*>(d + 2) = float2{o[2], o[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (lx + e < G::T1W) d[e] = o[e];
+            }
+        }
+    }
+}
+
+// 16 -> 16 weights: Wp = forward pack [ic][tap][oc]; wl[(tap*4 + s)*64 + kk*16 + oc], ic = 4s + kk (4 oc per vector)
+template <int K>
+__device__ __forceinline__ void w16_load(floatx4 (&wv)[Tile16<K>::NWV], const float* __restrict__ Wp, int tid) {
+    constexpr int KK = K * K;
+#pragma unroll
+    for (int r = 0; r < Tile16<K>::NWV; ++r) {
+        const int i = tid + r * NT;
+        const int oc4 = i & 3, kk = (i >> 2) & 3, s = (i >> 4) & 3, tap = i >> 6;
+        const float4 q = *reinterpret_cast<const float4*>(Wp + (i < KK * 64 ? ((4 * s + kk) * KK + tap) * 16 + 4 * oc4 : 0));
+        wv[r] = floatx4{q.x, q.y, q.z, q.w};
+    }
+}
+template <int K>
+__device__ __forceinline__ void w16_store(float* __restrict__ wl, const floatx4 (&wv)[Tile16<K>::NWV], int tid) {
+#pragma unroll
+    for (int r = 0; r < Tile16<K>::NWV; ++r) {
+        const int i = tid + r * NT;
+        if (i < K * K * 64) *reinterpret_cast<floatx4*>(wl + 4 * i) = wv[r];        // 4*i == (tap*4+s)*64 + kk*16 + 4*oc4
+    }
+}
+// transposed + mirrored (backward-data): wl[(tap'*4 + s)*64 + kk*16 + oc'] = W[oc = 4s+kk][ic = oc'][KK-1-tap']
+// (4 kk per vector: the source run over the forward oc)
+template <int K>
+__device__ __forceinline__ void w16T_load(floatx4 (&wv)[Tile16<K>::NWV], const float* __restrict__ Wp, int tid) {
+    constexpr int KK = K * K;
+#pragma unroll
+    for (int r = 0; r < Tile16<K>::NWV; ++r) {
+        const int i = tid + r * NT;
+        const int oc = i & 15, s = (i >> 4) & 3, tap = i >> 6;
+        const float4 q = *reinterpret_cast<const float4*>(Wp + (i < KK * 64 ? (oc * KK + (KK - 1 - tap)) * 16 + 4 * s : 0));
+        wv[r] = floatx4{q.x, q.y, q.z, q.w};
+    }
+}
+template <int K>
+__device__ __forceinline__ void w16T_store(float* __restrict__ wl, const floatx4 (&wv)[Tile16<K>::NWV], int tid) {
+#pragma unroll
+    for (int r = 0; r < Tile16<K>::NWV; ++r) {
+        const int i = tid + r * NT;
+        if (i < K * K * 64) {
+            const int oc = i & 15, s = (i >> 4) & 3, tap = i >> 6;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wl[(tap * 4 + s) * 64 + kk * 16 + oc] = wv[r][kk];
+        }
+    }
+}
+
+// acc[n] += conv over the 16-channel LDS tile t (planes of stride PS, rows of PITCH) for this wave's 8 pixel tiles.
+// Software-pipelined like the conv engine: the 9 LDS operands of k-step i+1 are requested before the 8 MFMAs of k-step i
+// are issued (sched_barrier keeps hipcc from sinking the reads back next to their use).  Measured alone on a CU, the
+// unpipelined loop ran at 47 cycles per MFMA instead of 32.
 template <int K, int PS, int PITCH>
 __device__ __forceinline__ void conv16_mfma_ps(const float* __restrict__ t, const float* __restrict__ wl, int wave,
                                                int lane, floatx4 (&acc)[8]) {
     const int px = lane & 15, kk = lane >> 4;
     const float* tb = t + kk * PS + (wave * 4) * PITCH + px;
     const float* wa = wl + lane;
+    constexpr int NS = K * 4;                       // k-steps per kernel row: (dx, s)
+#define LLDWT_C16_FETCH(A_, B_, i_)                                                                              \
+    {                                                                                                            \
+        const int dx_ = (i_) / 4, s_ = (i_) % 4;                                                                 \
+        A_ = wrow[(dx_ * 4 + s_) * 64];                                                                          \
+        _Pragma("unroll") for (int n = 0; n < 8; ++n)                                                            \
+            B_[n] = trow[(4 * s_) * PS + (n >> 1) * PITCH + (n & 1) * 16 + dx_];                                 \
+    }
+    __builtin_amdgcn_s_setprio(1);      // the matrix section outranks the co-resident workgroup's staging / epilogue VALU
+#pragma unroll 1
+    for (int dy = 0; dy < K; ++dy) {
+        const float* wrow = wa + dy * K * 4 * 64;
+        const float* trow = tb + dy * PITCH;
+        float A0, A1, B0[8], B1[8];
+        LLDWT_C16_FETCH(A0, B0, 0)
 #pragma unroll
-    for (int dy = 0; dy < K; ++dy)
+        for (int i = 0; i < NS; i += 2) {
+            LLDWT_C16_FETCH(A1, B1, i + 1)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dx = 0; dx < K; ++dx) {
+            for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B0[n], acc[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 2 < NS) LLDWT_C16_FETCH(A0, B0, i + 2)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float A = wa[((dy * K + dx) * 4 + s) * 64];
-                float B[8];
-#pragma unroll
-                for (int n = 0; n < 8; ++n) B[n] = tb[(4 * s) * PS + ((n >> 1) + dy) * PITCH + (n & 1) * 16 + dx];
-#pragma unroll
-                for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B[n], acc[n], 0, 0, 0);
-            }
+            for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B1[n], acc[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    __builtin_amdgcn_s_setprio(0);
+#undef LLDWT_C16_FETCH
 }
 
 // conv1 (1 -> 16) as a GEMM with K = taps (padded to a multiple of 4): B gathered from the single-channel skip tile
@@ -345,9 +530,9 @@ __global__ __launch_bounds__(NT) void k_lift_a_mfma(CView src, float* __restrict
     constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;      // 20 x 36 for K = 5: plane stride 720 == 16 (mod 32)
     constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s_lds = lds;                                    // [SH][SW+1]
-    float* t1 = s_lds + SH * (SW + 1);                     // [C] planes of stride T1PS, rows of T1W
+    float* t1 = lds;                                       // [C] planes of stride T1PS, rows of T1W (16-byte aligned)
     float* wl = t1 + C * T1PS;                             // [KK][4][64]
+    float* s_lds = wl + KK * 4 * 64;                       // [SH][SW+1]
     const PackOff o = pack_off(C, K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t z = blockIdx.z;
@@ -356,23 +541,42 @@ __global__ __launch_bounds__(NT) void k_lift_a_mfma(CView src, float* __restrict
     const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
     const float tp0 = taps[plane * 3 + 0], tp1 = taps[plane * 3 + 1], tp2 = taps[plane * 3 + 2];
     const int act = linear ? LLDWT_ACT_NONE : LLDWT_ACT_TANH;
-    stage_w16<K>(wl, pk + o.w2, tid);
-    for (int i = tid; i < SH * SW; i += NT) {
-        const int ly = i / SW, lx = i - ly * SW;
-        const int gy = y0 - R2 + ly, gx = x0 - R2 + lx;
-        float v = 0.f;
-        if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
-            const int ddy = vertical ? 1 : 0, ddx = vertical ? 0 : 1;
-            const float a = ld_view(src, z, gy - ddy, gx - ddx, h, w);
-            const float b = ld_view(src, z, gy, gx, h, w);
-            const float c = ld_view(src, z, gy + ddy, gx + ddx, h, w);
-            v = tp0 * a + tp1 * b + tp2 * c;
-            if (ly >= R2 && ly < R2 + TH && lx >= R2 && lx < R2 + TW) {
-                skip_out[(z * h + gy) * (int64_t)w + gx] = v;
-                if (src_out) src_out[(z * h + gy) * (int64_t)w + gx] = b;
+    {
+        // all global loads first (conv2 weights + the three skip-filter taps of every patch pixel), then the LDS stores
+        floatx4 wv[Tile16<K>::NWV];
+        constexpr int NS = (SH * SW + NT - 1) / NT;
+        float va[NS], vb[NS], vc[NS];
+        w16_load<K>(wv, pk + o.w2, tid);
+        const int ddy = vertical ? 1 : 0, ddx = vertical ? 0 : 1;
+        const float* sp = src.p + z * src.sz;
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            const int i = tid + r * NT;
+            const int ly = i / SW, lx = i - ly * SW;
+            const int gy = y0 - R2 + ly, gx = x0 - R2 + lx;
+            const bool in = i < SH * SW && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            const bool ina = in && gy - ddy >= 0 && gx - ddx >= 0, inc = in && gy + ddy < h && gx + ddx < w;
+            const int64_t off = (int64_t)gy * src.sy + (int64_t)gx * src.sx;
+            const int64_t step = (int64_t)ddy * src.sy + (int64_t)ddx * src.sx;
+            const float qa = sp[ina ? off - step : 0], qb = sp[in ? off : 0], qc = sp[inc ? off + step : 0];
+            va[r] = ina ? qa : 0.f; vb[r] = in ? qb : 0.f; vc[r] = inc ? qc : 0.f;
+        }
+        w16_store<K>(wl, wv, tid);
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            const int i = tid + r * NT;
+            if (i < SH * SW) {
+                const int ly = i / SW, lx = i - ly * SW;
+                const int gy = y0 - R2 + ly, gx = x0 - R2 + lx;
+                const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+                const float v = in ? tp0 * va[r] + tp1 * vb[r] + tp2 * vc[r] : 0.f;
+                if (in && ly >= R2 && ly < R2 + TH && lx >= R2 && lx < R2 + TW) {
+                    skip_out[(z * h + gy) * (int64_t)w + gx] = v;
+                    if (src_out) src_out[(z * h + gy) * (int64_t)w + gx] = vb[r];
+                }
+                s_lds[ly * (SW + 1) + lx] = v;
             }
         }
-        s_lds[ly * (SW + 1) + lx] = v;
     }
     __syncthreads();
     // conv1 (1 -> 16) + act on the (TH+2R)x(TW+2R) region (VALU: 6 % of the step's MACs); zero outside the image
@@ -424,56 +628,114 @@ __global__ __launch_bounds__(NT) void k_lift_a_mfma(CView src, float* __restrict
     (void)KK;
 }
 
+// Persistent over the tiles of one plane (grid = (workgroups, 1, planes)): the weights are staged once, and the loads of
+// tile i+1 are in flight while the matrix cores work on tile i.  (One workgroup per tile left the memory phase exposed:
+// the two workgroups of a CU start together and stay in lockstep -- measured 50 % MFMA-busy.)
 template <int K>
-__global__ __launch_bounds__(NT) void k_lift_b_mfma(const float* __restrict__ skip, const float* __restrict__ t2,
+__global__ __launch_bounds__(NT, 2) void k_lift_b_mfma(const float* __restrict__ skip, const float* __restrict__ t2,
                                                     float* __restrict__ t3_out, int batch, int h, int w,
                                                     const float* __restrict__ packed, int64_t packed_plane_stride,
                                                     int vertical) {
     constexpr int C = 16, R = K / 2, KK = K * K, KS4 = (KK + 3) / 4;
     constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;
     constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
+    constexpr int NSK = (T1H * T1W + NT - 1) / NT, NW1 = (KS4 * 64 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s_lds = lds;                                    // [T1H][T1W+1]
-    float* t = s_lds + T1H * (T1W + 1);                    // [C] planes
+    float* t = lds;                                        // [C] planes (16-byte aligned: vector stores)
     float* wl = t + C * T1PS;                              // conv3 weights [KK][4][64]
     float* w1l = wl + KK * 4 * 64;                         // conv1 weights [KS4][64]
+    float* s_lds = w1l + KS4 * 64;                         // [T1H][T1W+1]
     const PackOff o = pack_off(C, K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t z = blockIdx.z;
-    const int plane = (int)(z / batch);
-    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const int plane = blockIdx.z;
     const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
     const int64_t cs = (int64_t)h * w;
-    stage_w16<K>(wl, pk + o.w3, tid);
-    stage_w1<K>(w1l, pk + o.w1, tid);
-    for (int i = tid; i < T1H * T1W; i += NT) {
-        const int ly = i / T1W, lx = i - ly * T1W;
-        const int gy = y0 - R + ly, gx = x0 - R + lx;
-        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-        const int64_t off = (int64_t)gy * w + gx;
-        s_lds[ly * (T1W + 1) + lx] = in ? skip[z * cs + off] : 0.f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) t[c * T1PS + ly * T1W + lx] = in ? t2[(z * C + c) * cs + off] : 0.f;
+    const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+    const int per_img = tiles_x * tiles_y, ntiles = batch * per_img;
+    f4u raw[Tile16<K>::NVT];
+    float sk[NSK];
+
+#define LLDWT_LB_COORDS(i_)                                                                                      \
+    const int b_ = (i_) / per_img, r_ = (i_) - b_ * per_img;                                                     \
+    const int64_t z = (int64_t)plane * batch + b_;                                                               \
+    const int y0 = (r_ / tiles_x) * TH, x0 = (r_ % tiles_x) * TW;
+#define LLDWT_LB_ISSUE(i_)                                                                                       \
+    {                                                                                                            \
+        LLDWT_LB_COORDS(i_)                                                                                      \
+        tile16_issue<K>(raw, t2 + (z * C) * cs, cs, y0, x0, h, w, tid);                                          \
+        _Pragma("unroll") for (int r = 0; r < NSK; ++r) {                                                        \
+            const int i = tid + r * NT;                                                                          \
+            const int ly = i / T1W, lx = i - ly * T1W;                                                           \
+            const int gy = y0 - R + ly, gx = x0 - R + lx;                                                        \
+            const bool in = i < T1H * T1W && gy >= 0 && gy < h && gx >= 0 && gx < w;                             \
+            sk[r] = (skip + z * cs)[in ? (unsigned)(gy * w + gx) : 0u];                                          \
+        }                                                                                                        \
     }
-    __syncthreads();
-    floatx4 acc[8];
+
+    int it = blockIdx.x;
+    {
+        // weights once per workgroup; the first tile's loads are issued with them (one round trip)
+        floatx4 wv[Tile16<K>::NWV];
+        float w1v[NW1];
+        w16_load<K>(wv, pk + o.w3, tid);
 #pragma unroll
-    for (int n = 0; n < 8; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
-    conv1_mfma<K, T1W + 1>(s_lds, w1l, wave, lane, 0, 0, acc);          // residual r = conv1(skip), pre-activation
-    conv16_mfma_ps<K, T1PS, T1W>(t, wl, wave, lane, acc);               // + conv3(t2)
-    const int px = lane & 15, kk = lane >> 4;
+        for (int r = 0; r < NW1; ++r) {
+            const int i = tid + r * NT;
+            const int tap = 4 * (i >> 6) + ((i & 63) >> 4);
+            const bool ok = i < KS4 * 64 && tap < KK;
+            const float tq = pk[o.w1 + (ok ? tap * 16 + (i & 15) : 0)];
+            w1v[r] = ok ? tq : 0.f;
+        }
+        if (it < ntiles) LLDWT_LB_ISSUE(it)
+        w16_store<K>(wl, wv, tid);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int oc = 4 * kk + r;
-        const float bv = pk[o.b3 + oc] + pk[o.b1 + oc];
-        float* op = t3_out + (z * C + oc) * cs;
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
-            if (gy < h && gx < w) op[(int64_t)gy * w + gx] = acc[n][r] + bv;
+        for (int r = 0; r < NW1; ++r) {
+            const int i = tid + r * NT;
+            if (i < KS4 * 64) w1l[i] = w1v[r];
         }
     }
-    (void)KS4;
+    const int px = lane & 15, kk = lane >> 4;
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = pk[o.b3 + 4 * kk + r] + pk[o.b1 + 4 * kk + r];
+    for (; it < ntiles; it += gridDim.x) {
+        LLDWT_LB_COORDS(it)
+        __syncthreads();                                   // the previous tile's LDS reads are done
+        {
+            tile16_fix_store<K, T1PS, T1W>(t, raw, t2 + (z * C) * cs, cs, y0, x0, h, w, tid);
+#pragma unroll
+            for (int r = 0; r < NSK; ++r) {
+                const int i = tid + r * NT;
+                if (i < T1H * T1W) {
+                    const int ly = i / T1W, lx = i - ly * T1W;
+                    const int gy = y0 - R + ly, gx = x0 - R + lx;
+                    s_lds[ly * (T1W + 1) + lx] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? sk[r] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (it + (int)gridDim.x < ntiles) LLDWT_LB_ISSUE(it + (int)gridDim.x)     // in flight during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        floatx4 acc[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+        conv1_mfma<K, T1W + 1>(s_lds, w1l, wave, lane, 0, 0, acc);          // residual r = conv1(skip), pre-activation
+        conv16_mfma_ps<K, T1PS, T1W>(t, wl, wave, lane, acc);               // + conv3(t2)
+        __builtin_amdgcn_sched_barrier(0);        // keep the epilogue's address arithmetic out of the MFMA section
+        {
+            float* op = t3_out + (z * C) * cs;                                  // wave-uniform; 32-bit offsets below
+            const int e0 = 4 * kk * (int)cs + (y0 + wave * 4) * w + x0 + px;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
+                    if (gy < h && gx < w) op[(unsigned)(e0 + r * (int)cs + (n >> 1) * w + (n & 1) * 16)] = acc[n][r] + bv[r];
+                }
+        }
+    }
+#undef LLDWT_LB_COORDS
+#undef LLDWT_LB_ISSUE
 }
 
 // ---- kernel C: conv4(t3) ; dst_out = dst_in + sign*(skip + rw*net) -------------------------------------------
@@ -492,13 +754,19 @@ __global__ __launch_bounds__(NT) void k_lift_c(const float* __restrict__ skip, c
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
     const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
     const int64_t cs = (int64_t)h * w;
-    for (int i = tid; i < T1H * T1W; i += NT) {
-        const int ly = i / T1W, lx = i - ly * T1W;
-        const int gy = y0 - R + ly, gx = x0 - R + lx;
-        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-        const int64_t off = (int64_t)gy * w + gx;
+    if constexpr (C == 16) {
+        LLDWT_TILE16(K, tv, t3 + (z * C) * cs, cs, y0, x0, h, w, tid)
+        LLDWT_TILE16_FIX(K, tv, t3 + (z * C) * cs, cs, y0, x0, h, w, tid)
+        tile16_store<K, T1H * T1P, T1P>(&t[0][0][0], tv, tid);
+    } else {
+        for (int i = tid; i < T1H * T1W; i += NT) {
+            const int ly = i / T1W, lx = i - ly * T1W;
+            const int gy = y0 - R + ly, gx = x0 - R + lx;
+            const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+            const int64_t off = (int64_t)gy * w + gx;
 #pragma unroll
-        for (int c = 0; c < C; ++c) t[c][ly][lx] = in ? t3[(z * C + c) * cs + off] : 0.f;
+            for (int c = 0; c < C; ++c) t[c][ly][lx] = in ? t3[(z * C + c) * cs + off] : 0.f;
+        }
     }
     __syncthreads();
     const int ly = tid / TW, lx = tid % TW;
@@ -630,9 +898,9 @@ __global__ __launch_bounds__(NT) void k_lift_bwd_c_mfma(CView gout, lldwt_view g
     constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;
     constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s_lds = lds;                                    // [SH][SW+1] gradient patch
-    float* t1 = s_lds + SH * (SW + 1);                     // [C] planes of dt3
+    float* t1 = lds;                                       // [C] planes of dt3 (16-byte aligned)
     float* wl = t1 + C * T1PS;                             // conv3^T weights [KK][4][64]
+    float* s_lds = wl + KK * 4 * 64;                       // [SH][SW+1] gradient patch
     const PackOff o = pack_off(C, K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t z = blockIdx.z;
@@ -640,18 +908,35 @@ __global__ __launch_bounds__(NT) void k_lift_bwd_c_mfma(CView gout, lldwt_view g
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
     const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
     const int64_t cs = (int64_t)h * w;
-    stage_w16T<K>(wl, pk + o.w3, tid);
-    for (int i = tid; i < SH * SW; i += NT) {
-        const int ly = i / SW, lx = i - ly * SW;
-        const int gy = y0 - R2 + ly, gx = x0 - R2 + lx;
-        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-        const float t = gout.p[in ? z * gout.sz + (int64_t)gy * gout.sy + (int64_t)gx * gout.sx : 0];
-        const float v = in ? t : 0.f;
-        if (in && ly >= R2 && ly < R2 + TH && lx >= R2 && lx < R2 + TW) {
-            g_out[z * cs + (int64_t)gy * w + gx] = v;
-            gdin.p[z * gdin.sz + (int64_t)gy * gdin.sy + (int64_t)gx * gdin.sx] = v;   // the step passes dst through
+    {
+        floatx4 wv[Tile16<K>::NWV];
+        constexpr int NS = (SH * SW + NT - 1) / NT;
+        float gv[NS];
+        w16T_load<K>(wv, pk + o.w3, tid);
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            const int i = tid + r * NT;
+            const int ly = i / SW, lx = i - ly * SW;
+            const int gy = y0 - R2 + ly, gx = x0 - R2 + lx;
+            const bool in = i < SH * SW && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            const float tq = gout.p[in ? z * gout.sz + (int64_t)gy * gout.sy + (int64_t)gx * gout.sx : 0];
+            gv[r] = in ? tq : 0.f;
         }
-        s_lds[ly * (SW + 1) + lx] = v;
+        w16T_store<K>(wl, wv, tid);
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            const int i = tid + r * NT;
+            if (i < SH * SW) {
+                const int ly = i / SW, lx = i - ly * SW;
+                const int gy = y0 - R2 + ly, gx = x0 - R2 + lx;
+                const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+                if (in && ly >= R2 && ly < R2 + TH && lx >= R2 && lx < R2 + TW) {
+                    g_out[z * cs + (int64_t)gy * w + gx] = gv[r];
+                    gdin.p[z * gdin.sz + (int64_t)gy * gdin.sy + (int64_t)gx * gdin.sx] = gv[r];   // the step passes dst through
+                }
+                s_lds[ly * (SW + 1) + lx] = gv[r];
+            }
+        }
     }
     __syncthreads();
     // dt3 = conv4^T(g) on the (TH+2R)x(TW+2R) region; zero outside the image
@@ -709,7 +994,6 @@ __global__ __launch_bounds__(NT) void k_lift_bwd_b_mfma(const float* __restrict_
     constexpr int C = 16, R = K / 2, KK = K * K;
     constexpr int T1H = TH + 2 * R, T1W = TW + 2 * R;
     constexpr int T1PS = ((T1H * T1W + 15) / 32) * 32 + 16;
-    constexpr int NL = (T1H * T1W + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* t = lds;                                        // [C] planes of dpre2
     float* wl = t + C * T1PS;                              // conv2^T weights
@@ -720,21 +1004,13 @@ __global__ __launch_bounds__(NT) void k_lift_bwd_b_mfma(const float* __restrict_
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
     const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
     const int64_t cs = (int64_t)h * w;
-    stage_w16T<K>(wl, pk + o.w2, tid);
-#pragma unroll
-    for (int r = 0; r < NL; ++r) {
-        const int i = tid + r * NT;
-        const int ly = i / T1W, lx = i - ly * T1W;
-        const int gy = y0 - R + ly, gx = x0 - R + lx;
-        const bool in = i < T1H * T1W && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        const int64_t off = in ? (z * C) * cs + (int64_t)gy * w + gx : 0;
-        float v[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) v[c] = dpre2[off + c * cs];            // safe address + select: no branches
-        if (i < T1H * T1W) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) t[c * T1PS + ly * T1W + lx] = in ? v[c] : 0.f;
-        }
+    {
+        floatx4 wv[Tile16<K>::NWV];
+        w16T_load<K>(wv, pk + o.w2, tid);
+        LLDWT_TILE16(K, tv, dpre2 + (z * C) * cs, cs, y0, x0, h, w, tid)
+        w16T_store<K>(wl, wv, tid);
+        LLDWT_TILE16_FIX(K, tv, dpre2 + (z * C) * cs, cs, y0, x0, h, w, tid)
+        tile16_store<K, T1PS, T1W>(t, tv, tid);
     }
     __syncthreads();
     floatx4 acc[8];
@@ -774,19 +1050,25 @@ __global__ __launch_bounds__(NT) void k_lift_bwd_a(const float* __restrict__ dr,
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
     const float* pk = packed + plane * packed_plane_stride + (vertical ? 0 : o.orient);
     const int64_t cs = (int64_t)h * w;
+    if constexpr (C == 16) {
+        LLDWT_TILE16(K, tv, dr + (z * C) * cs, cs, y0, x0, h, w, tid)
+        LLDWT_TILE16_FIX(K, tv, dr + (z * C) * cs, cs, y0, x0, h, w, tid)
+        tile16_store<K, T1H * T1P, T1P>(&t[0][0][0], tv, tid);
+    } else {
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
-        const int i = tid + r * NT;
-        const int ly = i / T1W, lx = i - ly * T1W;
-        const int gy = y0 - R + ly, gx = x0 - R + lx;
-        const bool in = i < T1H * T1W && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        const int64_t off = in ? (z * C) * cs + (int64_t)gy * w + gx : 0;
-        float v[C];
+        for (int r = 0; r < NL; ++r) {
+            const int i = tid + r * NT;
+            const int ly = i / T1W, lx = i - ly * T1W;
+            const int gy = y0 - R + ly, gx = x0 - R + lx;
+            const bool in = i < T1H * T1W && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            const int64_t off = in ? (z * C) * cs + (int64_t)gy * w + gx : 0;
+            float v[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) v[c] = dr[off + c * cs];
-        if (i < T1H * T1W) {
+            for (int c = 0; c < C; ++c) v[c] = dr[off + c * cs];
+            if (i < T1H * T1W) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) t[c][ly][lx] = in ? v[c] : 0.f;
+                for (int c = 0; c < C; ++c) t[c][ly][lx] = in ? v[c] : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -838,8 +1120,14 @@ static int launch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, in
         }
         hipLaunchKernelGGL((k_lift_a_mfma<K>), grid, block, sh_a, st, cv(src), b.skip, b.t2, b.t1, b.srcv, (int)batch,
                            (int)h, (int)w, taps, packed, pstride, vertical, linear);
-        hipLaunchKernelGGL((k_lift_b_mfma<K>), grid, block, sh_b, st, b.skip, b.t2, b.t3, (int)batch, (int)h, (int)w,
-                           packed, pstride, vertical);
+        {
+            const int64_t planes_ = Z / batch, per_plane = batch * cdiv(w, TW) * cdiv(h, TH);
+            int64_t wg = (int64_t)lldwt_num_cus() * 2 / planes_;             // 2 workgroups per CU (LDS), one resident round
+            if (wg > per_plane) wg = per_plane;
+            if (wg < 1) wg = 1;
+            hipLaunchKernelGGL((k_lift_b_mfma<K>), dim3((unsigned)wg, 1, (unsigned)planes_), block, sh_b, st, b.skip, b.t2,
+                               b.t3, (int)batch, (int)h, (int)w, packed, pstride, vertical);
+        }
     } else {
         hipLaunchKernelGGL((k_lift_a<C, K>), grid, block, 0, st, cv(src), b.skip, b.t2, b.t1, b.srcv, (int)batch, (int)h,
                            (int)w, taps, packed, pstride, vertical, linear);
