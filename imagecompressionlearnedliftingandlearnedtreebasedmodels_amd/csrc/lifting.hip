@@ -446,6 +446,9 @@ __device__ __forceinline__ void w16T_store(float* __restrict__ wl, const floatx4
 }
 
 // acc[n] += conv over the 16-channel LDS tile t (planes of stride PS, rows of PITCH) for this wave's 8 pixel tiles.
+// The PIXELS are the MFMA's A operand (rows) and the weights its B operand (columns): D[row = pixel][col = oc], so a lane
+// ends up with 4 consecutive pixels (4*kk .. 4*kk+3 of the tile's 16) of ONE channel (oc = lane & 15) -- the epilogues
+// read and write 16 bytes per lane instead of 4 scalars in 4 different channel planes.
 // Software-pipelined like the conv engine: the 9 LDS operands of k-step i+1 are requested before the 8 MFMAs of k-step i
 // are issued (sched_barrier keeps hipcc from sinking the reads back next to their use).  Measured alone on a CU, the
 // unpipelined loop ran at 47 cycles per MFMA instead of 32.
@@ -475,12 +478,12 @@ __device__ __forceinline__ void conv16_mfma_ps(const float* __restrict__ t, cons
             LLDWT_C16_FETCH(A1, B1, i + 1)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B0[n], acc[n], 0, 0, 0);
+            for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(B0[n], A0, acc[n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (i + 2 < NS) LLDWT_C16_FETCH(A0, B0, i + 2)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B1[n], acc[n], 0, 0, 0);
+            for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(B1[n], A1, acc[n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -504,7 +507,7 @@ __device__ __forceinline__ void conv1_mfma(const float* __restrict__ sl, const f
         for (int n = 0; n < 8; ++n)
             B[n] = sl[(row_off + wave * 4 + (n >> 1) + dy) * SPITCH + col_off + (n & 1) * 16 + px + dx];
 #pragma unroll
-        for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B[n], acc[n], 0, 0, 0);
+        for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[n], A, acc[n], 0, 0, 0);
     }
 }
 
@@ -516,6 +519,32 @@ __device__ __forceinline__ void stage_w1(float* __restrict__ w1l, const float* _
         const int l = i & 63, s = i >> 6;
         const int tap = 4 * s + (l >> 4);
         w1l[i] = tap < KK ? W1p[tap * 16 + (l & 15)] : 0.f;
+    }
+}
+
+// epilogue addressing of the layout above: tile n of wave `wave` is row wave*4 + n/2, columns (n&1)*16 + 4*kk .. +3
+#define LLDWT_EPI_FOR(n_, gy_, gx_)                                                                              \
+    _Pragma("unroll") for (int n_ = 0; n_ < 8; ++n_)                                                             \
+        if (const int gy_ = y0 + wave * 4 + (n_ >> 1); gy_ < h)                                                  \
+            if (const int gx_ = x0 + (n_ & 1) * 16 + 4 * kk; gx_ < w)
+__device__ __forceinline__ floatx4 ld4_edge(const float* __restrict__ p, int gx, int w) {
+    if (gx + 3 < w) {
+        const f4u q = *reinterpret_cast<const f4u*>(p);
+        return floatx4{q.x, q.y, q.z, q.w};
+    }
+    floatx4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+        if (gx + e < w) v[e] = p[e];
+    return v;
+}
+__device__ __forceinline__ void st4_edge(float* __restrict__ p, floatx4 v, int gx, int w) {
+    if (gx + 3 < w) {
+        *reinterpret_cast<f4u*>(p) = f4u{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (gx + e < w) p[e] = v[e];
     }
 }
 
@@ -611,19 +640,16 @@ __global__ __launch_bounds__(NT) void k_lift_a_mfma(CView src, float* __restrict
 #pragma unroll
     for (int n = 0; n < 8; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
     conv16_mfma_ps<K, T1PS, T1W>(t1, wl, wave, lane, acc);
-    // epilogue: lane holds channels 4*kk + r of pixel px of its 8 pixel tiles
-    const int px = lane & 15, kk = lane >> 4;
+    // epilogue: lane holds 4 consecutive pixels of channel lane & 15 in each of its 8 pixel tiles
+    const int oc = lane & 15, kk = lane >> 4;
     const int64_t cs = (int64_t)h * w;
+    const float bv = pk[o.b2 + oc];
+    float* op = t2_out + (z * C + oc) * cs;
+    LLDWT_EPI_FOR(n, gy, gx) {
+        floatx4 v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int oc = 4 * kk + r;
-        const float bv = pk[o.b2 + oc];
-        float* op = t2_out + (z * C + oc) * cs;
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
-            if (gy < h && gx < w) op[(int64_t)gy * w + gx] = act_apply(acc[n][r] + bv, act);
-        }
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[n][e] + bv, act);
+        st4_edge(op + (int64_t)gy * w + gx, v, gx, w);
     }
     (void)KK;
 }
@@ -694,10 +720,8 @@ __global__ __launch_bounds__(NT, 2) void k_lift_b_mfma(const float* __restrict__
             if (i < KS4 * 64) w1l[i] = w1v[r];
         }
     }
-    const int px = lane & 15, kk = lane >> 4;
-    float bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = pk[o.b3 + 4 * kk + r] + pk[o.b1 + 4 * kk + r];
+    const int oc = lane & 15, kk = lane >> 4;
+    const float bv = pk[o.b3 + oc] + pk[o.b1 + oc];
     for (; it < ntiles; it += gridDim.x) {
         LLDWT_LB_COORDS(it)
         __syncthreads();                                   // the previous tile's LDS reads are done
@@ -723,15 +747,8 @@ __global__ __launch_bounds__(NT, 2) void k_lift_b_mfma(const float* __restrict__
         conv16_mfma_ps<K, T1PS, T1W>(t, wl, wave, lane, acc);               // + conv3(t2)
         __builtin_amdgcn_sched_barrier(0);        // keep the epilogue's address arithmetic out of the MFMA section
         {
-            float* op = t3_out + (z * C) * cs;                                  // wave-uniform; 32-bit offsets below
-            const int e0 = 4 * kk * (int)cs + (y0 + wave * 4) * w + x0 + px;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
-                    if (gy < h && gx < w) op[(unsigned)(e0 + r * (int)cs + (n >> 1) * w + (n & 1) * 16)] = acc[n][r] + bv[r];
-                }
+            float* op = t3_out + (z * C + oc) * cs;
+            LLDWT_EPI_FOR(n, gy, gx) st4_edge(op + (unsigned)(gy * w + gx), acc[n] + bv, gx, w);
         }
     }
 #undef LLDWT_LB_COORDS
@@ -970,19 +987,16 @@ __global__ __launch_bounds__(NT) void k_lift_bwd_c_mfma(CView gout, lldwt_view g
 #pragma unroll
     for (int n = 0; n < 8; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
     conv16_mfma_ps<K, T1PS, T1W>(t1, wl, wave, lane, acc);
-    const int px = lane & 15, kk = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t cb = (z * C + 4 * kk + r) * cs;
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
-            if (gy < h && gx < w) {
-                const int64_t idx = cb + (int64_t)gy * w + gx;
-                const float tv = t2[idx];
-                dpre2_out[idx] = linear ? acc[n][r] : acc[n][r] * (1.f - tv * tv);
-            }
+    const int oc = lane & 15, kk = lane >> 4;
+    const int64_t cb = (z * C + oc) * cs;
+    LLDWT_EPI_FOR(n, gy, gx) {
+        const int64_t idx = cb + (int64_t)gy * w + gx;
+        floatx4 v = acc[n];
+        if (!linear) {
+            const floatx4 tv = ld4_edge(t2 + idx, gx, w);
+            v = v * (1.f - tv * tv);
         }
+        st4_edge(dpre2_out + idx, v, gx, w);
     }
 }
 
@@ -1017,19 +1031,16 @@ __global__ __launch_bounds__(NT) void k_lift_bwd_b_mfma(const float* __restrict_
 #pragma unroll
     for (int n = 0; n < 8; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
     conv16_mfma_ps<K, T1PS, T1W>(t, wl, wave, lane, acc);
-    const int px = lane & 15, kk = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t cb = (z * C + 4 * kk + r) * cs;
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int gy = y0 + wave * 4 + (n >> 1), gx = x0 + (n & 1) * 16 + px;
-            if (gy < h && gx < w) {
-                const int64_t idx = cb + (int64_t)gy * w + gx;
-                const float tv = t1v[idx];
-                dr_out[idx] = (linear ? acc[n][r] : acc[n][r] * (1.f - tv * tv)) + dt3[idx];
-            }
+    const int oc = lane & 15, kk = lane >> 4;
+    const int64_t cb = (z * C + oc) * cs;
+    LLDWT_EPI_FOR(n, gy, gx) {
+        const int64_t idx = cb + (int64_t)gy * w + gx;
+        floatx4 v = acc[n];
+        if (!linear) {
+            const floatx4 tv = ld4_edge(t1v + idx, gx, w);
+            v = v * (1.f - tv * tv);
         }
+        st4_edge(dr_out + idx, v + ld4_edge(dt3 + idx, gx, w), gx, w);
     }
     (void)KK;
 }
