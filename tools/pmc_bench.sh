@@ -1,4 +1,6 @@
 #!/bin/bash
+# Two separate rocprofv3 --pmc passes (SQ wave/wait/LDS counters, then instruction mix / MFMA busy) over bench.py.
+# Run on the GPU box: bash tools/pmc_bench.sh ; summarise with python tools/pmc_show.py <kernel-name-substring>...
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

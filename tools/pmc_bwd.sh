@@ -1,4 +1,5 @@
 #!/bin/bash
+# Same two counter passes over tools_bench_bwd.py --only "$1" (one backward kernel shape).
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

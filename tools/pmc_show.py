@@ -1,3 +1,7 @@
+"""Sum the per-dispatch counters of the two passes written by tools/pmc_bench.sh / pmc_bwd.sh per kernel.
+
+    python tools/pmc_show.py k_lift_b_mfma k_cgp_rate
+"""
 import csv,collections,sys
 pat=sys.argv[1:]
 for f in ['gpurun_out/pmc_w1/w1_counter_collection.csv','gpurun_out/pmc_w2/w2_counter_collection.csv']:

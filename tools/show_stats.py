@@ -1,3 +1,4 @@
+"""Print the top kernels of a rocprofv3 --stats CSV:  python tools/show_stats.py <kernel_stats.csv> <steps> [rows]"""
 import csv,re,sys
 f=sys.argv[1]; div=float(sys.argv[2]); n=int(sys.argv[3]) if len(sys.argv)>3 else 12
 rows=list(csv.DictReader(open(f)))
