@@ -79,9 +79,23 @@ __global__ void k_cgp_pack(const float* __restrict__ w0, const float* __restrict
 // one dense layer on the LDS column: acc = W . buf ; result kept in registers.  Wave w owns tiles [w*MT, (w+1)*MT).
 // Branch-free hot loop: A operands stream from L2 through a double-buffered register ring (the loads of k-steps
 // [s0+U, s0+2U) are in flight while the MFMAs of [s0, s0+U) issue; addresses are clamped instead of predicated).
+constexpr int CGP_U = 4;            // depth of the A-operand register ring (k-steps)
+
+// first CGP_U k-steps of wave `wave`'s A operands: issued EARLY (before the barriers / epilogue of the previous layer) so
+// that the L2 latency of the ring warm-up is not paid between two barriers
+template <int MT>
+__device__ __forceinline__ void cgp_warm(float (&An)[CGP_U][MT], const float* __restrict__ pk, int K, int wave, int lane) {
+    const int ks = (K + 3) / 4;
+    const float* pa = pk + (int64_t)(wave * MT) * ks * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < CGP_U; ++u)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) An[u][j] = pa[(j * ks + min(u, ks - 1)) * 64];
+}
+
 template <int MT>
 __device__ __forceinline__ void cgp_layer(const float* __restrict__ buf, const float* __restrict__ pk, int K, int wave,
-                                          int lane, floatx4 (&acc)[MT][CGP_NPT]) {
+                                          int lane, floatx4 (&acc)[MT][CGP_NPT], float (&An)[CGP_U][MT]) {
     const int ks = (K + 3) / 4;
     const int px = lane & 15, kk = lane >> 4;
 #pragma unroll
@@ -90,12 +104,7 @@ __device__ __forceinline__ void cgp_layer(const float* __restrict__ buf, const f
         for (int n = 0; n < CGP_NPT; ++n) acc[j][n] = floatx4{0.f, 0.f, 0.f, 0.f};
     const float* bb = buf + kk * CGP_PS + px;
     const float* pa = pk + (int64_t)(wave * MT) * ks * 64 + lane;
-    constexpr int U = 4;
-    float An[U][MT];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) An[u][j] = pa[(j * ks + min(u, ks - 1)) * 64];
+    constexpr int U = CGP_U;
     int s0 = 0;
     for (; s0 + U <= ks; s0 += U) {
         float Ac[U][MT];
@@ -136,8 +145,22 @@ __device__ __forceinline__ void cgp_layer(const float* __restrict__ buf, const f
     }
 }
 
+// biases of wave `wave`'s output channels (4 per tile and lane), loaded before the layer's MFMA loop
 template <int MT>
-__device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float* __restrict__ bias, int M, int wave,
+__device__ __forceinline__ void cgp_bias(float (&bv)[MT][4], const float* __restrict__ bias, int M, int wave, int lane) {
+    const int kk = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = (wave * MT + j) * 16 + 4 * kk + r;
+            const float b = bias[oc < M ? oc : 0];
+            bv[j][r] = oc < M ? b : 0.f;
+        }
+}
+
+template <int MT>
+__device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float (&bv)[MT][4], int M, int wave,
                                           int lane, const floatx4 (&acc)[MT][CGP_NPT]) {
     const int px = lane & 15, kk = lane >> 4;
     const int mpad = (M + 3) & ~3;     // rows M..mpad-1 are the zero padding of the next layer's K dimension
@@ -147,10 +170,9 @@ __device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float* 
         for (int r = 0; r < 4; ++r) {
             const int oc = (wave * MT + j) * 16 + 4 * kk + r;
             if (oc < mpad) {
-                const float b = oc < M ? bias[oc] : 0.f;
 #pragma unroll
                 for (int n = 0; n < CGP_NPT; ++n) {
-                    float v = oc < M ? acc[j][n][r] + b : 0.f;
+                    float v = oc < M ? acc[j][n][r] + bv[j][r] : 0.f;
                     v = v >= 0.f ? v : 0.01f * v;             // LeakyReLU(0.01)
                     buf[oc * CGP_PS + n * 16 + px] = v;
                 }
@@ -159,13 +181,18 @@ __device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float* 
     }
 }
 
-template <int MT>
+// one hidden layer; An holds its warmed-up ring, AnNext receives the next layer's (issued before the barriers)
+template <int MT, int MTN>
 __device__ __forceinline__ void cgp_hidden(float* __restrict__ buf, const float* __restrict__ pk, const CgpDims& d, int l,
-                                           int wave, int lane) {
+                                           int wave, int lane, float (&An)[CGP_U][MT], float (&AnNext)[CGP_U][MTN],
+                                           int wave_next) {
     floatx4 acc[MT][CGP_NPT];
-    cgp_layer<MT>(buf, pk + d.woff[l], d.c[l], wave, lane, acc);
+    float bv[MT][4];
+    cgp_bias<MT>(bv, pk + d.boff[l], d.c[l + 1], wave, lane);
+    cgp_layer<MT>(buf, pk + d.woff[l], d.c[l], wave, lane, acc, An);
+    cgp_warm<MTN>(AnNext, pk + d.woff[l + 1], d.c[l + 1], wave_next, lane);
     __syncthreads();                       // every wave has read this layer's input
-    cgp_store<MT>(buf, pk + d.boff[l], d.c[l + 1], wave, lane, acc);
+    cgp_store<MT>(buf, bv, d.c[l + 1], wave, lane, acc);
     __syncthreads();
 }
 
@@ -201,8 +228,10 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
         const int pp = (int)((TILE) * CGP_PX) + p;                                                   \
         _Pragma("unroll") for (int r = 0; r < CGP_NIN; ++r) {                                        \
             const int c = c0 + 4 * r;                                                                \
-            const float* row = src + (int64_t)c * hw;          /* scalar */                          \
-            xin[r] = (c < C0 && pp < hw) ? row[pp] : 0.f;                                            \
+            const bool ok = c < C0 && pp < hw;                 /* safe address + select: no branch */ \
+            const float* row = src + (int64_t)(c < C0 ? c : 0) * hw;          /* scalar */           \
+            const float xq = row[pp < hw ? pp : 0];                                                  \
+            xin[r] = ok ? xq : 0.f;                                                                  \
         }                                                                                            \
     }
     if (t0 < ntiles) LLDWT_CGP_LOAD(t0)
@@ -217,13 +246,16 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
         }
         __syncthreads();
         if (t + 1 < t0 + CGP_TILES_PER_WG && t + 1 < ntiles) LLDWT_CGP_LOAD(t + 1)
-        cgp_hidden<CGP_MAXT>(buf, pk, d, 0, wave, lane);
-        cgp_hidden<1>(buf, pk, d, 1, wave, lane);
-        cgp_hidden<1>(buf, pk, d, 2, wave, lane);
+        {
+            float A0[CGP_U][CGP_MAXT], A1[CGP_U][1], A2[CGP_U][1], A3[CGP_U][1];
+            cgp_warm<CGP_MAXT>(A0, pk + d.woff[0], d.c[0], wave, lane);
+            cgp_hidden<CGP_MAXT, 1>(buf, pk, d, 0, wave, lane, A0, A1, wave);
+            cgp_hidden<1, 1>(buf, pk, d, 1, wave, lane, A1, A2, wave);
+            cgp_hidden<1, 1>(buf, pk, d, 2, wave, lane, A2, A3, 0);
         // ---- last layer (-> sigma, mu) on wave 0 (LiftingBasedDWT_net.py:360-362)
         if (wave == 0) {
             floatx4 acc[1][CGP_NPT];
-            cgp_layer<1>(buf, pk + d.woff[3], d.c[3], 0, lane, acc);
+            cgp_layer<1>(buf, pk + d.woff[3], d.c[3], 0, lane, acc, A3);
             if (lane < 16) {
                 const float bs = pk[d.boff[3] + 0], bm = pk[d.boff[3] + 1];
 #pragma unroll
@@ -232,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
                     sm[CGP_PX + n * 16 + lane] = acc[0][n][1] + bm;
                 }
             }
+        }
         }
         __syncthreads();
         // ---- Gaussian rate, one pixel per lane, on wave 1 (:364-365)
