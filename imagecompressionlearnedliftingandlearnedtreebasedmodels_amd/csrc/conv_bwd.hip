@@ -569,6 +569,144 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
     }
 }
 
+// ---- 1x1 convs without channel placement (cgp stack, auto-encoder MLPs): dW[m][n] = sum_px dY[m][px] X[n][px] is a plain
+// "NT" GEMM with K = pixels and no spatial structure, so the image is walked as flat 32-pixel segments (128-byte rows,
+// dwordx4 loads).  A workgroup owns ALL of dW of one (plane, group) when it fits the tile -- (MT x NT) 16x16 tiles on a
+// WGM x WGN wave grid -- and splits K with the other workgroups of the group; the bias gradient is the extra column
+// n == cin_g whose B operand is the constant 1.  The generic kernel's 64x64 tile re-stages 64 rows of dY per 64 columns.
+struct W1Args {
+    const float* x;
+    const float* dy;
+    float* dw;
+    float* db;
+    int batch, cin, cout, groups;
+    int64_t hw;
+    float alpha;
+};
+constexpr int W1_KC = 32;           // pixels per chunk
+constexpr int W1_PS = W1_KC + 2;    // LDS row stride: == 2 (mod 32) dwords, 8-byte aligned rows
+
+template <int WGM, int WGN, int WTM, int WTN>
+__global__ __launch_bounds__(256) void k_wgrad1x1(W1Args a) {
+    static_assert(WGM * WGN == 4, "4 waves");
+    constexpr int MR = WGM * WTM * 16, NR = WGN * WTN * 16;       // rows of dY / X staged per chunk
+    constexpr int NV = (MR + NR) * (W1_KC / 4) / 256;             // dwordx4 per thread and chunk
+    static_assert((MR + NR) * (W1_KC / 4) % 256 == 0, "staging divides evenly");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* la = lds;                  // [MR][W1_PS]
+    float* lb = lds + MR * W1_PS;     // [NR][W1_PS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int cin_g = a.cin / a.groups, cout_g = a.cout / a.groups;
+    const int m_blocks = (cout_g + MR - 1) / MR;                 // row blocks of dW per group (blockIdx.y = g*m_blocks + mb)
+    const int g = blockIdx.y / m_blocks, m0 = (blockIdx.y % m_blocks) * MR, plane = blockIdx.z;
+    const int64_t hw = a.hw;
+    const int cpi = (int)((hw + W1_KC - 1) / W1_KC);             // chunks per image
+    const int total = a.batch * cpi;
+    floatx4 acc[WTM][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // per-thread staging rows (chunk independent): vector v of row `row`; rows < MR are dY channels, the rest X channels
+    for (int q = blockIdx.x; q < total; q += gridDim.x) {
+        const int b = q / cpi;
+        const int64_t p0 = (int64_t)(q - b * cpi) * W1_KC;
+        const int64_t z = (int64_t)plane * a.batch + b;
+        const float* dyz = a.dy + (z * a.cout + (int64_t)g * cout_g + m0) * hw + p0;
+        const float* xz = a.x + (z * a.cin + (int64_t)g * cin_g) * hw + p0;
+        const int npx = (int)(hw - p0 < W1_KC ? hw - p0 : W1_KC);     // valid pixels of this chunk
+        f4u raw[NV];
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            const int i = tid + r * 256;
+            const int row = i / (W1_KC / 4), v4 = 4 * (i % (W1_KC / 4));
+            const bool isa = row < MR;
+            const int ch = isa ? row : row - MR;
+            const bool ok = (isa ? m0 + ch < cout_g : ch < cin_g) && v4 + 3 < npx;
+            const float* src = isa ? dyz : xz;
+            raw[r] = *reinterpret_cast<const f4u*>(src + (ok ? (int64_t)ch * hw + v4 : 0));
+        }
+        __syncthreads();                                   // the previous chunk's LDS reads are done
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            const int i = tid + r * 256;
+            const int row = i / (W1_KC / 4), v4 = 4 * (i % (W1_KC / 4));
+            const bool isa = row < MR;
+            const int ch = isa ? row : row - MR;
+            const bool chan = isa ? m0 + ch < cout_g : ch < cin_g;
+            const bool ok = chan && v4 + 3 < npx;
+            floatx4 v = ok ? floatx4{raw[r].x, raw[r].y, raw[r].z, raw[r].w} : floatx4{0.f, 0.f, 0.f, 0.f};
+            if (chan && !ok && v4 < npx) {                 // ragged end of the image
+                const float* src = (isa ? dyz : xz) + (int64_t)ch * hw + v4;
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    if (v4 + e < npx) v[e] = src[e];
+            }
+            if (!isa && ch == cin_g && a.db) {             // bias column: constant 1 over the valid pixels
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v4 + e < npx ? 1.f : 0.f;
+            }
+            float2* d2 = reinterpret_cast<float2*>((isa ? la + ch * W1_PS : lb + ch * W1_PS) + v4);
+            d2[0] = float2{v[0], v[1]};
+            d2[1] = float2{v[2], v[3]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < W1_KC / 4; ++s) {
+            float A[WTM], B[WTN];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) A[i] = la[((wm * WTM + i) * 16 + col) * W1_PS + 4 * s + kk];
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) B[j] = lb[((wn * WTN + j) * 16 + col) * W1_PS + 4 * s + kk];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], B[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[row = m (4*kk + r)][col = n]
+    float* dwp = a.dw + ((int64_t)plane * a.cout + (int64_t)g * cout_g) * cin_g;
+    float* dbp = a.db ? a.db + (int64_t)plane * a.cout + (int64_t)g * cout_g : nullptr;
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+        const int n = (wn * WTN + j) * 16 + col;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (wm * WTM + i) * 16 + 4 * kk + r;
+                if (m < cout_g) {
+                    if (n < cin_g) atomicAdd(dwp + (int64_t)m * cin_g + n, a.alpha * acc[i][j][r]);
+                    else if (n == cin_g && dbp) atomicAdd(dbp + m, a.alpha * acc[i][j][r]);
+                }
+            }
+    }
+}
+
+template <int WGM, int WGN, int WTM, int WTN>
+static int launch_wgrad1x1(const W1Args& a, int planes, hipStream_t st) {
+    constexpr int MR = WGM * WTM * 16, NR = WGN * WTN * 16;
+    const size_t shmem = sizeof(float) * (size_t)(MR + NR) * W1_PS;
+    auto kern = k_wgrad1x1<WGM, WGN, WTM, WTN>;
+    if (shmem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
+        set_error("conv2d_wgrad: cannot reserve %zu bytes of LDS", shmem);
+        return LLDWT_EHIP;
+    }
+    int per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, shmem) != hipSuccess || per_cu < 1) per_cu = 2;
+    const int64_t chunks = a.batch * cdiv(a.hw, W1_KC);
+    const int64_t m_blocks = cdiv(a.cout / a.groups, MR);
+    int64_t slices = (int64_t)lldwt_num_cus() * per_cu / ((int64_t)a.groups * m_blocks * planes);     // one resident round
+    if (slices > chunks / 8) slices = chunks / 8;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)slices, (unsigned)(a.groups * m_blocks), (unsigned)planes), dim3(256), shmem, st, a);
+    return check_launch("conv2d_wgrad");
+}
+
 // dbias[plane][oc] += sum over batch, pixels of dy (read through the output placement)
 __global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dy, float* __restrict__ db, lldwt_conv_desc d,
                                                    int batch, int64_t hw, float alpha) {
@@ -694,6 +832,17 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
     const int cin_g = d->cin / d->groups, cout_g = d->cout / d->groups;
     a.n_w = cin_g * nt;
     a.n_total = a.n_w + (dbias ? 1 : 0);
+    // 1x1 without placement: whole-dW tiles (see k_wgrad1x1); the column cin_g carries the bias gradient
+    if (d->K == 1 && !d->upsample2 && d->oc_block >= d->cout && d->oc_off == 0 && d->ytot == d->cout && d->ic_block == 0) {
+        W1Args w;
+        w.x = x; w.dy = dy; w.dw = dw; w.db = dbias; w.batch = (int)batch; w.cin = d->cin; w.cout = d->cout;
+        w.groups = d->groups; w.hw = h * w_; w.alpha = alpha;
+        const int nb = cin_g + (dbias ? 1 : 0);
+        // 96 x 192 tile (the 162 x 162 layer takes two row blocks: a 192 x 192 tile needs 144 accumulator registers per
+        // lane and leaves no room for the staging vectors at 2 waves per SIMD), 64 x 192 for the 54-row layers
+        if (cout_g > 64 && nb > 64 && nb <= 192) return launch_wgrad1x1<1, 4, 6, 3>(w, (int)planes, st);
+        if (cout_g > 16 && cout_g <= 64 && nb > 64 && nb <= 192) return launch_wgrad1x1<1, 4, 4, 3>(w, (int)planes, st);
+    }
     // lifting P-block shapes: dedicated kernels (see k_wgrad16 / k_wgrad_thin)
     {
         const bool plain = d->groups == 1 && !d->upsample2 && nt == KK && d->oc_block >= d->cout && d->oc_off == 0 &&

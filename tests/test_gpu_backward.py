@@ -23,7 +23,8 @@ BWD_CASES = [
     (243, 243, 3, 1, 0, False, None),      # plc second layer
     (3, 243, 5, 3, 0, False, "A"),         # csc masked 5x5 grouped
     (243, 81, 3, 3, 2, False, "B"),        # masked 3x3 B grouped
-    (486, 162, 1, 3, 2, False, None),      # cgp 1x1 grouped
+    (486, 162, 1, 3, 2, False, None),      # cgp 1x1 grouped (64 x 192 tile of the 1x1 weight-gradient GEMM)
+    (486, 486, 1, 3, 2, False, None),      # cgp first layer: 162 x 162 per group = two 96-row blocks
     (54, 6, 1, 3, 0, False, None),
     (1, 32, 1, 1, 1, False, None),         # subband AE first layer
     (96, 3, 1, 3, 0, False, None),         # subband AE last layer (grouped 32 -> 1)
