@@ -62,6 +62,33 @@ class GaussRateFn(torch.autograd.Function):
         return dx, dparams, None
 
 
+class CgpRateFn(torch.autograd.Function):
+    """bits of the fused cgp stack (four grouped 1x1 convs + Gaussian rate, LiftingBasedDWT_net.py:282-289,360-365) with a
+    fused backward: lldwt_gauss_rate_bwd -> lldwt_cgp_bwd (all four backward-data passes in one launch) -> four 1x1
+    weight-gradient GEMMs.  cat (P,B,G*c0,h,w); x, noise (P,B,G,h,w); w_l (P,G*c_{l+1},c_l,1,1); b_l (P,G*c_{l+1})."""
+
+    @staticmethod
+    def forward(ctx, cat, x, noise, groups, *wb):
+        ws, bs = list(wb[0::2]), list(wb[1::2])
+        packed, dims = ops.cgp_pack(ws, bs, groups)
+        bits, params, h1, h2, h3 = ops.cgp_rate_train(cat, x, packed, dims, noise)
+        ctx.save_for_backward(cat, x, noise, params, h1, h2, h3, *ws)
+        ctx.dims, ctx.groups = dims, groups
+        return bits
+
+    @staticmethod
+    def backward(ctx, gbits):
+        cat, x, noise, params, h1, h2, h3, *ws = ctx.saved_tensors
+        dims, G = ctx.dims, ctx.groups
+        dx, dparams = ops.gauss_rate_bwd(x, params, noise, gbits.contiguous())
+        dcat, d1, d2, d3 = ops.cgp_bwd(dparams, h1, h2, h3, ops.cgp_pack_bwd(ws, G), dims, G)
+        grads = []
+        for xin, dy, w in ((cat, d1, ws[0]), (h1, d2, ws[1]), (h2, d3, ws[2]), (h3, dparams, ws[3])):
+            dw, db = ops.conv2d_wgrad(xin, dy, tuple(w.shape), 1, groups=G)
+            grads += [dw, db]
+        return (dcat, dx, None, None, *grads)
+
+
 class FactorizedRateFn(torch.autograd.Function):
     """(bits, q) of the factorized model (lldwt_factorized_rate); eb: (P,C,59) packed raw parameters (built by torch.cat
     from the module parameters, so their gradients flow back through the tape)."""

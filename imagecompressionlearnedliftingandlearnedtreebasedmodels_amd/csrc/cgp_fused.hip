@@ -30,9 +30,9 @@ struct CgpDims {
 // 16-channel tiles of a layer, padded to a multiple of the 4 waves (zero weights): every wave owns the same number
 static inline __host__ __device__ int cgp_tiles(int M) { return ((((M + 15) / 16) + 3) / 4) * 4; }
 
-static inline CgpDims cgp_dims(int c0, int c1, int c2, int c3) {
+static inline CgpDims cgp_dims5(int c0, int c1, int c2, int c3, int c4) {
     CgpDims d;
-    d.c[0] = c0; d.c[1] = c1; d.c[2] = c2; d.c[3] = c3; d.c[4] = 2;
+    d.c[0] = c0; d.c[1] = c1; d.c[2] = c2; d.c[3] = c3; d.c[4] = c4;
     int off = 0;
     for (int l = 0; l < 4; ++l) {
         d.woff[l] = off;
@@ -45,12 +45,15 @@ static inline CgpDims cgp_dims(int c0, int c1, int c2, int c3) {
     d.group_floats = off;
     return d;
 }
+static inline CgpDims cgp_dims(int c0, int c1, int c2, int c3) { return cgp_dims5(c0, c1, c2, c3, 2); }
+// the backward-data stack runs the layers in reverse with transposed weights: 2 -> c3 -> c2 -> c1 -> c0
+static inline CgpDims cgp_dims_bwd(int c0, int c1, int c2, int c3) { return cgp_dims5(2, c3, c2, c1, c0); }
 
 // packed[plane][group] = { for each layer: [oc tile][k step][lane] weights, then biases }
 __global__ void k_cgp_pack(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1,
                            const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
                            const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ packed,
-                           CgpDims d, int groups) {
+                           CgpDims d, int groups, int transposed) {
     const int plane = blockIdx.z, g = blockIdx.y;
     const float* ws[4] = {w0, w1, w2, w3};
     const float* bs[4] = {b0, b1, b2, b3};
@@ -64,12 +67,15 @@ __global__ void k_cgp_pack(const float* __restrict__ w0, const float* __restrict
                 const int j = i - d.woff[l];
                 const int lane = j % 64, kstep = (j / 64) % ks, t = j / (64 * ks);
                 const int oc = t * 16 + (lane & 15), k = 4 * kstep + (lane >> 4);
-                if (oc < M && k < K) v = ws[l][((int64_t)plane * groups * M + (int64_t)g * M + oc) * K + k];
+                // transposed: ws[l] is the FORWARD weight of the mirrored layer, (planes, groups*K, M): element (k, oc)
+                if (oc < M && k < K)
+                    v = transposed ? ws[l][((int64_t)plane * groups * K + (int64_t)g * K + k) * M + oc]
+                                   : ws[l][((int64_t)plane * groups * M + (int64_t)g * M + oc) * K + k];
             }
             const int bpad = ((M + 15) / 16) * 16;
             if (i >= d.boff[l] && i < d.boff[l] + bpad) {
                 const int oc = i - d.boff[l];
-                if (oc < M) v = bs[l][(int64_t)plane * groups * M + g * M + oc];
+                if (oc < M && bs[l]) v = bs[l][(int64_t)plane * groups * M + g * M + oc];
             }
         }
         dst[i] = v;
@@ -159,9 +165,11 @@ __device__ __forceinline__ void cgp_bias(float (&bv)[MT][4], const float* __rest
         }
 }
 
+// hout (training): the hidden activations also go to HBM, (Z, groups*M, hw) -- same layout the unfused convs produce
 template <int MT>
 __device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float (&bv)[MT][4], int M, int wave,
-                                          int lane, const floatx4 (&acc)[MT][CGP_NPT]) {
+                                          int lane, const floatx4 (&acc)[MT][CGP_NPT], float* __restrict__ hout = nullptr,
+                                          int64_t hw = 0, int64_t p0 = 0) {
     const int px = lane & 15, kk = lane >> 4;
     const int mpad = (M + 3) & ~3;     // rows M..mpad-1 are the zero padding of the next layer's K dimension
 #pragma unroll
@@ -175,6 +183,7 @@ __device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float (
                     float v = oc < M ? acc[j][n][r] + bv[j][r] : 0.f;
                     v = v >= 0.f ? v : 0.01f * v;             // LeakyReLU(0.01)
                     buf[oc * CGP_PS + n * 16 + px] = v;
+                    if (hout && oc < M && p0 + n * 16 + px < hw) hout[(int64_t)oc * hw + p0 + n * 16 + px] = v;
                 }
             }
         }
@@ -185,14 +194,15 @@ __device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float (
 template <int MT, int MTN>
 __device__ __forceinline__ void cgp_hidden(float* __restrict__ buf, const float* __restrict__ pk, const CgpDims& d, int l,
                                            int wave, int lane, float (&An)[CGP_U][MT], float (&AnNext)[CGP_U][MTN],
-                                           int wave_next) {
+                                           int wave_next, float* __restrict__ hout = nullptr, int64_t hw = 0,
+                                           int64_t p0 = 0) {
     floatx4 acc[MT][CGP_NPT];
     float bv[MT][4];
     cgp_bias<MT>(bv, pk + d.boff[l], d.c[l + 1], wave, lane);
     cgp_layer<MT>(buf, pk + d.woff[l], d.c[l], wave, lane, acc, An);
     cgp_warm<MTN>(AnNext, pk + d.woff[l + 1], d.c[l + 1], wave_next, lane);
     __syncthreads();                       // every wave has read this layer's input
-    cgp_store<MT>(buf, bv, d.c[l + 1], wave, lane, acc);
+    cgp_store<MT>(buf, bv, d.c[l + 1], wave, lane, acc, hout, hw, p0);
     __syncthreads();
 }
 
@@ -206,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
                                                   const float* __restrict__ noise, const float* __restrict__ packed,
                                                   float* __restrict__ bits, float* __restrict__ params_out,
                                                   double* __restrict__ bit_sum, CgpDims d, int groups, int batch,
-                                                  int64_t hw) {
+                                                  int64_t hw, float* __restrict__ h1, float* __restrict__ h2,
+                                                  float* __restrict__ h3) {
     extern __shared__ __attribute__((aligned(16))) float buf[];     // [roundup(C0,4)][CGP_PS] + sigma/mu [2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.y;
@@ -217,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
     const int rows0 = (C0 + 3) & ~3;
     float* sm = buf + rows0 * CGP_PS;                               // sigma[64], mu[64]
     const float* src = cat + (z * (int64_t)groups * C0 + (int64_t)g * C0) * hw;
+    // training: hidden activations of this (image, group) in the layout of the unfused convs
+    float* h1g = h1 ? h1 + (z * groups + g) * (int64_t)d.c[1] * hw : nullptr;
+    float* h2g = h2 ? h2 + (z * groups + g) * (int64_t)d.c[2] * hw : nullptr;
+    float* h3g = h3 ? h3 + (z * groups + g) * (int64_t)d.c[3] * hw : nullptr;
     const int64_t ntiles = (hw + CGP_PX - 1) / CGP_PX;
     const int64_t t0 = (int64_t)blockIdx.x * CGP_TILES_PER_WG;
     // this thread stages channels c0, c0+4, ...: c0 = wave id is wave-uniform -> row bases live in SGPRs
@@ -249,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
         {
             float A0[CGP_U][CGP_MAXT], A1[CGP_U][1], A2[CGP_U][1], A3[CGP_U][1];
             cgp_warm<CGP_MAXT>(A0, pk + d.woff[0], d.c[0], wave, lane);
-            cgp_hidden<CGP_MAXT, 1>(buf, pk, d, 0, wave, lane, A0, A1, wave);
-            cgp_hidden<1, 1>(buf, pk, d, 1, wave, lane, A1, A2, wave);
-            cgp_hidden<1, 1>(buf, pk, d, 2, wave, lane, A2, A3, 0);
+            cgp_hidden<CGP_MAXT, 1>(buf, pk, d, 0, wave, lane, A0, A1, wave, h1g, hw, p0);
+            cgp_hidden<1, 1>(buf, pk, d, 1, wave, lane, A1, A2, wave, h2g, hw, p0);
+            cgp_hidden<1, 1>(buf, pk, d, 2, wave, lane, A2, A3, 0, h3g, hw, p0);
         // ---- last layer (-> sigma, mu) on wave 0 (LiftingBasedDWT_net.py:360-362)
         if (wave == 0) {
             floatx4 acc[1][CGP_NPT];
@@ -297,6 +312,111 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
     }
 }
 
+// ---- backward-data of the stack (training) ---------------------------------------------------------------------------
+// dparams (dsigma, dmu) -> d3 -> d2 -> d1 -> dcat with the transposed weights; d_l = (W_{l+1}^T d_{l+1}) * LeakyReLU'(h_l)
+// is the gradient at the PRE-activation output of layer l (what the weight-gradient GEMM of layer l needs), written to
+// HBM next to the column kept in LDS.  Same machinery as the forward: waves split output channels, A operands stream
+// from L2 through the register ring, one LDS column overwritten in place.
+template <int MT>
+__device__ __forceinline__ void cgp_gate_load(float (&gate)[MT][4][CGP_NPT], const float* __restrict__ h, int M, int wave,
+                                              int lane, int64_t hw, int64_t p0) {
+    const int px = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = (wave * MT + j) * 16 + 4 * kk + r;
+#pragma unroll
+            for (int n = 0; n < CGP_NPT; ++n) {
+                const int64_t p = p0 + n * 16 + px;
+                const bool ok = oc < M && p < hw;
+                const float hv = h[ok ? (int64_t)oc * hw + p : 0];
+                gate[j][r][n] = ok ? (hv > 0.f ? 1.f : 0.01f) : 0.f;      // forward stored LeakyReLU(pre): same sign
+            }
+        }
+}
+
+template <int MT, bool GATED>
+__device__ __forceinline__ void cgp_store_bwd(float* __restrict__ buf, const float (&gate)[MT][4][CGP_NPT], int M, int wave,
+                                              int lane, const floatx4 (&acc)[MT][CGP_NPT], float* __restrict__ out,
+                                              int64_t hw, int64_t p0, bool to_lds) {
+    const int px = lane & 15, kk = lane >> 4;
+    const int mpad = (M + 3) & ~3;
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = (wave * MT + j) * 16 + 4 * kk + r;
+            if (oc < mpad) {
+#pragma unroll
+                for (int n = 0; n < CGP_NPT; ++n) {
+                    float v = oc < M ? acc[j][n][r] : 0.f;
+                    if (GATED) v *= gate[j][r][n];
+                    if (to_lds) buf[oc * CGP_PS + n * 16 + px] = v;
+                    if (oc < M && p0 + n * 16 + px < hw) out[(int64_t)oc * hw + p0 + n * 16 + px] = v;
+                }
+            }
+        }
+}
+
+template <int MT, int MTN, bool GATED>
+__device__ __forceinline__ void cgp_bwd_layer(float* __restrict__ buf, const float* __restrict__ pk, const CgpDims& d, int l,
+                                              int wave, int lane, float (&An)[CGP_U][MT], float (&AnNext)[CGP_U][MTN],
+                                              const float* __restrict__ h, float* __restrict__ out, int64_t hw, int64_t p0,
+                                              bool last) {
+    floatx4 acc[MT][CGP_NPT];
+    float gate[MT][4][CGP_NPT];
+    if (GATED) cgp_gate_load<MT>(gate, h, d.c[l + 1], wave, lane, hw, p0);
+    cgp_layer<MT>(buf, pk + d.woff[l], d.c[l], wave, lane, acc, An);
+    if (!last) cgp_warm<MTN>(AnNext, pk + d.woff[l + 1], d.c[l + 1], wave, lane);
+    __syncthreads();                       // every wave has read this layer's input
+    cgp_store_bwd<MT, GATED>(buf, gate, d.c[l + 1], wave, lane, acc, out, hw, p0, !last);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 2) void k_cgp_bwd(const float* __restrict__ dparams, const float* __restrict__ h1,
+                                                 const float* __restrict__ h2, const float* __restrict__ h3,
+                                                 const float* __restrict__ packed, float* __restrict__ d1,
+                                                 float* __restrict__ d2, float* __restrict__ d3,
+                                                 float* __restrict__ dcat, CgpDims d, int groups, int batch, int64_t hw) {
+    extern __shared__ __attribute__((aligned(16))) float buf[];     // [roundup(max width,4)][CGP_PS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const float* pk = packed + ((int64_t)plane * groups + g) * d.group_floats;
+    // d.c = {2, c3, c2, c1, c0}
+    const int64_t zg = z * groups + g;
+    const float* dpz = dparams + zg * 2 * hw;
+    const float* h3g = h3 + zg * (int64_t)d.c[1] * hw;
+    const float* h2g = h2 + zg * (int64_t)d.c[2] * hw;
+    const float* h1g = h1 + zg * (int64_t)d.c[3] * hw;
+    float* d3g = d3 + zg * (int64_t)d.c[1] * hw;
+    float* d2g = d2 + zg * (int64_t)d.c[2] * hw;
+    float* d1g = d1 + zg * (int64_t)d.c[3] * hw;
+    float* dcg = dcat + zg * (int64_t)d.c[4] * hw;
+    const int64_t ntiles = (hw + CGP_PX - 1) / CGP_PX;
+    const int64_t t0 = (int64_t)blockIdx.x * CGP_TILES_PER_WG;
+    for (int64_t t = t0; t < t0 + CGP_TILES_PER_WG && t < ntiles; ++t) {
+        const int64_t p0 = t * CGP_PX;
+        __syncthreads();                       // previous column fully consumed
+        {
+            // rows 0,1 = (dsigma, dmu) of this group, rows 2,3 = the zero padding of K
+            const int row = tid >> 6, p = tid & 63;
+            const bool ok = row < 2 && p0 + p < hw;
+            const float v = dpz[ok ? (int64_t)row * hw + p0 + p : 0];
+            buf[row * CGP_PS + p] = ok ? v : 0.f;
+        }
+        float A0[CGP_U][1], A1[CGP_U][1], A2[CGP_U][CGP_MAXT], A3[CGP_U][CGP_MAXT];
+        cgp_warm<1>(A0, pk + d.woff[0], d.c[0], wave, lane);
+        __syncthreads();
+        cgp_bwd_layer<1, 1, true>(buf, pk, d, 0, wave, lane, A0, A1, h3g, d3g, hw, p0, false);
+        cgp_bwd_layer<1, CGP_MAXT, true>(buf, pk, d, 1, wave, lane, A1, A2, h2g, d2g, hw, p0, false);
+        cgp_bwd_layer<CGP_MAXT, CGP_MAXT, true>(buf, pk, d, 2, wave, lane, A2, A3, h1g, d1g, hw, p0, false);
+        cgp_bwd_layer<CGP_MAXT, CGP_MAXT, false>(buf, pk, d, 3, wave, lane, A3, A3, nullptr, dcg, hw, p0, true);
+    }
+}
+
 }  // namespace lldwt
 using namespace lldwt;
 
@@ -323,13 +443,13 @@ extern "C" int lldwt_cgp_pack(const float* w0, const float* b0, const float* w1,
     LLDWT_REQUIRE(w0 && b0 && w1 && b1 && w2 && b2 && w3 && b3 && packed && planes > 0, "cgp_pack: null pointer");
     const CgpDims d = cgp_dims(c0, c1, c2, c3);
     dim3 grid((unsigned)cdiv(d.group_floats, 256), (unsigned)groups, (unsigned)planes);
-    hipLaunchKernelGGL(k_cgp_pack, grid, dim3(256), 0, (hipStream_t)stream, w0, b0, w1, b1, w2, b2, w3, b3, packed, d, groups);
+    hipLaunchKernelGGL(k_cgp_pack, grid, dim3(256), 0, (hipStream_t)stream, w0, b0, w1, b1, w2, b2, w3, b3, packed, d, groups, 0);
     return check_launch("cgp_pack");
 }
 
-extern "C" int lldwt_cgp_rate(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
-                              float* params_out, double* bit_sum, int64_t planes, int64_t batch, int64_t hw, int c0,
-                              int c1, int c2, int c3, int groups, void* stream) {
+static int cgp_rate_impl(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
+                         float* params_out, float* h1, float* h2, float* h3, double* bit_sum, int64_t planes, int64_t batch,
+                         int64_t hw, int c0, int c1, int c2, int c3, int groups, void* stream) {
     int r = cgp_dims_ok("cgp_rate", c0, c1, c2, c3, groups);
     if (r) return r;
     LLDWT_REQUIRE(cat && x && packed && bits && planes > 0 && batch > 0 && hw > 0 && planes * batch <= 65535,
@@ -344,6 +464,69 @@ extern "C" int lldwt_cgp_rate(const float* cat, const float* x, const float* noi
     }
     dim3 grid((unsigned)cdiv(cdiv(hw, CGP_PX), CGP_TILES_PER_WG), (unsigned)groups, (unsigned)(planes * batch));
     hipLaunchKernelGGL(k_cgp_rate, grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits, params_out,
-                       bit_sum, d, groups, (int)batch, hw);
+                       bit_sum, d, groups, (int)batch, hw, h1, h2, h3);
     return check_launch("cgp_rate");
+}
+
+extern "C" int lldwt_cgp_rate(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
+                              float* params_out, double* bit_sum, int64_t planes, int64_t batch, int64_t hw, int c0,
+                              int c1, int c2, int c3, int groups, void* stream) {
+    return cgp_rate_impl(cat, x, noise, packed, bits, params_out, nullptr, nullptr, nullptr, bit_sum, planes, batch, hw, c0,
+                         c1, c2, c3, groups, stream);
+}
+
+extern "C" int lldwt_cgp_rate_train(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
+                                    float* params_out, float* h1, float* h2, float* h3, int64_t planes, int64_t batch,
+                                    int64_t hw, int c0, int c1, int c2, int c3, int groups, void* stream) {
+    LLDWT_REQUIRE(params_out && h1 && h2 && h3, "cgp_rate_train: null output");
+    return cgp_rate_impl(cat, x, noise, packed, bits, params_out, h1, h2, h3, nullptr, planes, batch, hw, c0, c1, c2, c3,
+                         groups, stream);
+}
+
+extern "C" int64_t lldwt_cgp_bwd_packed_floats(int c0, int c1, int c2, int c3, int groups) {
+    if (c0 <= 0 || c1 <= 0 || c2 <= 0 || c3 <= 0 || groups <= 0) return -1;
+    return (int64_t)cgp_dims_bwd(c0, c1, c2, c3).group_floats * groups;
+}
+
+static int cgp_bwd_dims_ok(const char* who, int c0, int c1, int c2, int c3, int groups) {
+    LLDWT_REQUIRE(groups > 0 && c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0, "%s: bad channel counts", who);
+    LLDWT_REQUIRE(c3 <= 64 && c2 <= 64 && c1 <= 64 * CGP_MAXT && c0 <= 64 * CGP_MAXT,
+                  "%s: widths (%d,%d,%d,%d) exceed the built tile plan", who, c0, c1, c2, c3);
+    return 0;
+}
+
+extern "C" int lldwt_cgp_pack_bwd(const float* w0, const float* w1, const float* w2, const float* w3, float* packed,
+                                  int64_t planes, int c0, int c1, int c2, int c3, int groups, void* stream) {
+    int r = cgp_bwd_dims_ok("cgp_pack_bwd", c0, c1, c2, c3, groups);
+    if (r) return r;
+    LLDWT_REQUIRE(w0 && w1 && w2 && w3 && packed && planes > 0, "cgp_pack_bwd: null pointer");
+    const CgpDims d = cgp_dims_bwd(c0, c1, c2, c3);
+    dim3 grid((unsigned)cdiv(d.group_floats, 256), (unsigned)groups, (unsigned)planes);
+    // backward layer l uses the forward weight of layer 3-l, transposed
+    hipLaunchKernelGGL(k_cgp_pack, grid, dim3(256), 0, (hipStream_t)stream, w3, (const float*)nullptr, w2,
+                       (const float*)nullptr, w1, (const float*)nullptr, w0, (const float*)nullptr, packed, d, groups, 1);
+    return check_launch("cgp_pack_bwd");
+}
+
+extern "C" int lldwt_cgp_bwd(const float* dparams, const float* h1, const float* h2, const float* h3, const float* packed_bwd,
+                             float* d1, float* d2, float* d3, float* dcat, int64_t planes, int64_t batch, int64_t hw, int c0,
+                             int c1, int c2, int c3, int groups, void* stream) {
+    int r = cgp_bwd_dims_ok("cgp_bwd", c0, c1, c2, c3, groups);
+    if (r) return r;
+    LLDWT_REQUIRE(dparams && h1 && h2 && h3 && packed_bwd && d1 && d2 && d3 && dcat && planes > 0 && batch > 0 && hw > 0 &&
+                      planes * batch <= 65535, "cgp_bwd: bad arguments");
+    const CgpDims d = cgp_dims_bwd(c0, c1, c2, c3);
+    int rows = 4;
+    for (int l = 1; l < 5; ++l) rows = rows > (int)round_up(d.c[l], 4) ? rows : (int)round_up(d.c[l], 4);
+    const size_t shmem = (size_t)rows * CGP_PS * sizeof(float);
+    if (shmem > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k_cgp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
+            set_error("cgp_bwd: cannot reserve %zu bytes of LDS", shmem);
+            return LLDWT_EHIP;
+        }
+    }
+    dim3 grid((unsigned)cdiv(cdiv(hw, CGP_PX), CGP_TILES_PER_WG), (unsigned)groups, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_cgp_bwd, grid, dim3(256), shmem, (hipStream_t)stream, dparams, h1, h2, h3, packed_bwd, d1, d2, d3,
+                       dcat, d, groups, (int)batch, hw);
+    return check_launch("cgp_bwd");
 }

@@ -1153,6 +1153,9 @@ static int launch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, in
 static int dispatch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, int64_t Z, int64_t batch, int64_t h,
                          int64_t w, const float* taps, const float* packed, int64_t pstride, int C, int K, int vertical,
                          float sign, float rw, int linear, const StepBufs& b, hipStream_t st) {
+    // the tile kernels address one image's C channels with 32-bit element offsets
+    LLDWT_REQUIRE((int64_t)C * h * w < (int64_t)1 << 31, "lift_step: C*h*w = %ld exceeds the 32-bit tile addressing",
+                  (long)((int64_t)C * h * w));
 #define LLDWT_CASE(CC, KK_)                                                                                         \
     if (C == CC && K == KK_)                                                                                        \
         return launch_step<CC, KK_>(src, dst_in, dst_out, Z, batch, h, w, taps, packed, pstride, vertical, sign, rw, \
@@ -1430,6 +1433,8 @@ extern "C" int lldwt_lift_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, ll
     LLDWT_REQUIRE(dw1 && db1 && dw2 && db2 && dw3 && db3 && dw4 && db4, "lift_step_bwd: null gradient pointer");
     LLDWT_REQUIRE(planes > 0 && batch > 0 && h > 0 && w > 0 && planes * batch <= 65535, "lift_step_bwd: bad dims");
     LLDWT_REQUIRE(C == 16 && (K == 3 || K == 5), "lift_step_bwd: built for C=16, K in {3,5} (got C=%d K=%d)", C, K);
+    LLDWT_REQUIRE((int64_t)C * h * w < (int64_t)1 << 31, "lift_step_bwd: C*h*w = %ld exceeds the 32-bit tile addressing",
+                  (long)((int64_t)C * h * w));
     const int64_t Z = planes * batch, n = Z * h * w;
     if (ws_bytes < lldwt_lift_step_bwd_ws_bytes(Z, h, w, C)) {
         set_error("lift_step_bwd: workspace %ld < %ld bytes", (long)ws_bytes, (long)lldwt_lift_step_bwd_ws_bytes(Z, h, w, C));

@@ -411,9 +411,10 @@ def _entropy_train_cond2(em, out_xe, out_xo, rnd):
         c0, c1, c2 = csc.chunk(3, dim=2)
         t = torch.cat((p0, c0, p1, c1, p2, c2), dim=2)                    # regroup (:357-359): data movement only
         cg = [l.cgp_out_xo_list[i] for l in em]
-        for n in (0, 2, 4, 6):
-            t = _tconv([s_[n] for s_ in cg], t, ops.ACT_NONE if n == 6 else ops.ACT_LRELU)
-        si_list.append(ag.GaussRateFn.apply(out_xo[i], t, rnd(out_xo[i])))
+        wb = [p for n in (0, 2, 4, 6) for p in (_tstack([s_[n] for s_ in cg], lambda m: m.weight),
+                                                _tstack([s_[n] for s_ in cg], lambda m: m.bias))]
+        # fused cgp stack + Gaussian rate, forward and backward (the unfused 1x1 convs cost 3x the time)
+        si_list.append(ag.CgpRateFn.apply(t.contiguous(), out_xo[i], rnd(out_xo[i]), cg[0][0].groups, *wb))
         q_list.append(xo_q)
         parent = xo_q
     q_list.reverse()

@@ -346,6 +346,42 @@ def cgp_rate(cat, x, packed, dims, noise=None, want_params=False, bit_sum=None):
     return bits, params
 
 
+def cgp_rate_train(cat, x, packed, dims, noise):
+    """Training forward of the fused cgp stack: -> (bits, params (P,B,2G,h,w), h1, h2, h3)."""
+    P, B, G, h, w = x.shape
+    assert cat.shape == (P, B, G * dims[0], h, w)
+    bits = torch.empty_like(x)
+    params = torch.empty(P, B, 2 * G, h, w, device=x.device, dtype=torch.float32)
+    hs = [torch.empty(P, B, G * dims[l], h, w, device=x.device, dtype=torch.float32) for l in (1, 2, 3)]
+    check(_lib.load().lldwt_cgp_rate_train(_chk(cat, "cat"), _chk(x, "x"), _opt(noise), _chk(packed, "packed"), _chk(bits),
+                                           _chk(params), _chk(hs[0]), _chk(hs[1]), _chk(hs[2]), P, B, h * w, dims[0],
+                                           dims[1], dims[2], dims[3], G, _stream()), "cgp_rate_train")
+    return bits, params, hs[0], hs[1], hs[2]
+
+
+def cgp_pack_bwd(ws, groups):
+    """The four forward 1x1 weights (P, groups*c_{l+1}, c_l, 1, 1) -> transposed pack for cgp_bwd."""
+    lib = _lib.load()
+    P = ws[0].shape[0]
+    c = [ws[0].shape[2]] + [w.shape[1] // groups for w in ws]
+    n = lib.lldwt_cgp_bwd_packed_floats(c[0], c[1], c[2], c[3], groups)
+    packed = torch.empty(P, n, device=ws[0].device, dtype=torch.float32)
+    check(lib.lldwt_cgp_pack_bwd(*[_chk(w, "w") for w in ws], _chk(packed), P, c[0], c[1], c[2], c[3], groups, _stream()),
+          "cgp_pack_bwd")
+    return packed
+
+
+def cgp_bwd(dparams, h1, h2, h3, packed_bwd, dims, groups):
+    """-> (dcat, d1, d2, d3): gradients at the input and at the pre-activation outputs of layers 1..3."""
+    P, B, _, h, w = dparams.shape
+    d1, d2, d3 = torch.empty_like(h1), torch.empty_like(h2), torch.empty_like(h3)
+    dcat = torch.empty(P, B, groups * dims[0], h, w, device=dparams.device, dtype=torch.float32)
+    check(_lib.load().lldwt_cgp_bwd(_chk(dparams), _chk(h1), _chk(h2), _chk(h3), _chk(packed_bwd), _chk(d1), _chk(d2),
+                                    _chk(d3), _chk(dcat), P, B, h * w, dims[0], dims[1], dims[2], dims[3], groups,
+                                    _stream()), "cgp_bwd")
+    return dcat, d1, d2, d3
+
+
 def factorized_rate(x, eb, noise=None, bit_sum=None):
     """x: (P,B,C,h,w); eb: (P,C,59) packed EntropyBottleneck parameters -> (bits, q)."""
     P, B, Cc, h, w = x.shape

@@ -276,6 +276,23 @@ int lldwt_cgp_pack(const float* w0, const float* b0, const float* w1, const floa
 int lldwt_cgp_rate(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
                    float* params_out, double* bit_sum, int64_t planes, int64_t batch, int64_t hw, int c0, int c1,
                    int c2, int c3, int groups, void* stream);
+/* Training variants of the fused stack.  lldwt_cgp_rate_train: as lldwt_cgp_rate (no bit_sum), and also writes
+ * params_out (sigma, mu: (Z, 2*groups, hw)) and the hidden activations after LeakyReLU, h1 (Z, groups*c1, hw),
+ * h2 (Z, groups*c2, hw), h3 (Z, groups*c3, hw) -- the layout the unfused 1x1 convs would produce.
+ * lldwt_cgp_bwd: backward-data of the four layers in one launch.  dparams (Z, 2*groups, hw) = gradient at (sigma, mu)
+ * (lldwt_gauss_rate_bwd) -> d3, d2, d1 = gradients at the PRE-activation outputs of layers 3, 2, 1 (shapes of
+ * h3, h2, h1; what lldwt_conv2d_wgrad needs as dy) and dcat (Z, groups*c0, hw).  packed_bwd: the forward weights
+ * w0..w3 (PyTorch layout) transposed into MFMA A-operand order by lldwt_cgp_pack_bwd
+ * (planes, lldwt_cgp_bwd_packed_floats).  Replaces autograd through LiftingBasedDWT_net.py:282-289,360-365. */
+int lldwt_cgp_rate_train(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
+                         float* params_out, float* h1, float* h2, float* h3, int64_t planes, int64_t batch, int64_t hw,
+                         int c0, int c1, int c2, int c3, int groups, void* stream);
+int64_t lldwt_cgp_bwd_packed_floats(int c0, int c1, int c2, int c3, int groups);
+int lldwt_cgp_pack_bwd(const float* w0, const float* w1, const float* w2, const float* w3, float* packed_bwd,
+                       int64_t planes, int c0, int c1, int c2, int c3, int groups, void* stream);
+int lldwt_cgp_bwd(const float* dparams, const float* h1, const float* h2, const float* h3, const float* packed_bwd,
+                  float* d1, float* d2, float* d3, float* dcat, int64_t planes, int64_t batch, int64_t hw, int c0, int c1,
+                  int c2, int c3, int groups, void* stream);
 
 /* Factorized (compressai EntropyBottleneck.forward, call sites LiftingBasedDWT_net.py:225,229,815,818):
  * per channel c of plane p: 5 tiny matrices softplus(_matrix{i}) (1x3,3x3,3x3,3x3,3x1), biases, tanh(_factor).
