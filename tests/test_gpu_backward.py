@@ -111,6 +111,42 @@ def test_wgrad_lifting_shapes(cin, cout, K, swap):
         assert maxdiff(db[p].cpu(), db0[p] + alpha * br.grad) < 2e-5 * max(1.0, float(br.grad.abs().max()))
 
 
+@pytest.mark.parametrize("dims,hw", [((162, 162, 54, 18), (9, 13)), ((20, 12, 8, 4), (8, 24))])
+def test_cgp_fused_forward_backward(dims, hw):
+    """CgpRateFn (fused cgp stack + Gaussian rate, forward and backward) vs torch autograd over the same maths: ragged
+    pixel count (not a multiple of the 64-pixel column), the reference widths and a narrow stack."""
+    ag, ops, gu = _mods()
+    g = torch.Generator().manual_seed(sum(dims))
+    P, B, G = 2, 2, 3
+    h, w = hw
+    c = list(dims) + [2]
+    cat = torch.randn(P, B, G * c[0], h, w, generator=g)
+    x = torch.randn(P, B, G, h, w, generator=g) * 2
+    noise = torch.rand(P, B, G, h, w, generator=g) - 0.5
+    ws = [torch.randn(P, G * c[l + 1], c[l], 1, 1, generator=g) * (1.5 / c[l] ** 0.5) for l in range(4)]
+    bs = [torch.randn(P, G * c[l + 1], generator=g) * 0.1 for l in range(4)]
+    bs[3] = bs[3] + torch.tensor([1.0, 0.0] * G)                      # keep sigma away from the 0.11 clamp mostly
+    gb = torch.rand(P, B, G, h, w, generator=g)
+    dv = [gu.dev(t).requires_grad_(True) for t in [cat, x] + [t for pair in zip(ws, bs) for t in pair]]
+    bits = ag.CgpRateFn.apply(dv[0], dv[1], gu.dev(noise), G, *dv[2:])
+    bits.backward(gu.dev(gb))
+    for p in range(P):
+        rv = [t[p].clone().requires_grad_(True) for t in [cat, x] + [t for pair in zip(ws, bs) for t in pair]]
+        t = rv[0]
+        for l in range(4):
+            t = F.conv2d(t, rv[2 + 2 * l], rv[3 + 2 * l], groups=G)
+            if l < 3:
+                t = F.leaky_relu(t, 0.01)
+        sigma, mu = t[:, 0::2], t[:, 1::2]
+        lik = entropy.gaussian_likelihood(rv[1] + noise[p], sigma, mu)
+        ref = -torch.log2(lik)
+        assert maxdiff(bits[p].detach().cpu(), ref) < 2e-4
+        ref.backward(gb[p])
+        for a, b, name in zip(dv, rv, ["cat", "x"] + ["w%d" % (i // 2) if i % 2 == 0 else "b%d" % (i // 2) for i in range(8)]):
+            scale = max(1.0, float(b.grad.abs().max()))
+            assert maxdiff(a.grad[p].cpu(), b.grad) < 5e-4 * scale, name
+
+
 def _lift_stacks(sds, nblocks, gu):
     """oracle per-plane state dicts -> taps (4,P,3) and the 8 stacked tensors (nblocks,2,P,...) on the device."""
     taps = torch.stack([torch.stack([sd["preProcessingList.%d.weight" % j].reshape(3) for sd in sds], 0) for j in range(4)], 0)
