@@ -195,26 +195,45 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     }
     __syncthreads();
 
+    // Fast staging path when the input has no channel placement (every layer of the eval path): the chunk base is a
+    // wave-uniform pointer (SGPRs), each thread keeps a 32-bit element offset per staged element, and the steady state
+    // issues one load + one select per element with no address arithmetic on the vector ALU -- which, on this fp32 path,
+    // is the same pipe the MFMAs need.  The last chunk (cin_g % CK channels) and placed inputs take the table path.
+    const bool plain_in = d.ic_block == 0;
+    unsigned voff[G::NIN];
+#pragma unroll
+    for (int r = 0; r < G::NIN; ++r)                 // BYTE offsets (< 4 GB: CK channel planes), so they fit the 32-bit voffset
+        voff[r] = in_off[r] >= 0 ? 4u * (unsigned)(in_c[r] * (int)hwi + in_off[r]) : 0u;
+    const int full_chunks = cin_g / CK;              // chunks whose CK channels all exist
+
     // (macros, not lambdas: by-reference captures of the register arrays end up in scratch)
+    // LOAD only issues the loads (from a safe address where the element is padding); the zeroing happens in STORE, one
+    // chunk later: a select right after the load would sit above the sched_barrier that pins the loads over the MFMAs
+    // and make every wave wait out the memory latency before its matrix work (seen as vmcnt waits in the .s).
 #define LLDWT_STAGE_LOAD(CHUNK)                                                                             \
     {                                                                                                       \
-        _Pragma("unroll") for (int r = 0; r < G::NIN; ++r) {                                                \
-            const int icm = s_icm[(CHUNK) * CK + in_c[r]];                                                  \
-            const bool ok = in_off[r] >= 0 && icm >= 0;     /* safe address + select: no branch per element */ \
-            const float xv = xg[ok ? icm * hwi + in_off[r] : 0];                                            \
-            xin[r] = ok ? xv : 0.f;                                                                         \
+        if (plain_in && (CHUNK) < full_chunks) {                                                            \
+            const float* cb = xg + (int64_t)(g * cin_g + (CHUNK) * CK) * hwi;      /* wave-uniform */        \
+            _Pragma("unroll") for (int r = 0; r < G::NIN; ++r)                                              \
+                xin[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cb) + voff[r]);      \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int r = 0; r < G::NIN; ++r) {                                            \
+                const int icm = s_icm[(CHUNK) * CK + in_c[r]];                                              \
+                xin[r] = xg[(in_off[r] >= 0 && icm >= 0) ? icm * hwi + in_off[r] : 0];                      \
+            }                                                                                               \
         }                                                                                                   \
         const float4* src = reinterpret_cast<const float4*>(pk + (int64_t)(CHUNK) * a.p.chunk_floats);     \
         _Pragma("unroll") for (int r = 0; r < G::NWV; ++r) {                                                \
             const int i = tid + r * G::NT;                                                                  \
             const float4 wq = src[i < wvec ? i : 0];                                                        \
-            wv[r] = (i < wvec) ? wq : float4{0.f, 0.f, 0.f, 0.f};                                           \
+            wv[r].x = wq.x; wv[r].y = wq.y; wv[r].z = wq.z; wv[r].w = wq.w;                                 \
         }                                                                                                   \
     }
-#define LLDWT_STAGE_STORE()                                                                                 \
+#define LLDWT_STAGE_STORE(CHUNK)                                                                            \
     {                                                                                                       \
         _Pragma("unroll") for (int r = 0; r < G::NIN; ++r)                                                  \
-            if (in_lds[r] >= 0) lin[in_lds[r]] = xin[r];                                                    \
+            if (in_lds[r] >= 0)                                                                             \
+                lin[in_lds[r]] = (in_off[r] >= 0 && (CHUNK) * CK + in_c[r] < cin_g) ? xin[r] : 0.f;         \
         float4* dst = reinterpret_cast<float4*>(lw);                                                        \
         _Pragma("unroll") for (int r = 0; r < G::NWV; ++r) {                                                \
             const int i = tid + r * G::NT;                                                                  \
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
     //  on the 243->243 layer -- the workgroups do not run in lockstep -- and is not kept)
     for (int chunk = 0; chunk < a.p.nchunk; ++chunk) {
         __syncthreads();          // all waves are done reading the previous chunk
-        LLDWT_STAGE_STORE()
+        LLDWT_STAGE_STORE(chunk)
         __syncthreads();
         if (chunk + 1 < a.p.nchunk) LLDWT_STAGE_LOAD(chunk + 1)
         if constexpr (DENSE) {
