@@ -24,19 +24,22 @@ struct CgpDims {
     int c[5];        // channels per group: C0 (in), C1, C2, C3, C4 (=2)
     int woff[4];     // float offset of layer l's packed weights inside a (plane, group) block
     int boff[4];     // float offset of layer l's bias
+    int mt[4];       // 16-channel tiles packed for layer l = 4 waves x the kernel's tiles per wave (zero weights beyond M)
     int group_floats;
 };
 
 // 16-channel tiles of a layer, padded to a multiple of the 4 waves (zero weights): every wave owns the same number
 static inline __host__ __device__ int cgp_tiles(int M) { return ((((M + 15) / 16) + 3) / 4) * 4; }
 
-static inline CgpDims cgp_dims5(int c0, int c1, int c2, int c3, int c4) {
+// wide: which layers the kernels run with CGP_MAXT tiles per wave (forward: the first; backward: the last two)
+static inline CgpDims cgp_dims5(int c0, int c1, int c2, int c3, int c4, unsigned wide) {
     CgpDims d;
     d.c[0] = c0; d.c[1] = c1; d.c[2] = c2; d.c[3] = c3; d.c[4] = c4;
     int off = 0;
     for (int l = 0; l < 4; ++l) {
+        d.mt[l] = 4 * (((wide >> l) & 1u) ? CGP_MAXT : 1);
         d.woff[l] = off;
-        off += cgp_tiles(d.c[l + 1]) * (int)cdiv(d.c[l], 4) * 64;
+        off += d.mt[l] * (int)cdiv(d.c[l] + 1, 4) * 64;      // K + 1: the bias is the weight of a constant-1 row
     }
     for (int l = 0; l < 4; ++l) {
         d.boff[l] = off;
@@ -45,9 +48,9 @@ static inline CgpDims cgp_dims5(int c0, int c1, int c2, int c3, int c4) {
     d.group_floats = off;
     return d;
 }
-static inline CgpDims cgp_dims(int c0, int c1, int c2, int c3) { return cgp_dims5(c0, c1, c2, c3, 2); }
+static inline CgpDims cgp_dims(int c0, int c1, int c2, int c3) { return cgp_dims5(c0, c1, c2, c3, 2, 0x1u); }
 // the backward-data stack runs the layers in reverse with transposed weights: 2 -> c3 -> c2 -> c1 -> c0
-static inline CgpDims cgp_dims_bwd(int c0, int c1, int c2, int c3) { return cgp_dims5(2, c3, c2, c1, c0); }
+static inline CgpDims cgp_dims_bwd(int c0, int c1, int c2, int c3) { return cgp_dims5(2, c3, c2, c1, c0, 0xCu); }
 
 // packed[plane][group] = { for each layer: [oc tile][k step][lane] weights, then biases }
 __global__ void k_cgp_pack(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1,
@@ -62,7 +65,7 @@ __global__ void k_cgp_pack(const float* __restrict__ w0, const float* __restrict
         float v = 0.f;
         for (int l = 0; l < 4; ++l) {
             const int K = d.c[l], M = d.c[l + 1];
-            const int ks = (K + 3) / 4, mt = cgp_tiles(M);
+            const int ks = (K + 1 + 3) / 4, mt = d.mt[l];
             if (i >= d.woff[l] && i < d.woff[l] + mt * ks * 64) {
                 const int j = i - d.woff[l];
                 const int lane = j % 64, kstep = (j / 64) % ks, t = j / (64 * ks);
@@ -71,11 +74,8 @@ __global__ void k_cgp_pack(const float* __restrict__ w0, const float* __restrict
                 if (oc < M && k < K)
                     v = transposed ? ws[l][((int64_t)plane * groups * K + (int64_t)g * K + k) * M + oc]
                                    : ws[l][((int64_t)plane * groups * M + (int64_t)g * M + oc) * K + k];
-            }
-            const int bpad = ((M + 15) / 16) * 16;
-            if (i >= d.boff[l] && i < d.boff[l] + bpad) {
-                const int oc = i - d.boff[l];
-                if (oc < M && bs[l]) v = bs[l][(int64_t)plane * groups * M + g * M + oc];
+                // row K of the activations is the constant 1: its weight is the bias (none in the backward stack)
+                if (oc < M && k == K && bs[l]) v = bs[l][(int64_t)plane * groups * M + g * M + oc];
             }
         }
         dst[i] = v;
@@ -151,27 +151,13 @@ __device__ __forceinline__ void cgp_layer(const float* __restrict__ buf, const f
     }
 }
 
-// biases of wave `wave`'s output channels (4 per tile and lane), loaded before the layer's MFMA loop
-template <int MT>
-__device__ __forceinline__ void cgp_bias(float (&bv)[MT][4], const float* __restrict__ bias, int M, int wave, int lane) {
-    const int kk = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oc = (wave * MT + j) * 16 + 4 * kk + r;
-            const float b = bias[oc < M ? oc : 0];
-            bv[j][r] = oc < M ? b : 0.f;
-        }
-}
-
 // hout (training): the hidden activations also go to HBM, (Z, groups*M, hw) -- same layout the unfused convs produce
 template <int MT>
-__device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float (&bv)[MT][4], int M, int wave,
-                                          int lane, const floatx4 (&acc)[MT][CGP_NPT], float* __restrict__ hout = nullptr,
+__device__ __forceinline__ void cgp_store(float* __restrict__ buf, int M, int wave, int lane,
+                                          const floatx4 (&acc)[MT][CGP_NPT], float* __restrict__ hout = nullptr,
                                           int64_t hw = 0, int64_t p0 = 0) {
     const int px = lane & 15, kk = lane >> 4;
-    const int mpad = (M + 3) & ~3;     // rows M..mpad-1 are the zero padding of the next layer's K dimension
+    const int mpad = (M + 1 + 3) & ~3;  // row M = the constant 1 that carries the next layer's bias, then zero padding of K
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
 #pragma unroll
@@ -180,8 +166,9 @@ __device__ __forceinline__ void cgp_store(float* __restrict__ buf, const float (
             if (oc < mpad) {
 #pragma unroll
                 for (int n = 0; n < CGP_NPT; ++n) {
-                    float v = oc < M ? acc[j][n][r] + bv[j][r] : 0.f;
+                    float v = acc[j][n][r];                   // bias already inside (weight of the constant-1 row)
                     v = v >= 0.f ? v : 0.01f * v;             // LeakyReLU(0.01)
+                    v = oc < M ? v : (oc == M ? 1.f : 0.f);
                     buf[oc * CGP_PS + n * 16 + px] = v;
                     if (hout && oc < M && p0 + n * 16 + px < hw) hout[(int64_t)oc * hw + p0 + n * 16 + px] = v;
                 }
@@ -197,12 +184,10 @@ __device__ __forceinline__ void cgp_hidden(float* __restrict__ buf, const float*
                                            int wave_next, float* __restrict__ hout = nullptr, int64_t hw = 0,
                                            int64_t p0 = 0) {
     floatx4 acc[MT][CGP_NPT];
-    float bv[MT][4];
-    cgp_bias<MT>(bv, pk + d.boff[l], d.c[l + 1], wave, lane);
-    cgp_layer<MT>(buf, pk + d.woff[l], d.c[l], wave, lane, acc, An);
-    cgp_warm<MTN>(AnNext, pk + d.woff[l + 1], d.c[l + 1], wave_next, lane);
+    cgp_layer<MT>(buf, pk + d.woff[l], d.c[l] + 1, wave, lane, acc, An);
+    cgp_warm<MTN>(AnNext, pk + d.woff[l + 1], d.c[l + 1] + 1, wave_next, lane);
     __syncthreads();                       // every wave has read this layer's input
-    cgp_store<MT>(buf, bv, d.c[l + 1], wave, lane, acc, hout, hw, p0);
+    cgp_store<MT>(buf, d.c[l + 1], wave, lane, acc, hout, hw, p0);
     __syncthreads();
 }
 
@@ -212,6 +197,7 @@ constexpr int CGP_TILES_PER_WG = 8;                       // consecutive 64-pixe
 
 // Persistent over CGP_TILES_PER_WG consecutive pixel columns: the next column's input is prefetched into registers
 // while the matrix work of the current one runs (issue early / write late), so HBM latency never parks the waves.
+template <bool TRAIN>      // TRAIN: also write the hidden activations (kept out of the eval kernel: the extra pointers spill)
 __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ cat, const float* __restrict__ x,
                                                   const float* __restrict__ noise, const float* __restrict__ packed,
                                                   float* __restrict__ bits, float* __restrict__ params_out,
@@ -225,13 +211,13 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
     const int plane = (int)(z / batch);
     const float* pk = packed + ((int64_t)plane * groups + g) * d.group_floats;
     const int C0 = d.c[0];
-    const int rows0 = (C0 + 3) & ~3;
+    const int rows0 = (C0 + 1 + 3) & ~3;                            // + the constant-1 row that carries the biases
     float* sm = buf + rows0 * CGP_PS;                               // sigma[64], mu[64]
     const float* src = cat + (z * (int64_t)groups * C0 + (int64_t)g * C0) * hw;
     // training: hidden activations of this (image, group) in the layout of the unfused convs
-    float* h1g = h1 ? h1 + (z * groups + g) * (int64_t)d.c[1] * hw : nullptr;
-    float* h2g = h2 ? h2 + (z * groups + g) * (int64_t)d.c[2] * hw : nullptr;
-    float* h3g = h3 ? h3 + (z * groups + g) * (int64_t)d.c[3] * hw : nullptr;
+    float* h1g = TRAIN ? h1 + (z * groups + g) * (int64_t)d.c[1] * hw : nullptr;
+    float* h2g = TRAIN ? h2 + (z * groups + g) * (int64_t)d.c[2] * hw : nullptr;
+    float* h3g = TRAIN ? h3 + (z * groups + g) * (int64_t)d.c[3] * hw : nullptr;
     const int64_t ntiles = (hw + CGP_PX - 1) / CGP_PX;
     const int64_t t0 = (int64_t)blockIdx.x * CGP_TILES_PER_WG;
     // this thread stages channels c0, c0+4, ...: c0 = wave id is wave-uniform -> row bases live in SGPRs
@@ -243,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
         const int pp = (int)((TILE) * CGP_PX) + p;                                                   \
         _Pragma("unroll") for (int r = 0; r < CGP_NIN; ++r) {                                        \
             const int c = c0 + 4 * r;                                                                \
-            const bool ok = c < C0 && pp < hw;                 /* safe address + select: no branch */ \
+            /* raw load from a safe address; the zeroing of padding happens at the LDS store, one tile later */ \
+            /* (a select here makes hipcc wait for every load in turn: 29 serialised round trips in the .s)  */ \
             const float* row = src + (int64_t)(c < C0 ? c : 0) * hw;          /* scalar */           \
-            const float xq = row[pp < hw ? pp : 0];                                                  \
-            xin[r] = ok ? xq : 0.f;                                                                  \
+            xin[r] = row[pp < hw ? pp : 0];                                                          \
         }                                                                                            \
     }
     if (t0 < ntiles) LLDWT_CGP_LOAD(t0)
@@ -257,26 +243,27 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
 #pragma unroll
         for (int r = 0; r < CGP_NIN; ++r) {
             const int c = c0 + 4 * r;
-            if (c < rows0) buf[c * CGP_PS + p] = xin[r];
+            if (c < rows0) buf[c * CGP_PS + p] = c < C0 ? (p0 + p < hw ? xin[r] : 0.f) : (c == C0 ? 1.f : 0.f);
         }
         __syncthreads();
-        if (t + 1 < t0 + CGP_TILES_PER_WG && t + 1 < ntiles) LLDWT_CGP_LOAD(t + 1)
         {
             float A0[CGP_U][CGP_MAXT], A1[CGP_U][1], A2[CGP_U][1], A3[CGP_U][1];
-            cgp_warm<CGP_MAXT>(A0, pk + d.woff[0], d.c[0], wave, lane);
+            cgp_warm<CGP_MAXT>(A0, pk + d.woff[0], d.c[0] + 1, wave, lane);
             cgp_hidden<CGP_MAXT, 1>(buf, pk, d, 0, wave, lane, A0, A1, wave, h1g, hw, p0);
+            // the next column's input is requested only now: during layer 0 (48 accumulators + the 24-register operand ring
+            // per lane) 41 more live registers spilled; layers 1-3 and the rate leave ~10 us to cover the latency
+            if (t + 1 < t0 + CGP_TILES_PER_WG && t + 1 < ntiles) LLDWT_CGP_LOAD(t + 1)
             cgp_hidden<1, 1>(buf, pk, d, 1, wave, lane, A1, A2, wave, h2g, hw, p0);
             cgp_hidden<1, 1>(buf, pk, d, 2, wave, lane, A2, A3, 0, h3g, hw, p0);
         // ---- last layer (-> sigma, mu) on wave 0 (LiftingBasedDWT_net.py:360-362)
         if (wave == 0) {
             floatx4 acc[1][CGP_NPT];
-            cgp_layer<1>(buf, pk + d.woff[3], d.c[3], 0, lane, acc, A3);
+            cgp_layer<1>(buf, pk + d.woff[3], d.c[3] + 1, 0, lane, acc, A3);
             if (lane < 16) {
-                const float bs = pk[d.boff[3] + 0], bm = pk[d.boff[3] + 1];
 #pragma unroll
                 for (int n = 0; n < CGP_NPT; ++n) {
-                    sm[n * 16 + lane] = acc[0][n][0] + bs;
-                    sm[CGP_PX + n * 16 + lane] = acc[0][n][1] + bm;
+                    sm[n * 16 + lane] = acc[0][n][0];
+                    sm[CGP_PX + n * 16 + lane] = acc[0][n][1];
                 }
             }
         }
@@ -341,7 +328,7 @@ __device__ __forceinline__ void cgp_store_bwd(float* __restrict__ buf, const flo
                                               int lane, const floatx4 (&acc)[MT][CGP_NPT], float* __restrict__ out,
                                               int64_t hw, int64_t p0, bool to_lds) {
     const int px = lane & 15, kk = lane >> 4;
-    const int mpad = (M + 3) & ~3;
+    const int mpad = (M + 1 + 3) & ~3;       // the packed K of the next layer is M + 1 (its bias row: zero weights here)
 #pragma unroll
     for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -367,8 +354,8 @@ __device__ __forceinline__ void cgp_bwd_layer(float* __restrict__ buf, const flo
     floatx4 acc[MT][CGP_NPT];
     float gate[MT][4][CGP_NPT];
     if (GATED) cgp_gate_load<MT>(gate, h, d.c[l + 1], wave, lane, hw, p0);
-    cgp_layer<MT>(buf, pk + d.woff[l], d.c[l], wave, lane, acc, An);
-    if (!last) cgp_warm<MTN>(AnNext, pk + d.woff[l + 1], d.c[l + 1], wave, lane);
+    cgp_layer<MT>(buf, pk + d.woff[l], d.c[l] + 1, wave, lane, acc, An);
+    if (!last) cgp_warm<MTN>(AnNext, pk + d.woff[l + 1], d.c[l + 1] + 1, wave, lane);
     __syncthreads();                       // every wave has read this layer's input
     cgp_store_bwd<MT, GATED>(buf, gate, d.c[l + 1], wave, lane, acc, out, hw, p0, !last);
     __syncthreads();
@@ -408,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void k_cgp_bwd(const float* __restrict__ dp
             buf[row * CGP_PS + p] = ok ? v : 0.f;
         }
         float A0[CGP_U][1], A1[CGP_U][1], A2[CGP_U][CGP_MAXT], A3[CGP_U][CGP_MAXT];
-        cgp_warm<1>(A0, pk + d.woff[0], d.c[0], wave, lane);
+        cgp_warm<1>(A0, pk + d.woff[0], d.c[0] + 1, wave, lane);
         __syncthreads();
         cgp_bwd_layer<1, 1, true>(buf, pk, d, 0, wave, lane, A0, A1, h3g, d3g, hw, p0, false);
         cgp_bwd_layer<1, CGP_MAXT, true>(buf, pk, d, 1, wave, lane, A1, A2, h2g, d2g, hw, p0, false);
@@ -422,11 +409,11 @@ using namespace lldwt;
 
 static int cgp_dims_ok(const char* who, int c0, int c1, int c2, int c3, int groups) {
     LLDWT_REQUIRE(groups > 0 && c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0, "%s: bad channel counts", who);
-    LLDWT_REQUIRE(c1 <= 64 * CGP_MAXT && c2 <= 64 && c3 <= 64,
-                  "%s: hidden widths (%d,%d,%d) exceed the built tile plan (%d,64,64)", who, c1, c2, c3, 64 * CGP_MAXT);
-    LLDWT_REQUIRE(c1 <= round_up(c0, 4) && c2 <= round_up(c0, 4) && c3 <= round_up(c0, 4),
+    LLDWT_REQUIRE(c1 < 64 * CGP_MAXT && c2 < 64 && c3 < 64,
+                  "%s: hidden widths (%d,%d,%d) exceed the built tile plan (%d,63,63)", who, c1, c2, c3, 64 * CGP_MAXT - 1);
+    LLDWT_REQUIRE(c1 <= c0 && c2 <= c0 && c3 <= c0,
                   "%s: hidden widths must not exceed the input width (in-place LDS column)", who);
-    LLDWT_REQUIRE(round_up(c0, 4) <= CGP_ROWS_MAX, "%s: input width %d exceeds %d", who, c0, CGP_ROWS_MAX);
+    LLDWT_REQUIRE(round_up(c0 + 1, 4) <= CGP_ROWS_MAX, "%s: input width %d exceeds %d", who, c0, CGP_ROWS_MAX - 1);
     return 0;
 }
 
@@ -455,16 +442,22 @@ static int cgp_rate_impl(const float* cat, const float* x, const float* noise, c
     LLDWT_REQUIRE(cat && x && packed && bits && planes > 0 && batch > 0 && hw > 0 && planes * batch <= 65535,
                   "cgp_rate: bad arguments");
     const CgpDims d = cgp_dims(c0, c1, c2, c3);
-    const size_t shmem = ((size_t)round_up(c0, 4) * CGP_PS + 2 * CGP_PX) * sizeof(float);
+    const size_t shmem = ((size_t)round_up(c0 + 1, 4) * CGP_PS + 2 * CGP_PX) * sizeof(float);
+    const bool train = h1 != nullptr;
+    const void* kern = train ? (const void*)k_cgp_rate<true> : (const void*)k_cgp_rate<false>;
     if (shmem > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)k_cgp_rate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
             set_error("cgp_rate: cannot reserve %zu bytes of LDS", shmem);
             return LLDWT_EHIP;
         }
     }
     dim3 grid((unsigned)cdiv(cdiv(hw, CGP_PX), CGP_TILES_PER_WG), (unsigned)groups, (unsigned)(planes * batch));
-    hipLaunchKernelGGL(k_cgp_rate, grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits, params_out,
-                       bit_sum, d, groups, (int)batch, hw, h1, h2, h3);
+    if (train)
+        hipLaunchKernelGGL(k_cgp_rate<true>, grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits,
+                           params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3);
+    else
+        hipLaunchKernelGGL(k_cgp_rate<false>, grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits,
+                           params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3);
     return check_launch("cgp_rate");
 }
 
@@ -490,7 +483,7 @@ extern "C" int64_t lldwt_cgp_bwd_packed_floats(int c0, int c1, int c2, int c3, i
 
 static int cgp_bwd_dims_ok(const char* who, int c0, int c1, int c2, int c3, int groups) {
     LLDWT_REQUIRE(groups > 0 && c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0, "%s: bad channel counts", who);
-    LLDWT_REQUIRE(c3 <= 64 && c2 <= 64 && c1 <= 64 * CGP_MAXT && c0 <= 64 * CGP_MAXT,
+    LLDWT_REQUIRE(c3 < 64 && c2 < 64 && c1 < 64 * CGP_MAXT && c0 < 64 * CGP_MAXT,
                   "%s: widths (%d,%d,%d,%d) exceed the built tile plan", who, c0, c1, c2, c3);
     return 0;
 }
@@ -517,7 +510,7 @@ extern "C" int lldwt_cgp_bwd(const float* dparams, const float* h1, const float*
                       planes * batch <= 65535, "cgp_bwd: bad arguments");
     const CgpDims d = cgp_dims_bwd(c0, c1, c2, c3);
     int rows = 4;
-    for (int l = 1; l < 5; ++l) rows = rows > (int)round_up(d.c[l], 4) ? rows : (int)round_up(d.c[l], 4);
+    for (int l = 1; l < 5; ++l) rows = rows > (int)round_up(d.c[l] + 1, 4) ? rows : (int)round_up(d.c[l] + 1, 4);
     const size_t shmem = (size_t)rows * CGP_PS * sizeof(float);
     if (shmem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k_cgp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
