@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
             const int i = tid + r * 256;                                                                         \
             const int gy = y0 - R + i / IW, gx = x0 - R + i % IW;                                                \
             const bool ok = i < IHW && gy >= 0 && gy < h && gx >= 0 && gx < w;                                   \
-            const float tv = bz[ok ? (int64_t)gy * w + gx : 0];                                                  \
-            vb[r] = ok ? tv : 0.f;                                                                               \
+            vb[r] = bz[ok ? (int64_t)gy * w + gx : 0];     /* raw: zeroed at the LDS store (a select here is  */  \
+                                                           /* pinned above the MFMAs with the load: a wait)   */  \
         }                                                                                                        \
     }
 
@@ -507,14 +507,16 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
                 d2[0] = float2{v4[0], v4[1]};
                 d2[1] = float2{v4[2], v4[3]};
             }
-        }
 #pragma unroll
-        for (int r = 0; r < NB; ++r) {
-            const int i = tid + r * 256;
-            if (i < IHW) {
-                lb[i] = vb[r];
-                const int ly = i / IW, lxx = i % IW;
-                if (ly >= R && ly < R + WG_TH && lxx >= R && lxx < R + WG_TW) bsb += vb[r];
+            for (int r = 0; r < NB; ++r) {
+                const int i = tid + r * 256;
+                if (i < IHW) {
+                    const int ly = i / IW, lxx = i % IW;
+                    const int gy = y0 - R + ly, gx = x0 - R + lxx;
+                    const float v = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? vb[r] : 0.f;
+                    lb[i] = v;
+                    if (ly >= R && ly < R + WG_TH && lxx >= R && lxx < R + WG_TW) bsb += v;
+                }
             }
         }
         __syncthreads();
