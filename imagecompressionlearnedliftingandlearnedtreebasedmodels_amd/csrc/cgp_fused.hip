@@ -317,8 +317,7 @@ __device__ __forceinline__ void cgp_gate_load(float (&gate)[MT][4][CGP_NPT], con
             for (int n = 0; n < CGP_NPT; ++n) {
                 const int64_t p = p0 + n * 16 + px;
                 const bool ok = oc < M && p < hw;
-                const float hv = h[ok ? (int64_t)oc * hw + p : 0];
-                gate[j][r][n] = ok ? (hv > 0.f ? 1.f : 0.01f) : 0.f;      // forward stored LeakyReLU(pre): same sign
+                gate[j][r][n] = h[ok ? (int64_t)oc * hw + p : 0];         // RAW activation; turned into the gate at the store
             }
         }
 }
@@ -338,7 +337,7 @@ __device__ __forceinline__ void cgp_store_bwd(float* __restrict__ buf, const flo
 #pragma unroll
                 for (int n = 0; n < CGP_NPT; ++n) {
                     float v = oc < M ? acc[j][n][r] : 0.f;
-                    if (GATED) v *= gate[j][r][n];
+                    if (GATED) v *= gate[j][r][n] > 0.f ? 1.f : 0.01f;    // LeakyReLU' from the sign of the stored activation
                     if (to_lds) buf[oc * CGP_PS + n * 16 + px] = v;
                     if (oc < M && p0 + n * 16 + px < hw) out[(int64_t)oc * hw + p0 + n * 16 + px] = v;
                 }
