@@ -680,6 +680,31 @@ __global__ __launch_bounds__(NT, 2) void k_lift_b_mfma(const float* __restrict__
     const int per_img = tiles_x * tiles_y, ntiles = batch * per_img;
     f4u raw[Tile16<K>::NVT];
     float sk[NSK];
+    // tile-independent staging coordinates, computed once per workgroup: INTERIOR tiles (no border logic needed, the
+    // common case) then cost one add + one load per vector at issue time and bare LDS stores afterwards -- vector ALU
+    // instructions come straight out of the matrix pipe's time on this fp32 path
+    constexpr bool FAST = (T1W % 4) == 0;                 // K = 5: the tile row is a whole number of vectors
+    int relv[Tile16<K>::NVT], ldsv[Tile16<K>::NVT], relk[NSK], ldsk[NSK];
+#pragma unroll
+    for (int r = 0; r < Tile16<K>::NVT; ++r) {
+        using G = Tile16<K>;
+        const int i = tid + r * NT;
+        const int c = i / (G::T1H * G::NVR), rem = i - c * (G::T1H * G::NVR);
+        const int ly = rem / G::NVR, lxv = 4 * (rem % G::NVR);
+        const bool live = i < G::NV;
+        relv[r] = live ? c * (int)cs + (ly - R) * w + (lxv - R) : 0;
+        ldsv[r] = live ? c * T1PS + ly * T1W + lxv : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < NSK; ++r) {
+        const int i = tid + r * NT;
+        const int ly = i / T1W, lx = i - ly * T1W;
+        const bool live = i < T1H * T1W;
+        relk[r] = live ? (ly - R) * w + (lx - R) : 0;
+        ldsk[r] = live ? ly * (T1W + 1) + lx : -1;
+    }
+#define LLDWT_LB_INTERIOR(y0_, x0_) \
+    (FAST && (y0_) >= R && (y0_) + TH + R <= h && (x0_) >= R && (x0_) - R + 4 * Tile16<K>::NVR <= w)
 
 #define LLDWT_LB_COORDS(i_)                                                                                      \
     const int b_ = (i_) / per_img, r_ = (i_) - b_ * per_img;                                                     \
@@ -688,13 +713,22 @@ __global__ __launch_bounds__(NT, 2) void k_lift_b_mfma(const float* __restrict__
 #define LLDWT_LB_ISSUE(i_)                                                                                       \
     {                                                                                                            \
         LLDWT_LB_COORDS(i_)                                                                                      \
-        tile16_issue<K>(raw, t2 + (z * C) * cs, cs, y0, x0, h, w, tid);                                          \
-        _Pragma("unroll") for (int r = 0; r < NSK; ++r) {                                                        \
-            const int i = tid + r * NT;                                                                          \
-            const int ly = i / T1W, lx = i - ly * T1W;                                                           \
-            const int gy = y0 - R + ly, gx = x0 - R + lx;                                                        \
-            const bool in = i < T1H * T1W && gy >= 0 && gy < h && gx >= 0 && gx < w;                             \
-            sk[r] = (skip + z * cs)[in ? (unsigned)(gy * w + gx) : 0u];                                          \
+        if (LLDWT_LB_INTERIOR(y0, x0)) {                                                                         \
+            const int toff = y0 * w + x0;                                                                        \
+            const float* tb_ = t2 + (z * C) * cs;                                                                \
+            const float* sb_ = skip + z * cs;                                                                    \
+            _Pragma("unroll") for (int r = 0; r < Tile16<K>::NVT; ++r)                                           \
+                raw[r] = *reinterpret_cast<const f4u*>(tb_ + (unsigned)(relv[r] + toff));                        \
+            _Pragma("unroll") for (int r = 0; r < NSK; ++r) sk[r] = sb_[(unsigned)(relk[r] + toff)];             \
+        } else {                                                                                                 \
+            tile16_issue<K>(raw, t2 + (z * C) * cs, cs, y0, x0, h, w, tid);                                      \
+            _Pragma("unroll") for (int r = 0; r < NSK; ++r) {                                                    \
+                const int i = tid + r * NT;                                                                      \
+                const int ly = i / T1W, lx = i - ly * T1W;                                                       \
+                const int gy = y0 - R + ly, gx = x0 - R + lx;                                                    \
+                const bool in = i < T1H * T1W && gy >= 0 && gy < h && gx >= 0 && gx < w;                         \
+                sk[r] = (skip + z * cs)[in ? (unsigned)(gy * w + gx) : 0u];                                      \
+            }                                                                                                    \
         }                                                                                                        \
     }
 
@@ -725,7 +759,19 @@ __global__ __launch_bounds__(NT, 2) void k_lift_b_mfma(const float* __restrict__
     for (; it < ntiles; it += gridDim.x) {
         LLDWT_LB_COORDS(it)
         __syncthreads();                                   // the previous tile's LDS reads are done
-        {
+        const bool interior = LLDWT_LB_INTERIOR(y0, x0);
+        if (interior) {
+#pragma unroll
+            for (int r = 0; r < Tile16<K>::NVT; ++r)
+                if (ldsv[r] >= 0) {
+                    float2* d2 = reinterpret_cast<float2*>(t + ldsv[r]);
+                    d2[0] = float2{raw[r].x, raw[r].y};
+                    d2[1] = float2{raw[r].z, raw[r].w};
+                }
+#pragma unroll
+            for (int r = 0; r < NSK; ++r)
+                if (ldsk[r] >= 0) s_lds[ldsk[r]] = sk[r];
+        } else {
             tile16_fix_store<K, T1PS, T1W>(t, raw, t2 + (z * C) * cs, cs, y0, x0, h, w, tid);
 #pragma unroll
             for (int r = 0; r < NSK; ++r) {
@@ -747,12 +793,24 @@ __global__ __launch_bounds__(NT, 2) void k_lift_b_mfma(const float* __restrict__
         conv16_mfma_ps<K, T1PS, T1W>(t, wl, wave, lane, acc);               // + conv3(t2)
         __builtin_amdgcn_sched_barrier(0);        // keep the epilogue's address arithmetic out of the MFMA section
         {
-            float* op = t3_out + (z * C + oc) * cs;
-            LLDWT_EPI_FOR(n, gy, gx) st4_edge(op + (unsigned)(gy * w + gx), acc[n] + bv, gx, w);
+            float* op = t3_out + (z * C) * cs;
+            if (interior) {
+                // whole tile inside the image: one add per store, no bounds logic
+                const unsigned e0 = (unsigned)(oc * (int)cs + (y0 + wave * 4) * w + x0 + 4 * kk);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const floatx4 v = acc[n] + bv;
+                    *reinterpret_cast<f4u*>(op + ((n >> 1) * w + (n & 1) * 16) + e0) = f4u{v[0], v[1], v[2], v[3]};
+                }
+            } else {
+                op += oc * cs;
+                LLDWT_EPI_FOR(n, gy, gx) st4_edge(op + (unsigned)(gy * w + gx), acc[n] + bv, gx, w);
+            }
         }
     }
 #undef LLDWT_LB_COORDS
 #undef LLDWT_LB_ISSUE
+#undef LLDWT_LB_INTERIOR
 }
 
 // ---- kernel C: conv4(t3) ; dst_out = dst_in + sign*(skip + rw*net) -------------------------------------------

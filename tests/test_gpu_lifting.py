@@ -18,13 +18,15 @@ def _ops():
 
 @pytest.mark.parametrize("K", [3, 5])
 @pytest.mark.parametrize("vertical", [1, 0])
-@pytest.mark.parametrize("sign", [1.0, -1.0])
-def test_lift_step_vs_oracle(K, vertical, sign):
+@pytest.mark.parametrize("sign,hw", [(1.0, (19, 45)), (-1.0, (19, 45)), (1.0, (70, 150))])
+def test_lift_step_vs_oracle(K, vertical, sign, hw):
     ops, gu = _ops()
     cfg = dict(model.DEFAULT_CFG, filtersize=K, dwtlevels=1)
     sds = [filled(weights.autoencoder_template(cfg), "m%d." % p) for p in range(2)]
     g = torch.Generator().manual_seed(5)
-    P, B, h, w = 2, 2, 19, 45          # ragged: not multiples of the 16x32 tile
+    # 19x45: every 16x32 tile touches the border, ragged; 70x150: interior tiles (the kernels' fast path), border tiles
+    # and a ragged last row / column of tiles, several tiles per persistent workgroup
+    P, B, (h, w) = 2, 2, hw
     src = torch.rand(P, B, 1, h, w, generator=g) - 0.5
     dst = torch.rand(P, B, 1, h, w, generator=g) - 0.5
     taps, packed = gu.lifting_params(sds)
