@@ -112,6 +112,100 @@ __global__ __launch_bounds__(256) void k_subband_mlp(const float* __restrict__ x
     }
 }
 
+// MFMA version for HD == 32: the two 32x32 layers run on v_mfma_f32_16x16x4_f32 with everything in registers.
+// A wave takes 64 coefficients (4 column tiles of 16).  Layer outputs come out of the MFMA as D[row = oc][col = coef]
+// with lane (col, kk) holding rows 4kk..4kk+3 of each 16-row tile -- and that is directly usable as the NEXT layer's
+// B operand if its 8 k-steps are taken in the order (tile m', r): k index kk <-> input channel m'*16 + 4kk + r.  So the
+// weights are loaded once per wave in that permuted order (32 registers for both layers) and no activation ever goes
+// through LDS or a lane shuffle; the 1 -> 32 layer is computed straight into that layout, the 32 -> 1 layer is a dot
+// product over the lane's 8 rows plus two xor-shuffles across kk.
+typedef float floatx4m __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_subband_mlp_mfma(const float* __restrict__ x, float* __restrict__ y, int batch, int C,
+                                                          int64_t hw, const float* __restrict__ w0,
+                                                          const float* __restrict__ b0, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, const float* __restrict__ w3,
+                                                          const float* __restrict__ b3, int transposed) {
+    constexpr int HD = 32;
+    const int c = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int64_t pc = (int64_t)plane * C + c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    // A operands: A[m][q], q = (m', r): weight W[oc = m*16 + col][ic = m'*16 + 4kk + r]
+    float A1[2][8], A2[2][8], w0b[8], b0b[8], b1d[8], b2d[8], w3d[8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int oc = m * 16 + col, ic = (q >> 2) * 16 + 4 * kk + (q & 3);
+            const int64_t src = transposed ? (pc * HD + ic) * HD + oc : (pc * HD + oc) * HD + ic;
+            A1[m][q] = w1[src];
+            A2[m][q] = w2[src];
+        }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int ch = (q >> 2) * 16 + 4 * kk + (q & 3);       // the lane's 8 rows / input channels
+        w0b[q] = w0[pc * HD + ch];
+        b0b[q] = b0[pc * HD + ch];
+        b1d[q] = b1[pc * HD + ch];
+        b2d[q] = b2[pc * HD + ch];
+        w3d[q] = w3[pc * HD + ch];
+    }
+    const float bb3 = b3[pc];
+    const float* xp = x + (z * C + c) * hw;
+    float* yp = y + (z * C + c) * hw;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 64; i0 < hw; i0 += (int64_t)gridDim.x * 256) {
+        float xv[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int64_t i = i0 + n * 16 + col;
+            xv[n] = xp[i < hw ? i : 0];
+        }
+        float h[4][8];                                          // activations in B-operand layout: [column tile][q]
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[n][q] = fast_tanh(fmaf(w0b[q], xv[n], b0b[q]));
+#pragma unroll
+        for (int layer = 0; layer < 2; ++layer) {
+            floatx4m acc[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const float* bd = layer == 0 ? b1d : b2d;
+                    acc[m][n] = floatx4m{bd[m * 4 + 0], bd[m * 4 + 1], bd[m * 4 + 2], bd[m * 4 + 3]};
+                }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(layer == 0 ? A1[m][q] : A2[m][q], h[n][q], acc[m][n],
+                                                                         0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[n][m * 4 + r] = fast_tanh(acc[m][n][r]);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float o = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o = fmaf(w3d[q], h[n][q], o);
+            o += __shfl_xor(o, 16, 64);
+            o += __shfl_xor(o, 32, 64);
+            const int64_t i = i0 + n * 16 + col;
+            if (kk == 0 && i < hw) yp[i] = o + bb3;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ direct conv (reference order)
 constexpr int OCB = 8;
 __global__ __launch_bounds__(256) void k_conv_direct(const float* __restrict__ x, float* __restrict__ y,
@@ -583,7 +677,7 @@ extern "C" int lldwt_subband_mlp(const float* x, float* y, int64_t planes, int64
     int64_t gx = cdiv(hw, 256);
     if (gx > 1024) gx = 1024;
     dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
-    hipLaunchKernelGGL((k_subband_mlp<32>), grid, dim3(256), 0, (hipStream_t)stream, x, y, (int)batch, C, hw, w0, b0, w1, b1,
+    hipLaunchKernelGGL(k_subband_mlp_mfma, grid, dim3(256), 0, (hipStream_t)stream, x, y, (int)batch, C, hw, w0, b0, w1, b1,
                        w2, b2, w3, b3, transposed);
     return check_launch("subband_mlp");
 }
