@@ -709,22 +709,6 @@ static int launch_wgrad1x1(const W1Args& a, int planes, hipStream_t st) {
     return check_launch("conv2d_wgrad");
 }
 
-// dbias[plane][oc] += sum over batch, pixels of dy (read through the output placement)
-__global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dy, float* __restrict__ db, lldwt_conv_desc d,
-                                                   int batch, int64_t hw, float alpha) {
-    __shared__ float part[4];
-    const int oc = blockIdx.x, plane = blockIdx.z, b = blockIdx.y;
-    const int ocp = (oc / d.oc_block) * d.oc_stride + d.oc_off + oc % d.oc_block;
-    const float* p = dy + (((int64_t)plane * batch + b) * d.ytot + ocp) * hw;
-    float s = 0.f;
-    for (int64_t i = threadIdx.x; i < hw; i += 256) s += p[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(db + plane * d.cout + oc, alpha * (part[0] + part[1] + part[2] + part[3]));
-}
-
 __global__ void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, int64_t n,
                           int act) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

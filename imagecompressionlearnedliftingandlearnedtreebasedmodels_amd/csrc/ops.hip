@@ -55,64 +55,8 @@ __global__ void k_ycc_to_rgb(const float* __restrict__ ycc, float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ subband MLP
-// SubbandAutoEncoder (lifting_dwt_nets.py:99-110): 1 -> HD -> HD -> HD -> 1 per coefficient, tanh between.
-template <int HD>
-__global__ __launch_bounds__(256) void k_subband_mlp(const float* __restrict__ x, float* __restrict__ y, int batch, int C,
-                                                     int64_t hw, const float* __restrict__ w0, const float* __restrict__ b0,
-                                                     const float* __restrict__ w1, const float* __restrict__ b1,
-                                                     const float* __restrict__ w2, const float* __restrict__ b2,
-                                                     const float* __restrict__ w3, const float* __restrict__ b3,
-                                                     int transposed) {
-    __shared__ float sw1[HD * HD], sw2[HD * HD], sw0[HD], sb0[HD], sb1[HD], sb2[HD], sw3[HD];
-    const int c = blockIdx.y;
-    const int64_t z = blockIdx.z;
-    const int plane = (int)(z / batch);
-    const int64_t pc = (int64_t)plane * C + c;
-    // stage this (plane, channel)'s weights as [out j][in k]
-    for (int i = threadIdx.x; i < HD * HD; i += blockDim.x) {
-        const int j = i / HD, k = i % HD;
-        const int64_t src = transposed ? (pc * HD + k) * HD + j : (pc * HD + j) * HD + k;
-        sw1[i] = w1[src];
-        sw2[i] = w2[src];
-    }
-    for (int i = threadIdx.x; i < HD; i += blockDim.x) {
-        sw0[i] = w0[pc * HD + i];          // (C*HD,1) or (C,HD): same flat index
-        sb0[i] = b0[pc * HD + i];
-        sb1[i] = b1[pc * HD + i];
-        sb2[i] = b2[pc * HD + i];
-        sw3[i] = w3[pc * HD + i];          // (C,HD) or (C*HD,1): same flat index
-    }
-    __syncthreads();
-    const float bb3 = b3[pc];
-    const float* xp = x + (z * C + c) * hw;
-    float* yp = y + (z * C + c) * hw;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = xp[i];
-        float ha[HD], hb[HD];
-#pragma unroll
-        for (int j = 0; j < HD; ++j) ha[j] = tanhf(fmaf(sw0[j], v, sb0[j]));   // (ocml tanhf measured faster here than exp2+rcp)
-#pragma unroll
-        for (int j = 0; j < HD; ++j) {
-            float a = sb1[j];
-#pragma unroll
-            for (int k = 0; k < HD; ++k) a = fmaf(sw1[j * HD + k], ha[k], a);
-            hb[j] = tanhf(a);
-        }
-#pragma unroll
-        for (int j = 0; j < HD; ++j) {
-            float a = sb2[j];
-#pragma unroll
-            for (int k = 0; k < HD; ++k) a = fmaf(sw2[j * HD + k], hb[k], a);
-            ha[j] = tanhf(a);
-        }
-        float o = bb3;
-#pragma unroll
-        for (int k = 0; k < HD; ++k) o = fmaf(sw3[k], ha[k], o);
-        yp[i] = o;
-    }
-}
-
-// MFMA version for HD == 32: the two 32x32 layers run on v_mfma_f32_16x16x4_f32 with everything in registers.
+// SubbandAutoEncoder (lifting_dwt_nets.py:99-110): 1 -> 32 -> 32 -> 32 -> 1 per coefficient, tanh between, on the matrix
+// cores: the two 32x32 layers run on v_mfma_f32_16x16x4_f32 with everything in registers.
 // A wave takes 64 coefficients (4 column tiles of 16).  Layer outputs come out of the MFMA as D[row = oc][col = coef]
 // with lane (col, kk) holding rows 4kk..4kk+3 of each 16-row tile -- and that is directly usable as the NEXT layer's
 // B operand if its 8 k-steps are taken in the order (tile m', r): k index kk <-> input channel m'*16 + 4kk + r.  So the
