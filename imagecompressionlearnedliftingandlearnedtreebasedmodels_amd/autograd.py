@@ -62,6 +62,29 @@ class GaussRateFn(torch.autograd.Function):
         return dx, dparams, None
 
 
+class SubbandMlpFn(torch.autograd.Function):
+    """SubbandAutoEncoder MLP (1 -> 32 -> 32 -> 32 -> 1 per coefficient, grouped 1x1 convs) as one forward kernel and one
+    backward-data kernel, both on the matrix cores with the activations in registers; the four weight gradients are the
+    grouped 1x1 GEMMs.  Weights in Conv2d layout: w0 (P,C*32,1,1,1), w1,w2 (P,C*32,32,1,1), w3 (P,C,32,1,1)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, w2, b2, w3, b3):
+        ctx.save_for_backward(x, w0, b0, w1, b1, w2, b2, w3)
+        return ops.subband_mlp(x, w0, b0, w1, b1, w2, b2, w3, b3, transposed=False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w0, b0, w1, b1, w2, b2, w3 = ctx.saved_tensors
+        Cc = x.shape[2]
+        gy = gy.contiguous()
+        gx, hs, ds = ops.subband_mlp_bwd(x, gy, w0, b0, w1, b1, w2, b2, w3)
+        grads = []
+        for xin, dy, w in ((x, ds[0], w0), (hs[0], ds[1], w1), (hs[1], ds[2], w2), (hs[2], gy, w3)):
+            dw, db = ops.conv2d_wgrad(xin, dy, tuple(w.shape), 1, groups=Cc)
+            grads += [dw, db]
+        return (gx, *grads)
+
+
 class CgpRateFn(torch.autograd.Function):
     """bits of the fused cgp stack (four grouped 1x1 convs + Gaussian rate, LiftingBasedDWT_net.py:282-289,360-365) with a
     fused backward: lldwt_gauss_rate_bwd -> lldwt_cgp_bwd (all four backward-data passes in one launch) -> four 1x1

@@ -150,6 +150,133 @@ __global__ __launch_bounds__(256) void k_subband_mlp_mfma(const float* __restric
     }
 }
 
+// Backward of the same MLP (training), also in registers: the forward is recomputed, then the gradient runs back through
+// the transposed 32x32 layers with the same permuted-k trick (a layer's gradient in D layout is the next MFMA's B operand).
+// Written out for the weight-gradient GEMMs (lldwt_conv2d_wgrad with groups == C): the activations h0,h1,h2 (their x
+// operands) and d0,d1,d2, the gradients at the pre-activation outputs of layers 0..2 (their dy operands), all
+// (Z, C*32, hw); gx (Z, C, hw) is the gradient at the input.  Weights in Conv2d layout (as lldwt_subband_mlp, encode).
+__global__ __launch_bounds__(256) void k_subband_mlp_bwd(const float* __restrict__ x, const float* __restrict__ gy,
+                                                         float* __restrict__ gx, float* __restrict__ h0o,
+                                                         float* __restrict__ h1o, float* __restrict__ h2o,
+                                                         float* __restrict__ d0o, float* __restrict__ d1o,
+                                                         float* __restrict__ d2o, int batch, int C, int64_t hw,
+                                                         const float* __restrict__ w0, const float* __restrict__ b0,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         const float* __restrict__ w3) {
+    constexpr int HD = 32, NC = 2;                       // NC column tiles (16 coefficients each) per wave and iteration
+    const int c = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    const int64_t pc = (int64_t)plane * C + c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    float A1[2][8], A2[2][8], A1T[2][8], A2T[2][8], w0b[8], b0b[8], b1d[8], b2d[8], w3d[8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = m * 16 + col, ch = (q >> 2) * 16 + 4 * kk + (q & 3);
+            A1[m][q] = w1[(pc * HD + row) * HD + ch];            // forward: row = oc, k <-> ic
+            A2[m][q] = w2[(pc * HD + row) * HD + ch];
+            A1T[m][q] = w1[(pc * HD + ch) * HD + row];           // backward: row = ic, k <-> oc
+            A2T[m][q] = w2[(pc * HD + ch) * HD + row];
+        }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int ch = (q >> 2) * 16 + 4 * kk + (q & 3);
+        w0b[q] = w0[pc * HD + ch];
+        b0b[q] = b0[pc * HD + ch];
+        b1d[q] = b1[pc * HD + ch];
+        b2d[q] = b2[pc * HD + ch];
+        w3d[q] = w3[pc * HD + ch];
+    }
+    const float* xp = x + (z * C + c) * hw;
+    const float* gp = gy + (z * C + c) * hw;
+    float* gxp = gx + (z * C + c) * hw;
+    const int64_t hb = (z * C + c) * (int64_t)HD * hw;      // base of this (image, channel)'s 32 hidden channels
+#define LLDWT_MLP_GEMM(OUT_, AW_, IN_, BIAS_)                                                                    \
+    {                                                                                                            \
+        floatx4m acc_[2][NC];                                                                                    \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                            \
+            _Pragma("unroll") for (int n = 0; n < NC; ++n)                                                       \
+                acc_[m][n] = floatx4m{BIAS_[m * 4 + 0], BIAS_[m * 4 + 1], BIAS_[m * 4 + 2], BIAS_[m * 4 + 3]};   \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                            \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                        \
+                _Pragma("unroll") for (int n = 0; n < NC; ++n)                                                   \
+                    acc_[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW_[m][q], IN_[n][q], acc_[m][n], 0, 0, 0); \
+        _Pragma("unroll") for (int n = 0; n < NC; ++n)                                                           \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                        \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) OUT_[n][m * 4 + r] = acc_[m][n][r];                \
+    }
+#define LLDWT_MLP_WRITE(PTR_, V_)                                                                                \
+    _Pragma("unroll") for (int n = 0; n < NC; ++n) {                                                             \
+        const int64_t i_ = i0 + n * 16 + col;                                                                    \
+        if (i_ < hw) {                                                                                           \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                        \
+                PTR_[hb + (int64_t)((q >> 2) * 16 + 4 * kk + (q & 3)) * hw + i_] = V_[n][q];                     \
+        }                                                                                                        \
+    }
+    const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NC); i0 < hw; i0 += (int64_t)gridDim.x * 4 * 16 * NC) {
+        float xv[NC], gv[NC];
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            const int64_t i = i0 + n * 16 + col;
+            xv[n] = xp[i < hw ? i : 0];
+            gv[n] = gp[i < hw ? i : 0];
+        }
+        float h0[NC][8], h1[NC][8], h2[NC][8], d[NC][8], t[NC][8];
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h0[n][q] = fast_tanh(fmaf(w0b[q], xv[n], b0b[q]));
+        LLDWT_MLP_GEMM(t, A1, h0, b1d)
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h1[n][q] = fast_tanh(t[n][q]);
+        LLDWT_MLP_GEMM(t, A2, h1, b2d)
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h2[n][q] = fast_tanh(t[n][q]);
+        LLDWT_MLP_WRITE(h0o, h0)
+        LLDWT_MLP_WRITE(h1o, h1)
+        LLDWT_MLP_WRITE(h2o, h2)
+        // y = w3 . h2 + b3  ->  d2 = w3 * gy * tanh'(pre2)
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[n][q] = w3d[q] * gv[n] * (1.f - h2[n][q] * h2[n][q]);
+        LLDWT_MLP_WRITE(d2o, d)
+        LLDWT_MLP_GEMM(t, A2T, d, zero8)
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[n][q] = t[n][q] * (1.f - h1[n][q] * h1[n][q]);
+        LLDWT_MLP_WRITE(d1o, d)
+        LLDWT_MLP_GEMM(t, A1T, d, zero8)
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[n][q] = t[n][q] * (1.f - h0[n][q] * h0[n][q]);
+        LLDWT_MLP_WRITE(d0o, d)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            float o = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o = fmaf(w0b[q], d[n][q], o);
+            o += __shfl_xor(o, 16, 64);
+            o += __shfl_xor(o, 32, 64);
+            const int64_t i = i0 + n * 16 + col;
+            if (kk == 0 && i < hw) gxp[i] = o;
+        }
+    }
+#undef LLDWT_MLP_GEMM
+#undef LLDWT_MLP_WRITE
+}
+
 // ------------------------------------------------------------------------------------------ direct conv (reference order)
 constexpr int OCB = 8;
 __global__ __launch_bounds__(256) void k_conv_direct(const float* __restrict__ x, float* __restrict__ y,
@@ -624,6 +751,23 @@ extern "C" int lldwt_subband_mlp(const float* x, float* y, int64_t planes, int64
     hipLaunchKernelGGL(k_subband_mlp_mfma, grid, dim3(256), 0, (hipStream_t)stream, x, y, (int)batch, C, hw, w0, b0, w1, b1,
                        w2, b2, w3, b3, transposed);
     return check_launch("subband_mlp");
+}
+
+extern "C" int lldwt_subband_mlp_bwd(const float* x, const float* gy, float* gx, float* h0, float* h1, float* h2, float* d0,
+                                     float* d1, float* d2, int64_t planes, int64_t batch, int C, int64_t hw, int Hd,
+                                     const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                                     const float* b2, const float* w3, void* stream) {
+    LLDWT_REQUIRE(x && gy && gx && h0 && h1 && h2 && d0 && d1 && d2 && w0 && b0 && w1 && b1 && w2 && b2 && w3,
+                  "subband_mlp_bwd: null pointer");
+    LLDWT_REQUIRE(planes > 0 && batch > 0 && C > 0 && hw > 0, "subband_mlp_bwd: bad dims");
+    LLDWT_REQUIRE(Hd == 32, "subband_mlp_bwd: hidden width %d unsupported (reference uses H=32, lifting_dwt_nets.py:98)", Hd);
+    LLDWT_REQUIRE(planes * batch <= 65535 && C <= 65535, "subband_mlp_bwd: grid too large");
+    int64_t gxn = cdiv(hw, 128);
+    if (gxn > 1024) gxn = 1024;
+    dim3 grid((unsigned)gxn, (unsigned)C, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_subband_mlp_bwd, grid, dim3(256), 0, (hipStream_t)stream, x, gy, gx, h0, h1, h2, d0, d1, d2, (int)batch,
+                       C, hw, w0, b0, w1, b1, w2, b2, w3);
+    return check_launch("subband_mlp_bwd");
 }
 
 extern "C" int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,

@@ -358,6 +358,20 @@ def _ae_train(aes, x, decode):
                 g = [s_[n + 1] for s_ in seqs]
                 t = ag.gdn_train(t, _tstack(g, lambda m: m.beta), _tstack(g, lambda m: m.gamma), decode, g[0].beta_min)
         return t
+    if seqs[0][2].in_channels // seqs[0][2].groups == 32:
+        # the reference's H = 32 (lifting_dwt_nets.py:98): one fused forward and one fused backward-data kernel
+        wb = []
+        for n in (0, 2, 4, 6):
+            layer = [s_[n] for s_ in seqs]
+            if decode:      # ConvTranspose2d (in, out/groups) -> the equivalent grouped Conv2d weight
+                G = layer[0].groups
+                cin_g, cout_g = layer[0].in_channels // G, layer[0].out_channels // G
+                wb.append(_tstack(layer, lambda m: m.weight.view(G, cin_g, cout_g).transpose(1, 2)
+                                  .reshape(G * cout_g, cin_g, 1, 1)).contiguous())
+            else:
+                wb.append(_tstack(layer, lambda m: m.weight))
+            wb.append(_tstack(layer, lambda m: m.bias))
+        return ag.SubbandMlpFn.apply(t.contiguous(), *wb)
     for n in (0, 2, 4, 6):
         act = ops.ACT_NONE if n == 6 else ops.ACT_TANH
         layer = [s_[n] for s_ in seqs]

@@ -171,6 +171,17 @@ def subband_mlp(x, w0, b0, w1, b1, w2, b2, w3, b3, transposed=False, hidden=32):
     return y
 
 
+def subband_mlp_bwd(x, gy, w0, b0, w1, b1, w2, b2, w3, hidden=32):
+    """Backward-data of the encode-layout subband MLP: -> (gx, [h0,h1,h2], [d0,d1,d2]); hidden tensors (P,B,C*hidden,h,w)."""
+    P, B, Cc, h, w = x.shape
+    gx = torch.empty_like(x)
+    hs = [torch.empty(P, B, Cc * hidden, h, w, device=x.device, dtype=torch.float32) for _ in range(6)]
+    check(_lib.load().lldwt_subband_mlp_bwd(_chk(x, "x"), _chk(gy, "gy"), _chk(gx), *[_chk(t) for t in hs], P, B, Cc, h * w,
+                                            hidden, _chk(w0), _chk(b0), _chk(w1), _chk(b1), _chk(w2), _chk(b2), _chk(w3),
+                                            _stream()), "subband_mlp_bwd")
+    return gx, hs[:3], hs[3:]
+
+
 def conv_desc(cin, cout, K, groups=1, act=ACT_NONE, upsample2=False, transposed=False, tap_mask=None, oc_block=None,
               oc_stride=0, oc_off=0, ytot=None, ic_block=0, ic_stride=0, ic_off=0, xtot=0, epi=0):
     return ConvDesc(cin, cout, K, groups, act, int(bool(upsample2)), int(bool(transposed)),

@@ -164,6 +164,14 @@ int lldwt_lift_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_
 int lldwt_subband_mlp(const float* x, float* y, int64_t planes, int64_t batch, int C, int64_t hw, int Hd,
                       const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
                       const float* b2, const float* w3, const float* b3, int transposed, void* stream);
+/* Backward of the encode-layout MLP (training; replaces autograd through lifting_dwt_nets.py:99-104 / :105-110 once the
+ * decoder's ConvTranspose2d weights are viewed in Conv2d layout): recomputes the forward, returns gx (Z,C,hw) and, for
+ * the four weight-gradient GEMMs (lldwt_conv2d_wgrad, groups == C), the activations h0,h1,h2 and the pre-activation
+ * gradients d0,d1,d2, all (Z, C*Hd, hw). */
+int lldwt_subband_mlp_bwd(const float* x, const float* gy, float* gx, float* h0, float* h1, float* h2, float* d0, float* d1,
+                          float* d2, int64_t planes, int64_t batch, int C, int64_t hw, int Hd, const float* w0,
+                          const float* b0, const float* w1, const float* b1, const float* w2, const float* b2,
+                          const float* w3, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * General conv layer for the context models and the Berk auto-encoder

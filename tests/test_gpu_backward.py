@@ -147,6 +147,36 @@ def test_cgp_fused_forward_backward(dims, hw):
             assert maxdiff(a.grad[p].cpu(), b.grad) < 5e-4 * scale, name
 
 
+@pytest.mark.parametrize("C,hw", [(3, (7, 19)), (1, (16, 40))])
+def test_subband_mlp_fused_forward_backward(C, hw):
+    """SubbandMlpFn (in-register MFMA MLP, forward and backward-data, + grouped 1x1 weight gradients) vs torch autograd:
+    ragged coefficient counts (not multiples of the 32/64-coefficient wave tiles), 1 and 3 channels."""
+    ag, ops, gu = _mods()
+    g = torch.Generator().manual_seed(40 + C)
+    P, B, H = 2, 2, 32
+    h, w = hw
+    x = torch.randn(P, B, C, h, w, generator=g)
+    shapes = [(C * H, 1), (C * H, H), (C * H, H), (C, H)]
+    ws = [torch.randn(P, o, i, 1, 1, generator=g) * (1.2 / i ** 0.5) for o, i in shapes]
+    bs = [torch.randn(P, o, generator=g) * 0.2 for o, _ in shapes]
+    gy = torch.randn(P, B, C, h, w, generator=g)
+    dv = [gu.dev(t).requires_grad_(True) for t in [x] + [t for pair in zip(ws, bs) for t in pair]]
+    y = ag.SubbandMlpFn.apply(*dv)
+    y.backward(gu.dev(gy))
+    for p in range(P):
+        rv = [t[p].clone().requires_grad_(True) for t in [x] + [t for pair in zip(ws, bs) for t in pair]]
+        t = rv[0]
+        for l in range(4):
+            t = F.conv2d(t, rv[1 + 2 * l], rv[2 + 2 * l], groups=C)
+            if l < 3:
+                t = torch.tanh(t)
+        assert maxdiff(y[p].detach().cpu(), t) < 2e-5
+        t.backward(gy[p])
+        for i, (a, b) in enumerate(zip(dv, rv)):
+            scale = max(1.0, float(b.grad.abs().max()))
+            assert maxdiff(a.grad[p].cpu(), b.grad) < 2e-4 * scale, i
+
+
 def _lift_stacks(sds, nblocks, gu):
     """oracle per-plane state dicts -> taps (4,P,3) and the 8 stacked tensors (nblocks,2,P,...) on the device."""
     taps = torch.stack([torch.stack([sd["preProcessingList.%d.weight" % j].reshape(3) for sd in sds], 0) for j in range(4)], 0)
