@@ -191,20 +191,31 @@ __device__ __forceinline__ void cgp_hidden(float* __restrict__ buf, const float*
     __syncthreads();
 }
 
+// Optional folded context (eval): the masked csc conv (LiftingBasedDWT_net.py:275-277,353) feeds the first cgp layer with
+// no nonlinearity in between, so W0[:, csc half] . Wcsc is folded on the host into 12 extra columns of layer 0 whose
+// inputs are the live taps of the quantised subband itself -- gathered here, straight from the 1-channel image.  Rows
+// 0..cplc-1 of the column then come from the plc tensor, rows cplc..cplc+npatch-1 from xq at (y + dy - R, x + dx - R).
+struct CgpCtx {
+    const float* xq;     // (Z, groups, h, w) quantised coefficients, or null: all c0 rows come from `cat`
+    int cplc, npatch, w, R;
+    int8_t tdy[16], tdx[16];
+};
 constexpr int CGP_ROWS_MAX = 164;                         // input channels per group supported by the register prefetch
-constexpr int CGP_NIN = CGP_ROWS_MAX * CGP_PX / 256;      // input floats staged per thread
+constexpr int CGP_NIN = CGP_ROWS_MAX * CGP_PX / 256;      // input floats staged per thread (full-width column)
+constexpr int CGP_NIN_SMALL = 96 * CGP_PX / 256;          // ... when the input column has <= 96 rows (folded context)
 constexpr int CGP_TILES_PER_WG = 8;                       // consecutive 64-pixel columns per workgroup
 
 // Persistent over CGP_TILES_PER_WG consecutive pixel columns: the next column's input is prefetched into registers
 // while the matrix work of the current one runs (issue early / write late), so HBM latency never parks the waves.
-template <bool TRAIN>      // TRAIN: also write the hidden activations (kept out of the eval kernel: the extra pointers spill)
+template <bool TRAIN, int NIN>  // TRAIN: also write the hidden activations (kept out of the eval kernel: the extra pointers
+                                // spill); NIN: input rows staged per thread (rows / 4 waves)
 __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ cat, const float* __restrict__ x,
                                                   const float* __restrict__ noise, const float* __restrict__ packed,
                                                   float* __restrict__ bits, float* __restrict__ params_out,
                                                   double* __restrict__ bit_sum, CgpDims d, int groups, int batch,
                                                   int64_t hw, float* __restrict__ h1, float* __restrict__ h2,
-                                                  float* __restrict__ h3) {
-    extern __shared__ __attribute__((aligned(16))) float buf[];     // [roundup(C0,4)][CGP_PS] + sigma/mu [2][64]
+                                                  float* __restrict__ h3, CgpCtx cx, int rows_max) {
+    extern __shared__ __attribute__((aligned(16))) float buf[];     // [rows_max][CGP_PS] + sigma/mu [2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.y;
     const int64_t z = blockIdx.z;
@@ -212,8 +223,11 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
     const float* pk = packed + ((int64_t)plane * groups + g) * d.group_floats;
     const int C0 = d.c[0];
     const int rows0 = (C0 + 1 + 3) & ~3;                            // + the constant-1 row that carries the biases
-    float* sm = buf + rows0 * CGP_PS;                               // sigma[64], mu[64]
-    const float* src = cat + (z * (int64_t)groups * C0 + (int64_t)g * C0) * hw;
+    float* sm = buf + rows_max * CGP_PS;                            // sigma[64], mu[64]
+    const int cplc = cx.xq ? cx.cplc : C0;                          // rows that come from `cat`
+    const float* src = cat + (z * (int64_t)groups * cplc + (int64_t)g * cplc) * hw;
+    const float* xqg = cx.xq ? cx.xq + (z * groups + g) * hw : src;
+    const int h_img = cx.xq ? (int)(hw / cx.w) : 1;
     // training: hidden activations of this (image, group) in the layout of the unfused convs
     float* h1g = TRAIN ? h1 + (z * groups + g) * (int64_t)d.c[1] * hw : nullptr;
     float* h2g = TRAIN ? h2 + (z * groups + g) * (int64_t)d.c[2] * hw : nullptr;
@@ -223,16 +237,28 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
     // this thread stages channels c0, c0+4, ...: c0 = wave id is wave-uniform -> row bases live in SGPRs
     const int p = tid & (CGP_PX - 1), c0 = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    float xin[CGP_NIN];
+    float xin[NIN];
+    // patch rows: is tap (row c) of pixel pp inside the image?  (recomputed at the LDS store: the load is raw)
+#define LLDWT_CGP_PATCH(pp_, c_, ok_, off_)                                                          \
+    const int t_ = (c_) - cplc;                                                                      \
+    const int py_ = (pp_) / cx.w, px_ = (pp_) - py_ * cx.w;                                          \
+    const int qy_ = py_ + cx.tdy[t_ & 15] - cx.R, qx_ = px_ + cx.tdx[t_ & 15] - cx.R;               \
+    const bool ok_ = (pp_) < hw && qy_ >= 0 && qy_ < h_img && qx_ >= 0 && qx_ < cx.w;                \
+    const int off_ = qy_ * cx.w + qx_;
 #define LLDWT_CGP_LOAD(TILE)                                                                         \
     {                                                                                                \
         const int pp = (int)((TILE) * CGP_PX) + p;                                                   \
-        _Pragma("unroll") for (int r = 0; r < CGP_NIN; ++r) {                                        \
+        _Pragma("unroll") for (int r = 0; r < NIN; ++r) {                                            \
             const int c = c0 + 4 * r;                                                                \
             /* raw load from a safe address; the zeroing of padding happens at the LDS store, one tile later */ \
             /* (a select here makes hipcc wait for every load in turn: 29 serialised round trips in the .s)  */ \
-            const float* row = src + (int64_t)(c < C0 ? c : 0) * hw;          /* scalar */           \
-            xin[r] = row[pp < hw ? pp : 0];                                                          \
+            if (c < cplc || c >= C0) {                                       /* wave-uniform */       \
+                const float* row = src + (int64_t)(c < cplc ? c : 0) * hw;   /* scalar */             \
+                xin[r] = row[pp < hw ? pp : 0];                                                      \
+            } else {                                                                                 \
+                LLDWT_CGP_PATCH(pp, c, ok, off)                                                      \
+                xin[r] = xqg[ok ? off : 0];                                                          \
+            }                                                                                        \
         }                                                                                            \
     }
     if (t0 < ntiles) LLDWT_CGP_LOAD(t0)
@@ -241,9 +267,21 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
         const int64_t p0 = t * CGP_PX;
         __syncthreads();                       // previous column fully consumed
 #pragma unroll
-        for (int r = 0; r < CGP_NIN; ++r) {
+        for (int r = 0; r < NIN; ++r) {
             const int c = c0 + 4 * r;
-            if (c < rows0) buf[c * CGP_PS + p] = c < C0 ? (p0 + p < hw ? xin[r] : 0.f) : (c == C0 ? 1.f : 0.f);
+            if (c < rows0) {
+                float v;
+                if (c < cplc) {
+                    v = p0 + p < hw ? xin[r] : 0.f;
+                } else if (c < C0) {
+                    LLDWT_CGP_PATCH((int)p0 + p, c, ok, off)
+                    (void)off;
+                    v = ok ? xin[r] : 0.f;
+                } else {
+                    v = c == C0 ? 1.f : 0.f;
+                }
+                buf[c * CGP_PS + p] = v;
+            }
         }
         __syncthreads();
         {
@@ -293,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_cgp_rate(const float* __restrict__ c
         }
     }
 #undef LLDWT_CGP_LOAD
+#undef LLDWT_CGP_PATCH
     if (bit_sum && wave == 1) {
         local = wave_sum(local);
         if (lane == 0) atomicAdd(bit_sum, local);
@@ -410,9 +449,8 @@ static int cgp_dims_ok(const char* who, int c0, int c1, int c2, int c3, int grou
     LLDWT_REQUIRE(groups > 0 && c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0, "%s: bad channel counts", who);
     LLDWT_REQUIRE(c1 < 64 * CGP_MAXT && c2 < 64 && c3 < 64,
                   "%s: hidden widths (%d,%d,%d) exceed the built tile plan (%d,63,63)", who, c1, c2, c3, 64 * CGP_MAXT - 1);
-    LLDWT_REQUIRE(c1 <= c0 && c2 <= c0 && c3 <= c0,
-                  "%s: hidden widths must not exceed the input width (in-place LDS column)", who);
-    LLDWT_REQUIRE(round_up(c0 + 1, 4) <= CGP_ROWS_MAX, "%s: input width %d exceeds %d", who, c0, CGP_ROWS_MAX - 1);
+    LLDWT_REQUIRE(round_up(c0 + 1, 4) <= CGP_ROWS_MAX && round_up(c1 + 1, 4) <= CGP_ROWS_MAX,
+                  "%s: widths (%d,%d) exceed the %d-row LDS column", who, c0, c1, CGP_ROWS_MAX - 1);
     return 0;
 }
 
@@ -435,15 +473,19 @@ extern "C" int lldwt_cgp_pack(const float* w0, const float* b0, const float* w1,
 
 static int cgp_rate_impl(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
                          float* params_out, float* h1, float* h2, float* h3, double* bit_sum, int64_t planes, int64_t batch,
-                         int64_t hw, int c0, int c1, int c2, int c3, int groups, void* stream) {
+                         int64_t hw, int c0, int c1, int c2, int c3, int groups, const CgpCtx& cx, void* stream) {
     int r = cgp_dims_ok("cgp_rate", c0, c1, c2, c3, groups);
     if (r) return r;
     LLDWT_REQUIRE(cat && x && packed && bits && planes > 0 && batch > 0 && hw > 0 && planes * batch <= 65535,
                   "cgp_rate: bad arguments");
     const CgpDims d = cgp_dims(c0, c1, c2, c3);
-    const size_t shmem = ((size_t)round_up(c0 + 1, 4) * CGP_PS + 2 * CGP_PX) * sizeof(float);
+    int rows_max = 4;
+    for (int l = 0; l < 4; ++l) rows_max = rows_max > (int)round_up(d.c[l] + 1, 4) ? rows_max : (int)round_up(d.c[l] + 1, 4);
+    const size_t shmem = ((size_t)rows_max * CGP_PS + 2 * CGP_PX) * sizeof(float);
     const bool train = h1 != nullptr;
-    const void* kern = train ? (const void*)k_cgp_rate<true> : (const void*)k_cgp_rate<false>;
+    const bool small = round_up(c0 + 1, 4) <= 96;
+    const void* kern = train ? (const void*)k_cgp_rate<true, CGP_NIN>
+                             : (small ? (const void*)k_cgp_rate<false, CGP_NIN_SMALL> : (const void*)k_cgp_rate<false, CGP_NIN>);
     if (shmem > 64 * 1024) {
         if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
             set_error("cgp_rate: cannot reserve %zu bytes of LDS", shmem);
@@ -452,19 +494,51 @@ static int cgp_rate_impl(const float* cat, const float* x, const float* noise, c
     }
     dim3 grid((unsigned)cdiv(cdiv(hw, CGP_PX), CGP_TILES_PER_WG), (unsigned)groups, (unsigned)(planes * batch));
     if (train)
-        hipLaunchKernelGGL(k_cgp_rate<true>, grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits,
-                           params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3);
+        hipLaunchKernelGGL((k_cgp_rate<true, CGP_NIN>), grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits,
+                           params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3, cx, rows_max);
+    else if (small)
+        hipLaunchKernelGGL((k_cgp_rate<false, CGP_NIN_SMALL>), grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise,
+                           packed, bits, params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3, cx, rows_max);
     else
-        hipLaunchKernelGGL(k_cgp_rate<false>, grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits,
-                           params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3);
+        hipLaunchKernelGGL((k_cgp_rate<false, CGP_NIN>), grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed,
+                           bits, params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3, cx, rows_max);
     return check_launch("cgp_rate");
+}
+
+static inline CgpCtx cgp_no_ctx() {
+    CgpCtx cx;
+    cx.xq = nullptr; cx.cplc = 0; cx.npatch = 0; cx.w = 1; cx.R = 0;
+    for (int i = 0; i < 16; ++i) { cx.tdy[i] = 0; cx.tdx[i] = 0; }
+    return cx;
 }
 
 extern "C" int lldwt_cgp_rate(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
                               float* params_out, double* bit_sum, int64_t planes, int64_t batch, int64_t hw, int c0,
                               int c1, int c2, int c3, int groups, void* stream) {
     return cgp_rate_impl(cat, x, noise, packed, bits, params_out, nullptr, nullptr, nullptr, bit_sum, planes, batch, hw, c0,
-                         c1, c2, c3, groups, stream);
+                         c1, c2, c3, groups, cgp_no_ctx(), stream);
+}
+
+extern "C" int lldwt_cgp_rate_ctx(const float* plc, const float* xq, const float* x, const float* noise, const float* packed,
+                                  float* bits, float* params_out, double* bit_sum, int64_t planes, int64_t batch, int64_t h,
+                                  int64_t w_, int cplc, int K, uint32_t tap_mask, int c1, int c2, int c3, int groups,
+                                  void* stream) {
+    LLDWT_REQUIRE(plc && xq && h > 0 && w_ > 0 && cplc > 0 && (K == 3 || K == 5), "cgp_rate_ctx: bad arguments");
+    LLDWT_REQUIRE(h * w_ < ((int64_t)1 << 31), "cgp_rate_ctx: image too large for 32-bit pixel offsets");
+    CgpCtx cx = cgp_no_ctx();
+    cx.xq = xq; cx.cplc = cplc; cx.w = (int)w_; cx.R = K / 2;
+    int n = 0;
+    for (int t = 0; t < K * K; ++t)
+        if ((tap_mask >> t) & 1u) {
+            LLDWT_REQUIRE(n < 16, "cgp_rate_ctx: more than 16 live taps");
+            cx.tdy[n] = (int8_t)(t / K);
+            cx.tdx[n] = (int8_t)(t % K);
+            ++n;
+        }
+    LLDWT_REQUIRE(n > 0, "cgp_rate_ctx: empty tap mask");
+    cx.npatch = n;
+    return cgp_rate_impl(plc, x, noise, packed, bits, params_out, nullptr, nullptr, nullptr, bit_sum, planes, batch, h * w_,
+                         cplc + n, c1, c2, c3, groups, cx, stream);
 }
 
 extern "C" int lldwt_cgp_rate_train(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
@@ -472,7 +546,7 @@ extern "C" int lldwt_cgp_rate_train(const float* cat, const float* x, const floa
                                     int64_t hw, int c0, int c1, int c2, int c3, int groups, void* stream) {
     LLDWT_REQUIRE(params_out && h1 && h2 && h3, "cgp_rate_train: null output");
     return cgp_rate_impl(cat, x, noise, packed, bits, params_out, h1, h2, h3, nullptr, planes, batch, hw, c0, c1, c2, c3,
-                         groups, stream);
+                         groups, cgp_no_ctx(), stream);
 }
 
 extern "C" int64_t lldwt_cgp_bwd_packed_floats(int c0, int c1, int c2, int c3, int groups) {

@@ -212,19 +212,24 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
             x = out_xo_list[i]
             P, B, so, h, w = x.shape
             xo_q = ops.quantize(x, _noise(x, training))
-            # (plc_g, csc_g) interleaved per subband g, written in place by the two producers (:357-359)
-            cat = torch.empty(P, B, 2 * so * 81, h, w, device=x.device, dtype=torch.float32)
-            _conv([l.csc_list[i] for l in layers], xo_q, out=cat, oc_block=81, oc_stride=162, oc_off=81)      # :353
             seqs = [l.plc_list[i] for l in layers]
             t = _conv([s[0] for s in seqs], parent, act=ops.ACT_LRELU, upsample2=True)                       # :348,355
-            _conv([s[2] for s in seqs], t, out=cat, oc_block=81, oc_stride=162, oc_off=0)
+            plc = _conv([s[2] for s in seqs], t)
             del t
             cg = [l.cgp_out_xo_list[i] for l in layers]
+            cs = [l.csc_list[i] for l in layers]
             convs = [[s[n] for s in cg] for n in (0, 2, 4, 6)]
-            packed, dims = _cache.get(("cgp", id(cg[0])), [p for layer in convs for m in layer for p in (m.weight, m.bias)],
-                                      lambda: ops.cgp_pack([_stack(layer, lambda m: m.weight) for layer in convs],
-                                                           [_stack(layer, lambda m: m.bias) for layer in convs], so))
-            bits, _ = ops.cgp_rate(cat, x, packed, dims, _noise(x, training))                                # :360-365
+            for m in cs:
+                m.apply_mask_()
+            # The masked csc conv (:275-277,353) feeds cgp layer 0 (:282) with no nonlinearity in between and the regroup
+            # (:357-359) is pure data movement, so its 81 channels per subband are folded into layer 0:
+            #   W0[:, csc half] . Wcsc -> 12 extra input columns = the live taps of the quantised subband itself,
+            # gathered inside the fused kernel.  The csc conv, its 243-channel output and half of layer 0's MACs disappear.
+            packed, dims = _cache.get(("cgp_ctx", id(cg[0])),
+                                      [p for layer in convs for m in layer for p in (m.weight, m.bias)] +
+                                      [p for m in cs for p in (m.weight, m.bias)],
+                                      lambda: _fold_csc_into_cgp(convs, cs, so))
+            bits = ops.cgp_rate_ctx(plc, xo_q, x, packed, dims, cs[0].kernel_size[0], cs[0].tap_bits(), _noise(x, training))
             si_list.append(bits)
             q_list.append(xo_q)
             parent = xo_q
@@ -398,6 +403,35 @@ def _eb_train(ebs):
     """(P,C,59) packed EntropyBottleneck parameters WITH autograd history."""
     from ...entropy_models import pack_entropy_bottleneck
     return torch.stack([pack_entropy_bottleneck(dict(e.named_parameters())) for e in ebs], 0).contiguous()
+
+
+def _fold_csc_into_cgp(convs, cs, G):
+    """(packed, dims) of the cgp stack with the masked context conv folded into layer 0 (float64 on the host, once per
+    weight version).  convs: the four cgp layers as lists over planes; cs: the csc MaskedConv2d per plane (mask applied);
+    G subbands.  Layer 0 of subband g sees [plc_g (81), csc_g (81)] (LiftingBasedDWT_net.py:357-359)."""
+    K = cs[0].kernel_size[0]
+    bits_ = cs[0].tap_bits()
+    live = [t for t in range(K * K) if (bits_ >> t) & 1]
+    w0n, b0n = [], []
+    for pl in range(len(cs)):
+        W0 = convs[0][pl].weight.detach().double()[:, :, 0, 0]          # (G*c1, 2*cpl)
+        b0 = convs[0][pl].bias.detach().double()
+        Wc = cs[pl].weight.detach().double()                            # (G*cc, 1, K, K)
+        bc = cs[pl].bias.detach().double()
+        c1 = W0.shape[0] // G
+        cc = Wc.shape[0] // G
+        cpl = W0.shape[1] - cc
+        rows_w, rows_b = [], []
+        for g in range(G):
+            W0g = W0[g * c1:(g + 1) * c1]                               # (c1, cpl + cc)
+            Wcg = Wc[g * cc:(g + 1) * cc, 0].reshape(cc, K * K)[:, live]
+            rows_w.append(torch.cat([W0g[:, :cpl], W0g[:, cpl:] @ Wcg], 1))
+            rows_b.append(b0[g * c1:(g + 1) * c1] + W0g[:, cpl:] @ bc[g * cc:(g + 1) * cc])
+        w0n.append(torch.cat(rows_w, 0).float()[:, :, None, None])
+        b0n.append(torch.cat(rows_b, 0).float())
+    ws = [torch.stack(w0n, 0).contiguous()] + [_stack(layer, lambda m: m.weight) for layer in convs[1:]]
+    bs = [torch.stack(b0n, 0).contiguous()] + [_stack(layer, lambda m: m.bias) for layer in convs[1:]]
+    return ops.cgp_pack(ws, bs, G)
 
 
 def _stack5(seqs, t):

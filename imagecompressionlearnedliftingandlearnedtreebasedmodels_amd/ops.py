@@ -357,6 +357,21 @@ def cgp_rate(cat, x, packed, dims, noise=None, want_params=False, bit_sum=None):
     return bits, params
 
 
+def cgp_rate_ctx(plc, xq, x, packed, dims, K, tap_mask, noise=None, bit_sum=None):
+    """Fused cgp stack whose first layer also holds the folded masked context conv (include/lldwt.h lldwt_cgp_rate_ctx).
+    plc (P,B,G*cplc,h,w); xq, x (P,B,G,h,w); dims = (cplc + ntaps, c1, c2, c3) as returned by cgp_pack."""
+    P, B, G, h, w = x.shape
+    ntaps = bin(tap_mask & ((1 << (K * K)) - 1)).count("1")
+    cplc = dims[0] - ntaps
+    assert plc.shape == (P, B, G * cplc, h, w) and xq.shape == x.shape
+    bits = torch.empty_like(x)
+    bs = C.c_void_p(0) if bit_sum is None else C.c_void_p(bit_sum.data_ptr())
+    check(_lib.load().lldwt_cgp_rate_ctx(_chk(plc, "plc"), _chk(xq, "xq"), _chk(x, "x"), _opt(noise), _chk(packed, "packed"),
+                                         _chk(bits), C.c_void_p(0), bs, P, B, h, w, cplc, K, int(tap_mask), dims[1], dims[2],
+                                         dims[3], G, _stream()), "cgp_rate_ctx")
+    return bits
+
+
 def cgp_rate_train(cat, x, packed, dims, noise):
     """Training forward of the fused cgp stack: -> (bits, params (P,B,2G,h,w), h1, h2, h3)."""
     P, B, G, h, w = x.shape

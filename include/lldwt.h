@@ -284,6 +284,14 @@ int lldwt_cgp_pack(const float* w0, const float* b0, const float* w1, const floa
 int lldwt_cgp_rate(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
                    float* params_out, double* bit_sum, int64_t planes, int64_t batch, int64_t hw, int c0, int c1,
                    int c2, int c3, int groups, void* stream);
+/* lldwt_cgp_rate with the masked context conv folded into its first layer (eval).  The csc conv (MaskedConv2d 5x5 type A,
+ * LiftingBasedDWT_net.py:275-277,353) feeds cgp layer 0 with no nonlinearity in between, so the host folds
+ * W0[:, csc half] . Wcsc (+ bias) into `ntaps` extra input columns of layer 0 -- packed with lldwt_cgp_pack for
+ * c0 = cplc + ntaps -- and the kernel gathers those inputs itself: the live taps (tap_mask, KxK) of the quantised
+ * subband xq (Z, groups, h, w), zero outside the image.  plc: (Z, groups*cplc, h, w), the tree-context conv's output. */
+int lldwt_cgp_rate_ctx(const float* plc, const float* xq, const float* x, const float* noise, const float* packed,
+                       float* bits, float* params_out, double* bit_sum, int64_t planes, int64_t batch, int64_t h,
+                       int64_t w_, int cplc, int K, uint32_t tap_mask, int c1, int c2, int c3, int groups, void* stream);
 /* Training variants of the fused stack.  lldwt_cgp_rate_train: as lldwt_cgp_rate (no bit_sum), and also writes
  * params_out (sigma, mu: (Z, 2*groups, hw)) and the hidden activations after LeakyReLU, h1 (Z, groups*c1, hw),
  * h2 (Z, groups*c2, hw), h3 (Z, groups*c3, hw) -- the layout the unfused 1x1 convs would produce.
