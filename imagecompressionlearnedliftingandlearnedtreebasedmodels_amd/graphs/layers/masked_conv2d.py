@@ -20,8 +20,11 @@ class MaskedConv2d(nn.Conv2d):
 
     def tap_bits(self):
         """Bit t = ky*K+kx set for live taps (the mask is identical for every (out,in) pair)."""
-        m = self.mask[0, 0].flatten().tolist()
-        return sum(1 << t for t, v in enumerate(m) if v > 0)
+        bits = getattr(self, "_tap_bits", None)
+        if bits is None:        # the mask is a constant buffer: read it back from the device once, not on every forward
+            m = self.mask[0, 0].flatten().tolist()
+            bits = self._tap_bits = sum(1 << t for t, v in enumerate(m) if v > 0)
+        return bits
 
     def apply_mask_(self):
         # the reference mutates weight.data in place on every forward (masked_conv2d.py:20).  Masking is idempotent, so
