@@ -9,6 +9,7 @@ planes and the whole batch (plane-major tensors, per-plane weights stacked), ins
 Real entropy coding (``compress`` / ``test``, :136-152,374-556) is outside the hot path.
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from ... import autograd as ag
@@ -434,6 +435,36 @@ def _fold_csc_into_cgp(convs, cs, G):
     return ops.cgp_pack(ws, bs, G)
 
 
+def _fold_csc_train(cg, cs, xq):
+    """Differentiable version of _fold_csc_into_cgp for the training path.  Returns the folded layer-0 weight
+    (P, G*c1, cpl + ntaps, 1, 1), bias (P, G*c1) and the gathered taps of xq as a (P,B,G*ntaps,h,w) tensor."""
+    for m in cs:
+        m.apply_mask_()
+    K = cs[0].kernel_size[0]
+    R = K // 2
+    bits_ = cs[0].tap_bits()
+    live = [t_ for t_ in range(K * K) if (bits_ >> t_) & 1]
+    G = cg[0][0].groups
+    W0 = _tstack([s_[0] for s_ in cg], lambda m: m.weight)[:, :, :, 0, 0]        # (P, G*c1, cpl + cc)
+    b0 = _tstack([s_[0] for s_ in cg], lambda m: m.bias)                           # (P, G*c1)
+    Wc = _tstack(cs, lambda m: m.weight)                                           # (P, G*cc, 1, K, K)
+    bc = _tstack(cs, lambda m: m.bias)                                             # (P, G*cc)
+    P = W0.shape[0]
+    c1, cc = W0.shape[1] // G, Wc.shape[1] // G
+    cpl = W0.shape[2] - cc
+    W0g = W0.reshape(P, G, c1, cpl + cc)
+    Wcg = Wc.reshape(P, G, cc, K * K)[:, :, :, live]                                # (P, G, cc, ntaps)
+    Wf = torch.matmul(W0g[..., cpl:], Wcg)                                          # (P, G, c1, ntaps)
+    w0f = torch.cat([W0g[..., :cpl], Wf], dim=3).reshape(P, G * c1, cpl + len(live), 1, 1)
+    b0f = (b0.reshape(P, G, c1) + torch.matmul(W0g[..., cpl:], bc.reshape(P, G, cc, 1))[..., 0]).reshape(P, G * c1)
+    # taps of the quantised subband, zero outside the image: patches[:, :, g*ntaps + j] = xq[:, :, g] shifted by tap j
+    Pn, B, Gx, h, w = xq.shape
+    xp = F.pad(xq, (R, R, R, R))
+    taps = [xp[:, :, :, (t_ // K):(t_ // K) + h, (t_ % K):(t_ % K) + w] for t_ in live]   # each (P,B,G,h,w)
+    patches = torch.stack(taps, dim=3).reshape(Pn, B, Gx * len(live), h, w)
+    return w0f.contiguous(), b0f.contiguous(), patches
+
+
 def _stack5(seqs, t):
     for n in (0, 2, 4, 6, 8):
         t = _tconv([s_[n] for s_ in seqs], t, ops.ACT_NONE if n == 8 else ops.ACT_LRELU)
@@ -452,17 +483,20 @@ def _entropy_train_cond2(em, out_xe, out_xo, rnd):
     parent = xo_q
     for i in range(L - 2, -1, -1):
         xo_q = ag.QuantNoiseFn.apply(out_xo[i], rnd(out_xo[i]))
-        csc = _tconv([l.csc_list[i] for l in em], xo_q)
         seqs = [l.plc_list[i] for l in em]
         plc = _tconv([s_[2] for s_ in seqs], _tconv([s_[0] for s_ in seqs], parent, ops.ACT_LRELU, upsample2=True))
-        p0, p1, p2 = plc.chunk(3, dim=2)
-        c0, c1, c2 = csc.chunk(3, dim=2)
-        t = torch.cat((p0, c0, p1, c1, p2, c2), dim=2)                    # regroup (:357-359): data movement only
         cg = [l.cgp_out_xo_list[i] for l in em]
-        wb = [p for n in (0, 2, 4, 6) for p in (_tstack([s_[n] for s_ in cg], lambda m: m.weight),
-                                                _tstack([s_[n] for s_ in cg], lambda m: m.bias))]
-        # fused cgp stack + Gaussian rate, forward and backward (the unfused 1x1 convs cost 3x the time)
-        si_list.append(ag.CgpRateFn.apply(t.contiguous(), out_xo[i], rnd(out_xo[i]), cg[0][0].groups, *wb))
+        cs = [l.csc_list[i] for l in em]
+        # Same fold as the eval path (the masked csc conv is linear into cgp layer 0), written with differentiable tensor
+        # ops on the PARAMETERS (tiny matmuls) and on the 12-tap patch gather (data movement), so autograd carries the
+        # gradients of the fused kernels back to W0, the csc weights / bias and the quantised subband by itself.
+        w0f, b0f, patches = _fold_csc_train(cg, cs, xo_q)
+        G = cg[0][0].groups
+        pl, pa = plc.chunk(G, dim=2), patches.chunk(G, dim=2)
+        t = torch.cat([z_ for g_ in range(G) for z_ in (pl[g_], pa[g_])], dim=2)      # per subband [plc_g | taps_g]
+        wb = [w0f, b0f] + [p for n in (2, 4, 6) for p in (_tstack([s_[n] for s_ in cg], lambda m: m.weight),
+                                                          _tstack([s_[n] for s_ in cg], lambda m: m.bias))]
+        si_list.append(ag.CgpRateFn.apply(t.contiguous(), out_xo[i], rnd(out_xo[i]), G, *wb))
         q_list.append(xo_q)
         parent = xo_q
     q_list.reverse()
