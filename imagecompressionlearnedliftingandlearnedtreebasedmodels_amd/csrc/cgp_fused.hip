@@ -484,24 +484,28 @@ static int cgp_rate_impl(const float* cat, const float* x, const float* noise, c
     const size_t shmem = ((size_t)rows_max * CGP_PS + 2 * CGP_PX) * sizeof(float);
     const bool train = h1 != nullptr;
     const bool small = round_up(c0 + 1, 4) <= 96;
-    const void* kern = train ? (const void*)k_cgp_rate<true, CGP_NIN>
-                             : (small ? (const void*)k_cgp_rate<false, CGP_NIN_SMALL> : (const void*)k_cgp_rate<false, CGP_NIN>);
+#define LLDWT_CGP_DISPATCH(STMT_)                                      \
+    if (train && small) { STMT_(true, CGP_NIN_SMALL) }                \
+    else if (train) { STMT_(true, CGP_NIN) }                          \
+    else if (small) { STMT_(false, CGP_NIN_SMALL) }                   \
+    else { STMT_(false, CGP_NIN) }
     if (shmem > 64 * 1024) {
-        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
-            set_error("cgp_rate: cannot reserve %zu bytes of LDS", shmem);
-            return LLDWT_EHIP;
-        }
+#define LLDWT_CGP_ATTR(T_, N_)                                                                                          \
+    if (hipFuncSetAttribute((const void*)k_cgp_rate<T_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != \
+        hipSuccess) {                                                                                                   \
+        set_error("cgp_rate: cannot reserve %zu bytes of LDS", shmem);                                                  \
+        return LLDWT_EHIP;                                                                                              \
+    }
+        LLDWT_CGP_DISPATCH(LLDWT_CGP_ATTR)
+#undef LLDWT_CGP_ATTR
     }
     dim3 grid((unsigned)cdiv(cdiv(hw, CGP_PX), CGP_TILES_PER_WG), (unsigned)groups, (unsigned)(planes * batch));
-    if (train)
-        hipLaunchKernelGGL((k_cgp_rate<true, CGP_NIN>), grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits,
-                           params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3, cx, rows_max);
-    else if (small)
-        hipLaunchKernelGGL((k_cgp_rate<false, CGP_NIN_SMALL>), grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise,
-                           packed, bits, params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3, cx, rows_max);
-    else
-        hipLaunchKernelGGL((k_cgp_rate<false, CGP_NIN>), grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed,
-                           bits, params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3, cx, rows_max);
+#define LLDWT_CGP_LAUNCH(T_, N_)                                                                                        \
+    hipLaunchKernelGGL((k_cgp_rate<T_, N_>), grid, dim3(256), shmem, (hipStream_t)stream, cat, x, noise, packed, bits,  \
+                       params_out, bit_sum, d, groups, (int)batch, hw, h1, h2, h3, cx, rows_max);
+    LLDWT_CGP_DISPATCH(LLDWT_CGP_LAUNCH)
+#undef LLDWT_CGP_LAUNCH
+#undef LLDWT_CGP_DISPATCH
     return check_launch("cgp_rate");
 }
 
