@@ -844,26 +844,32 @@ __global__ __launch_bounds__(NT) void k_lift_c(const float* __restrict__ skip, c
         }
     }
     __syncthreads();
-    const int ly = tid / TW, lx = tid % TW;
-    float a0 = pk[o.b4], a1 = pk[o.b4];
+    // a thread owns two ADJACENT pixels of one row: the K + 1 values of a kernel row serve both (6 LDS reads per 10 FMAs
+    // instead of 10; the kernel is bound by LDS reads, not by the FMAs), accumulated as one packed pair
+    typedef float floatx2c __attribute__((ext_vector_type(2)));
+    const int ly = tid / (TW / 2), lx = 2 * (tid % (TW / 2));
+    floatx2c a01 = {pk[o.b4], pk[o.b4]};
     for (int ic = 0; ic < C; ++ic) {
         const float* wi = pk + o.w4 + ic * K * K;
 #pragma unroll
-        for (int dy = 0; dy < K; ++dy)
+        for (int dy = 0; dy < K; ++dy) {
+            float v[K + 1];
+#pragma unroll
+            for (int j = 0; j < K + 1; ++j) v[j] = t[ic][ly + dy][lx + j];
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
                 const float wv = wi[dy * K + dx];
-                a0 = fmaf(wv, t[ic][ly + dy][lx + dx], a0);
-                a1 = fmaf(wv, t[ic][ly + TH / 2 + dy][lx + dx], a1);
+                a01 = __builtin_elementwise_fma(floatx2c{wv, wv}, floatx2c{v[dx], v[dx + 1]}, a01);
             }
+        }
     }
-    const int gx = x0 + lx;
-    if (gx < w) {
+    const int gy = y0 + ly;
+    if (gy < h) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int gy = y0 + ly + r * (TH / 2);
-            if (gy < h) {
-                const float net = r ? a1 : a0;
+            const int gx = x0 + lx + r;
+            if (gx < w) {
+                const float net = a01[r];
                 const float sk = skip[z * cs + (int64_t)gy * w + gx];
                 const float d = dst_in.p[z * dst_in.sz + (int64_t)gy * dst_in.sy + (int64_t)gx * dst_in.sx];
                 dst_out.p[z * dst_out.sz + (int64_t)gy * dst_out.sy + (int64_t)gx * dst_out.sx] =
@@ -1141,23 +1147,27 @@ __global__ __launch_bounds__(NT) void k_lift_bwd_a(const float* __restrict__ dr,
         }
     }
     __syncthreads();
-    const int ly = tid / TW, lx = tid % TW;
-    float a0 = 0.f, a1 = 0.f;
+    // two adjacent pixels per thread, one kernel row of K + 1 LDS values serves both (see kernel C)
+    typedef float floatx2c __attribute__((ext_vector_type(2)));
+    const int ly = tid / (TW / 2), lx = 2 * (tid % (TW / 2));
+    floatx2c a01 = {0.f, 0.f};
     for (int ic = 0; ic < C; ++ic) {
 #pragma unroll
-        for (int dy = 0; dy < K; ++dy)
+        for (int dy = 0; dy < K; ++dy) {
+            float v[K + 1];
+#pragma unroll
+            for (int j = 0; j < K + 1; ++j) v[j] = t[ic][ly + dy][lx + j];
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
                 const float wv = pk[o.w1 + (KK - 1 - (dy * K + dx)) * C + ic];     // W1[oc = ic][mirrored tap]
-                a0 = fmaf(wv, t[ic][ly + dy][lx + dx], a0);
-                a1 = fmaf(wv, t[ic][ly + TH / 2 + dy][lx + dx], a1);
+                a01 = __builtin_elementwise_fma(floatx2c{wv, wv}, floatx2c{v[dx], v[dx + 1]}, a01);
             }
+        }
     }
-    const int gx = x0 + lx;
-    if (gx < w) {
-        const int gy0 = y0 + ly, gy1 = gy0 + TH / 2;
-        if (gy0 < h) dsk[z * cs + (int64_t)gy0 * w + gx] = a0;
-        if (gy1 < h) dsk[z * cs + (int64_t)gy1 * w + gx] = a1;
+    const int gy = y0 + ly;
+    if (gy < h) {
+        if (x0 + lx < w) dsk[z * cs + (int64_t)gy * w + x0 + lx] = a01[0];
+        if (x0 + lx + 1 < w) dsk[z * cs + (int64_t)gy * w + x0 + lx + 1] = a01[1];
     }
 }
 
