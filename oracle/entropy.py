@@ -157,7 +157,7 @@ def _neg_log2(p):
 
 
 # ----------------------------------------------------------------------------- entropy layers
-def factorized_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None):
+def factorized_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None, dbg=None):
     """DWTFactorizedEntropyLayer.forward (LiftingBasedDWT_net.py:215-231)."""
     nlev = cfg["dwtlevels"]
     si_xo, q_xo = [], []
@@ -170,8 +170,11 @@ def factorized_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None
     return _neg_log2(p), si_xo, q_xe, q_xo
 
 
-def conditioned2_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None):
+def conditioned2_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None, dbg=None):
     """DWTConditioned2EntropyLayerZTsepSubbands.forward (LiftingBasedDWT_net.py:322-372).
+
+    ``dbg`` (tests only): a dict that receives the rate-domain residuals x - mu per tensor ('xe', level i), so a test can
+    tell a rounding flip of round(x - mu) (a residual within float noise of a half-integer) from a real mismatch.
 
     ``noises`` (training only, for reproducible tests): dict with 'xe': (n1, n2), 'xo': [(n1, n2)] -- n1 is the
     context/decoder sample (:330,341,352), n2 the independent sample drawn inside forward (:334,345,364)."""
@@ -187,6 +190,8 @@ def conditioned2_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=No
     xe_q = quantize(out_xe, mode, None, nz("xe", None, 0))
     ms = _csc_stack(xe_q, sd, "csc_xe.", groups=out_xe.shape[1])
     sigma, mu = ms[:, 0::2], ms[:, 1::2]
+    if dbg is not None:
+        dbg["xe"] = out_xe - mu
     _, p = gaussian_conditional_forward(out_xe, sigma, mu, training, nz("xe", None, 1))
     si_xe = _neg_log2(p)
 
@@ -195,6 +200,8 @@ def conditioned2_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=No
     xo_q = quantize(out_xo_list[i], mode, None, nz("xo", i, 0))
     ms = _csc_stack(xo_q, sd, "csc_list.%d." % i, groups=out_xo_list[i].shape[1])
     sigma, mu = ms[:, 0::2], ms[:, 1::2]
+    if dbg is not None:
+        dbg[i] = out_xo_list[i] - mu
     _, p = gaussian_conditional_forward(out_xo_list[i], sigma, mu, training, nz("xo", i, 1))
     si_list.append(_neg_log2(p))
     q_list.append(xo_q)
@@ -215,6 +222,8 @@ def conditioned2_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=No
             if n != 6:
                 t = F.leaky_relu(t, 0.01)
         sigma, mu = t[:, 0::2], t[:, 1::2]
+        if dbg is not None:
+            dbg[i] = out_xo_list[i] - mu
         _, p = gaussian_conditional_forward(out_xo_list[i], sigma, mu, training, nz("xo", i, 1))
         si_list.append(_neg_log2(p))
         q_list.append(xo_q)
@@ -224,7 +233,7 @@ def conditioned2_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=No
     return si_xe, si_list, xe_q, q_list
 
 
-def only_ezwt_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None):
+def only_ezwt_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None, dbg=None):
     """onlyEZWT.forward (LiftingBasedDWT_net.py:804-840)."""
     nlev = cfg["dwtlevels"]
     q_list, si_list = [], []
@@ -243,6 +252,8 @@ def only_ezwt_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None)
         t = F.leaky_relu(t, 0.01)
         t = F.conv2d(t, sd["plc_list.%d.4.weight" % i], sd["plc_list.%d.4.bias" % i])
         sigma, mu = t[:, 0::2], t[:, 1::2]
+        if dbg is not None:
+            dbg[i] = out_xo_list[i] - mu
         xo_q, p = gaussian_conditional_forward(out_xo_list[i], sigma, mu, training,
                                                None if noises is None else noises["xo"][i])
         si_list.append(_neg_log2(p))
@@ -264,7 +275,7 @@ def _dep_net(x, sd, prefix):
     return t
 
 
-def ztblock_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None):
+def ztblock_forward(out_xe, out_xo_list, sd, cfg, training=False, noises=None, dbg=None):
     """DWTConditioned2EntropyLayerZTBlock.forward (LiftingBasedDWT_net.py:691-757): the four polyphase phases of every
     subband are predicted in sequence from the (not upsampled) parent and the phases already coded.
     noises (training): {'xe': n, 'xo_top': n, 'xo': [[(n1,n2) per subband j] per level]}."""

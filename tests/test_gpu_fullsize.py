@@ -1,4 +1,6 @@
-"""GPU: size-independent properties at BASELINE.json's full sizes (the oracle is too slow there)."""
+"""GPU: size-independent properties at BASELINE.json's full batch sizes (perfect reconstruction, determinism, shard
+consistency, linearity).  These are self-consistency checks only -- a wrong P-block cancels in the inverse -- so VALUE
+parity at the same sizes lives in test_gpu_fullsize_oracle.py (HIP path vs the CPU oracle on the same input)."""
 import pytest
 import torch
 

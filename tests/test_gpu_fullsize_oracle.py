@@ -1,0 +1,235 @@
+"""GPU: ORACLE parity at BASELINE.json's sizes -- the HIP path and the CPU oracle on the same seeded input and weights.
+
+Why: every tile fast path only runs at real sizes (interior tiles of k_lift_b_mfma, persistent multi-tile workgroups, the
+8-wave 128-oc conv tile on a multi-tile grid, k_cgp_rate's column persistence, an L=4 pyramid); the small fixtures and the
+property tests of test_gpu_fullsize.py cannot see a wrong value there (a wrong P-block cancels in the inverse).  The
+oracle runs at ~0.3 Mpixel/s on the box's cores, i.e. a few seconds per case.
+
+Scheme (same two stages as test_gpu_model.py::test_wrapper_vs_reference):
+  (1) encode from pixels: subband coefficients within 1e-4 of the oracle's (north_star's bar);
+  (2) entropy model on the ORACLE's coefficients (identical quantisation input): per-coefficient bits within 5e-4 and the
+      estimated rate within 1e-4 relative.  round(x - mu) is discontinuous: where the oracle's residual x - mu sits within
+      1e-3 of a half-integer the two sides may legitimately round apart ("rounding flip").  Flips are COUNTED and bounded,
+      never hidden: every position whose bits differ by more than 5e-4 must be such a boundary case.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import filled, maxdiff
+from oracle import model as omodel
+from oracle import weights
+from oracle.entropy import ENTROPY_LAYERS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def natural_ish(B, H, W, seed):
+    """Seeded smooth + detail image in [0,1]: box-filtered noise (low frequencies) plus a little white noise."""
+    g = torch.Generator().manual_seed(seed)
+    r = torch.rand(B, 3, H, W, generator=g)
+    sm = F.avg_pool2d(F.pad(r, (4, 3, 4, 3), mode="replicate"), 8, stride=1)
+    sm2 = F.avg_pool2d(F.pad(r, (16, 15, 16, 15), mode="replicate"), 32, stride=1)
+    x = 0.5 + 3.0 * (sm - 0.5) + 8.0 * (sm2 - 0.5) + 0.08 * (torch.rand(B, 3, H, W, generator=g) - 0.5)
+    return x.clamp(0.0, 1.0).contiguous()
+
+
+def _net(cfg):
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import \
+        LiftingBasedDWTNetWrapper
+    net = LiftingBasedDWTNetWrapper(cfg)
+    sd = filled(weights.wrapper_template(dict(cfg)))
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected
+    return net.to(DEV).eval(), sd
+
+
+GAIN = 8.0      # stage (2) feeds BOTH entropy models the oracle's coefficients x GAIN: the deterministic by-name weights give
+                # |coefficients| < 1 (everything would quantise to 0 / +-1); the gain spreads them over ~+-6 bins so the
+                # context models see varied quantised neighbourhoods.  Stage (1) compares the unscaled coefficients.
+
+
+def _oracle(y, sd, cfg):
+    """-> per plane: (out_xe, out_xo, GAIN*out_xe, [GAIN*out_xo], si_xe, si_xo, residual dict) (rates of the scaled set)."""
+    out = []
+    with torch.no_grad():
+        for c in range(3):
+            s = omodel.sub(sd, "model%d." % c)
+            oxe, oxo = omodel.encode(y[:, c:c + 1], omodel.sub(s, "autoencoder."), dict(cfg))
+            gxe, gxo = oxe * GAIN, [t * GAIN for t in oxo]
+            dbg = {}
+            si_xe, si_xo, _, _ = ENTROPY_LAYERS[cfg["entropy_layer"]](gxe, gxo, omodel.sub(s, "entropymodel."), dict(cfg),
+                                                                     False, None, dbg=dbg)
+            out.append((oxe, oxo, gxe, gxo, si_xe, si_xo, dbg))
+    return out
+
+
+def _check_bits(name, got, ref, resid, stats):
+    """Per-coefficient bits within 5e-4, except at rounding flips (residual within 1e-3 of a half-integer)."""
+    d = (got - ref).abs()
+    bad = d > 5e-4
+    nbad = int(bad.sum())
+    stats["n"] += ref.numel()
+    if nbad:
+        assert resid is not None, "%s: %d coefficients differ by > 5e-4 (max %.3g) and the layer has no learned mean" % (
+            name, nbad, float(d.max()))
+        fr = (resid[bad] - torch.floor(resid[bad]) - 0.5).abs()
+        assert float(fr.max()) < 1e-3, "%s: bits differ at a coefficient that is NOT a rounding boundary (frac-0.5 = %.3g)" % (
+            name, float(fr.max()))
+        stats["flips"] += nbad
+        stats["flip_bits"] += float(d[bad].sum())
+    stats["sum_got"] += float(got[~bad].double().sum())
+    stats["sum_ref"] += float(ref[~bad].double().sum())
+
+
+def _parity(cfg, x, coef_tol=1e-4):
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.layers.lifting_dwt_nets import encode_planes
+    net, sd = _net(cfg)
+    L = cfg.dwtlevels
+    y = omodel.rgb2ycbcr(x) - omodel._YSHIFT
+    ora = _oracle(y, sd, cfg)
+    nets = net.nets()
+    with torch.no_grad():
+        # (1) coefficients from pixels
+        y_pm = y.permute(1, 0, 2, 3).unsqueeze(2).contiguous().to(DEV)
+        e_xe, e_xo = encode_planes([n.autoencoder for n in nets], y_pm)
+        worst = 0.0
+        quant_flips = 0
+        for c in range(3):
+            worst = max(worst, maxdiff(e_xe[c].cpu(), ora[c][0]))
+            for i in range(L):
+                worst = max(worst, maxdiff(e_xo[i][c].cpu(), ora[c][1][i]))
+                quant_flips += int((torch.round(e_xo[i][c].cpu()) != torch.round(ora[c][1][i])).sum())
+        assert worst < coef_tol, "subband coefficients differ from the oracle by %.3g" % worst
+        # (2) entropy model on the oracle's coefficients
+        oxe = torch.stack([ora[c][2] for c in range(3)], 0).to(DEV).contiguous()
+        oxo = [torch.stack([ora[c][3][i] for c in range(3)], 0).to(DEV).contiguous() for i in range(L)]
+        em = [n.entropymodel for n in nets]
+        si_xe, si_xo, _, _ = type(em[0]).forward_planes(em, oxe, oxo, False)
+        stats = {"n": 0, "flips": 0, "flip_bits": 0.0, "sum_got": 0.0, "sum_ref": 0.0}
+        for c in range(3):
+            dbg = ora[c][6]
+            _check_bits("p%d xe" % c, si_xe[c].cpu(), ora[c][4], dbg.get("xe"), stats)
+            for i in range(L):
+                _check_bits("p%d xo%d" % (c, i), si_xo[i][c].cpu(), ora[c][5][i], dbg.get(i), stats)
+    assert abs(stats["sum_got"] - stats["sum_ref"]) < 1e-4 * stats["sum_ref"], stats      # estimated rate, 1e-4 relative
+    assert stats["flips"] <= max(4, 2e-5 * stats["n"]), stats                             # flips stay a counted handful
+    assert stats["flip_bits"] < 1e-4 * stats["sum_ref"], stats                            # ... and cannot move the rate
+    print("\n[fullsize parity] %s %s: max|coef-oracle|=%.2e, round(coef) flips=%d, rate-domain flips=%d of %d, "
+          "sum bits %.1f vs %.1f" % (cfg.entropy_layer, tuple(x.shape), worst, quant_flips, stats["flips"], stats["n"],
+                                     stats["sum_got"], stats["sum_ref"]))
+    return net, sd, ora
+
+
+def _cfg(**over):
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
+    return make_config(mode="validate", **over)
+
+
+def test_cfg3_conditioned2_512_L4():
+    """BASELINE configs[2] shape (the headline): 2x3x512x512, L=4, conditioned2ZTsepSubbands."""
+    _parity(_cfg(dwtlevels=4, entropy_layer="conditioned2ZTsepSubbands"), natural_ish(2, 512, 512, 11))
+
+
+def test_cfg2_factorized_256_L3():
+    """BASELINE configs[1] shape: 2x3x256x256, L=3, factorized (fp32 storage; the bf16 variant has its own test)."""
+    _parity(_cfg(dwtlevels=3, entropy_layer="factorized"), natural_ish(2, 256, 256, 12))
+
+
+def test_cfg4_onlyezwt_1024_L4():
+    """BASELINE configs[3] shape: 1x3x1024x1024, L=4, the inter-subband tree model."""
+    _parity(_cfg(dwtlevels=4, entropy_layer="onlyEZWT"), natural_ish(1, 1024, 1024, 13))
+
+
+def test_cfg5_strip_480x2160_tree():
+    """BASELINE configs[4] geometry: one 2160(H) x 480(W) strip of a 3840-wide frame, tree model; and a strip coded
+    inside the strip batch equals the same crop run alone (strips are independent images)."""
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops, tiling
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import rate_planes
+    cfg = _cfg(dwtlevels=4, entropy_layer="onlyEZWT")
+    frame = natural_ish(1, 2160, 3840, 14)
+    strips = tiling.split_strips(frame, 8)
+    assert strips.shape == (8, 3, 2160, 480)
+    assert torch.equal(tiling.merge_strips(strips, 8), frame)
+    assert torch.equal(strips[3], frame[0, :, :, 3 * 480:4 * 480])
+    net, sd, ora = _parity(cfg, strips[3:4].contiguous())                   # oracle parity on strip 3 as a crop
+    with torch.no_grad():
+        tot, per = tiling.frame_rate_bits(net, frame.to(DEV), 8)            # all 8 strips as one batch
+        y1 = ops.rgb_to_ycc(strips[3:4].contiguous().to(DEV))
+        s_xe, s_xo = rate_planes(net.nets(), y1, False)                     # the crop alone
+    alone = float(s_xe.double().sum()) + sum(float(t.double().sum()) for t in s_xo)
+    assert abs(float(per[3]) - alone) < 1e-6 * alone
+    assert abs(float(tot) - float(per.sum())) < 1e-9 * float(tot)
+
+
+@pytest.mark.parametrize("case", [(243, 243, 3, 1, 0, None, 2, 128, 160),     # plc second conv: 8-wave tile, multi-tile grid
+                                  (3, 243, 3, 1, 2, None, 1, 128, 128),       # plc first conv on the upsampled parent
+                                  (3, 243, 5, 3, 0, "A", 2, 136, 200),        # masked 5x5 grouped
+                                  (243, 81, 3, 3, 2, "B", 2, 128, 144),       # masked 3x3 B grouped
+                                  (96, 192, 3, 1, 0, None, 1, 130, 128)])     # Berk middle layer
+def test_conv_engine_large_vs_torch(case):
+    """The MFMA conv engine on multi-tile grids (interior tiles, ragged right/bottom tiles) vs F.conv2d."""
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    from oracle import entropy
+    cin, cout, K, groups, act, mt, B, h, w = case
+    g = torch.Generator().manual_seed(1000 + cin + cout + K)
+    up = cin == 3 and K == 3
+    hi, wi = (h // 2, w // 2) if up else (h, w)
+    x = torch.rand(1, B, cin, hi, wi, generator=g) - 0.5
+    wt = (torch.rand(1, cout, cin // groups, K, K, generator=g) - 0.5) * (2.0 / (cin // groups * K * K) ** 0.5)
+    bias = torch.rand(1, cout, generator=g) - 0.5
+    bits_ = None
+    if mt:
+        m = entropy.conv_mask((cout, cin // groups, K, K), mt)
+        wt = wt * m
+        bits_ = int(sum(1 << t for t in range(K * K) if m[0, 0].flatten()[t] > 0))
+    y = ops.conv2d(x.to(DEV), wt.to(DEV), bias.to(DEV), K, groups=groups, act=act, upsample2=up, tap_mask=bits_)
+    xi = entropy.upsample2(x[0]) if up else x[0]
+    ref = F.conv2d(xi, wt[0], bias[0], padding=K // 2, groups=groups)
+    ref = F.leaky_relu(ref, 0.01) if act == 2 else ref
+    assert maxdiff(y[0].cpu(), ref) < 3e-5, case
+
+
+def test_cgp_rate_ctx_large_vs_torch():
+    """k_cgp_rate with the folded csc context on 128x192 subbands (8-column persistence, ragged last column group)
+    vs the unfused torch stack: masked 5x5 conv -> regroup -> grouped 1x1 stack -> Gaussian rate."""
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import \
+        DWTConditioned2EntropyLayerZTsepSubbands, _fold_csc_into_cgp
+    from oracle import entropy
+    cfg = _cfg(dwtlevels=2)
+    torch.manual_seed(5)
+    lay = DWTConditioned2EntropyLayerZTsepSubbands(cfg)
+    sd = filled({k: v for k, v in lay.state_dict().items() if v.dtype.is_floating_point and v.numel() > 1 and "mask" not in k})
+    lay.load_state_dict(sd, strict=False)
+    lay = lay.to(DEV).eval()
+    g = torch.Generator().manual_seed(6)
+    B, h, w = 2, 128, 200
+    plc = (torch.rand(1, B, 243, h, w, generator=g) - 0.5)
+    x = (torch.rand(1, B, 3, h, w, generator=g) - 0.5) * 9
+    xq = torch.round(x)
+    cg, cs = lay.cgp_out_xo_list[0], lay.csc_list[0]
+    cs.apply_mask_()
+    convs = [[cg[n]] for n in (0, 2, 4, 6)]
+    packed, dims = _fold_csc_into_cgp(convs, [cs], 3)
+    bits = ops.cgp_rate_ctx(plc.to(DEV), xq.to(DEV), x.to(DEV), packed, dims, 5, cs.tap_bits())
+    with torch.no_grad():
+        csc = F.conv2d(xq[0], cs.weight.cpu() * cs.mask.cpu(), cs.bias.cpu(), padding=2, groups=3)
+        p0, p1, p2 = plc[0].chunk(3, 1)
+        c0, c1, c2 = csc.chunk(3, 1)
+        t = torch.cat((p0, c0, p1, c1, p2, c2), 1)
+        for n in (0, 2, 4, 6):
+            t = F.conv2d(t, cg[n].weight.cpu(), cg[n].bias.cpu(), groups=3)
+            if n != 6:
+                t = F.leaky_relu(t, 0.01)
+        sg, mu = t[:, 0::2], t[:, 1::2]
+        _, lik = entropy.gaussian_conditional_forward(x[0], sg, mu, False)
+        ref = -torch.log2(lik)
+        resid = x[0] - mu
+    d = (bits[0].cpu() - ref).abs()
+    bad = d > 5e-4
+    if int(bad.sum()):
+        fr = (resid[bad] - torch.floor(resid[bad]) - 0.5).abs()
+        assert float(fr.max()) < 1e-3 and int(bad.sum()) < 20, (int(bad.sum()), float(fr.max()))
+    assert abs(float(bits[0].cpu()[~bad].double().sum()) - float(ref[~bad].double().sum())) < 1e-4 * float(ref.double().sum())
