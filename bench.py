@@ -1,36 +1,147 @@
 #!/usr/bin/env python
-"""bench.py -- Mpixels/s of (learned lifting DWT encode + entropy-model forward) at 512x512 RGB on MI355X.
+"""bench.py -- Mpixels/s of (lifting DWT encode + entropy-model forward) on MI355X; default = BASELINE.json configs[2].
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py                          # N=1, configs[2] (the configuration the metric is quoted on)
+    python bench.py --gpus 8                 # self-launching: spawns 8 rank processes (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --config {0,1,2,3,4}     # the other BASELINE.json configs (parity-test cases; extra bench lines)
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): learned 4-level lifting (k=5, 16 ch)
-+ SubbandAutoEncoder + conditioned2ZTsepSubbands context model, 8 x 3 x 512 x 512 per GPU, fp32, eval mode, synthetic
-inputs resident in HBM, deterministic by-name weights.  One step = RGB->YCbCr, encode (lifting + subband AE), entropy
-model forward (all context CNNs + Gaussian rate) for 3 planes, sum of bits.  N > 1: the image batch is sharded across
-ranks (weak scaling, no data-path collective on the forward path).
+One step = RGB->YCbCr, encode (DWT + subband auto-encoder), entropy-model forward (context CNNs + likelihood + -log2)
+for the 3 colour planes, sum of bits; eval mode, fp32, synthetic inputs resident in HBM, random-init weights.
+N > 1: the image batch is sharded across ranks (weak scaling, one process per GPU, no data-path collective on the
+forward path); the training leg adds ONE flat-bucket gradient all-reduce (RCCL) per step.
+
+A run with --gpus N either sees N ranks or FAILS: when WORLD_SIZE is unset and N > 1 this process (which never touches
+the GPU) launches the ranks itself; when the launcher's WORLD_SIZE differs from --gpus it exits non-zero.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA / f32 vector peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (the split-bf16 conv path issues 3 bf16 MFMAs per fp32 product)
 HBM_PEAK_GBS = 8000.0
 
+# BASELINE.json configs[i] -> the workload this repo runs for it (what differs from the BASELINE wording is stated)
+CONFIGS = {
+    0: dict(netType="CDF97", entropy_layer="factorized", levels=4, batch=1, H=256, W=256, strips=0,
+            note="configs[0] is the reference's CPU plumbing case (liftingDWT.json); the product has no CPU path, so the "
+                 "same model runs on the GPU here (HBM / launch bound)"),
+    1: dict(netType="LiftingBasedNeuralWaveletv4", entropy_layer="factorized", levels=3, batch=16, H=256, W=256, strips=0,
+            note="configs[1] names bf16 storage; this line is the fp32 path (bf16 storage is reported separately)"),
+    2: dict(netType="LiftingBasedNeuralWaveletv4", entropy_layer="conditioned2ZTsepSubbands", levels=4, batch=8, H=512,
+            W=512, strips=0, note="the configuration the metric is quoted on"),
+    3: dict(netType="LiftingBasedNeuralWaveletv4", entropy_layer="onlyEZWT", levels=4, batch=4, H=1024, W=1024, strips=0,
+            note="configs[3]: batch 32 over 8 ranks = 4 images of 1024x1024 per GPU; the training leg is the DP step"),
+    4: dict(netType="LiftingBasedNeuralWaveletv4", entropy_layer="onlyEZWT", levels=4, batch=1, H=2160, W=3840, strips=8,
+            note="configs[4]: one 3840x2160 frame per GPU cut into 8 independent 480x2160 strips (tiling.split_strips); "
+                 "fp32 storage (fp16 storage is reported separately)"),
+}
 
-def build_model(levels, device):
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the config")
+    ap.add_argument("--size", type=int, default=0, help="override: square input size")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--levels", type=int, default=0)
+    ap.add_argument("--entropy", default="", help="override entropy_layer")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-kernels", action="store_true", help="skip the secondary roofline_hbm block")
+    ap.add_argument("--train-steps", type=int, default=2,
+                    help="extra (not part of `value`): time this many full training steps (fwd + hand-written bwd + "
+                         "gradient all-reduce + Adam) on the same workload; 0 disables")
+    ap.add_argument("--plc-mode", default="", help="override LLDWT_PLC_MODE (f32 | bf16x3) for the dominant conv")
+    return ap.parse_args()
+
+
+def self_launch(a):
+    """--gpus N > 1 without a launcher: start N rank processes BEFORE anything touches the GPU, pass their output
+    through and exit with their status.  torch.cuda.device_count() does not initialise the GPU."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus:
+        print("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run fewer ranks than asked"
+              % (a.gpus, n_dev), file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("self-launch: %s" % " ".join(cmd))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def resolve_workload(a):
+    c = dict(CONFIGS[a.config])
+    explicit = []
+    if a.batch:
+        c["batch"] = a.batch
+        explicit.append("batch")
+    if a.size:
+        c["H"] = c["W"] = a.size
+        c["strips"] = 0
+        explicit.append("size")
+    if a.height:
+        c["H"] = a.height
+        explicit.append("height")
+    if a.width:
+        c["W"] = a.width
+        explicit.append("width")
+    if a.levels:
+        c["levels"] = a.levels
+        explicit.append("levels")
+    if a.entropy:
+        c["entropy_layer"] = a.entropy
+        explicit.append("entropy")
+    c["overrides"] = explicit
+    return c
+
+
+def workload_string(c, a):
+    tr = "fixed CDF 9/7 (bior4.4, periodization)" if c["netType"] == "CDF97" else \
+        "learned %d-level lifting (k=5, 16 ch)" % c["levels"]
+    if c["netType"] == "CDF97":
+        tr += " %d-level" % c["levels"]
+    if c["strips"]:
+        shape = "%d frame(s) of 3x%dx%d per GPU as %d strips of 3x%dx%d" % (
+            c["batch"], c["H"], c["W"], c["batch"] * c["strips"], c["H"], c["W"] // c["strips"])
+    else:
+        shape = "%dx3x%dx%d per GPU" % (c["batch"], c["H"], c["W"])
+    s = "BASELINE configs[%d]%s: %s + SubbandAutoEncoder + %s, %s, fp32, eval" % (
+        a.config, " with overrides (%s)" % ",".join(c["overrides"]) if c["overrides"] else "", tr, c["entropy_layer"], shape)
+    return s
+
+
+def build_model(c, device):
+    import torch
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import \
         LiftingBasedDWTNetWrapper
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
-    cfg = make_config(dwtlevels=levels, mode="validate")
+    cfg = make_config(dwtlevels=c["levels"], mode="validate", netType=c["netType"], entropy_layer=c["entropy_layer"])
     torch.manual_seed(1337)                       # random-init weights of the architecture (PyTorch default initialisers)
     net = LiftingBasedDWTNetWrapper(cfg)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}    # host copy, handed to the cpu_baseline leg only
@@ -39,6 +150,7 @@ def build_model(levels, device):
 
 def cpu_baseline(sd, cfg, size, seconds_budget=25.0):
     """Oracle (CPU port of the reference path) on a bounded sample of the same workload: 1 x 3 x size x size."""
+    import torch
     from oracle import model as omodel
     from oracle.entropy import ENTROPY_LAYERS
     cores = min(16, len(os.sched_getaffinity(0)))     # the GPU box grants a 16-core share per GPU
@@ -65,16 +177,19 @@ def cpu_baseline(sd, cfg, size, seconds_budget=25.0):
                 break
         dt = (time.perf_counter() - t0) / n
     return {"value": size * size / dt / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": "oracle (torch-CPU restatement of the reference path), 1x3x%dx%d, %d timed runs after 1 warm-up" % (size, size, n)}
+            "sample": "oracle (torch-CPU restatement of the reference path), same model, 1x3x%dx%d, %d timed runs after 1 "
+                      "warm-up" % (size, size, n)}
 
 
-def train_leg(a, dev, rank, world, x):
+def train_leg(a, c, dev, rank, world, x):
+    import torch
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.agents.liftingDWT_agent import LiftingBasedDWTAgent
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
-    cfg = make_config(dwtlevels=a.levels, mode="train", batch_size=a.batch, patch_size=a.size, seed=1337)
-    if x.shape[2] != x.shape[3] and x.numel() > 3 * 1024 * 1024 * 8:
-        return {"skipped": "training leg is sized for the square BASELINE crops"}
+    cfg = make_config(dwtlevels=c["levels"], mode="train", batch_size=x.shape[0], patch_size=x.shape[2], seed=1337,
+                      netType=c["netType"], entropy_layer=c["entropy_layer"])
+    if x.shape[0] * x.shape[2] * x.shape[3] > 8 * 1024 * 1024:
+        return {"skipped": "training leg is sized for <= 8 Mpixel per GPU per step (saved activations)"}
     torch.manual_seed(1337)
     agent = LiftingBasedDWTAgent(cfg)                     # random-init weights (same on every rank: replicated model)
     agent.model.train()
@@ -93,69 +208,141 @@ def train_leg(a, dev, rank, world, x):
     return {"ms_per_step": dt / a.train_steps * 1e3,
             "Mpixels/s": x.shape[0] * x.shape[2] * x.shape[3] * world * a.train_steps / dt / 1e6,
             "steps": a.train_steps, "loss": float(loss.detach()), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "grad_allreduce": "one flat fp32 bucket of %d floats, backend %s, world %d" % (
+                agent._bucket.flat.numel(), parallel.backend_name(), world),
             "what": "forward (noise) + hand-written backward + flat-bucket gradient all-reduce (mean over ranks) + Adam, "
                     "same workload, batch sharded over ranks"}
 
 
-def log(msg):
-    print("[bench %.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+def hbm_kernels(dev, B, S):
+    """Secondary block: the HBM-bound kernels of the path at the BASELINE batch (north_star's HBM-roofline target applies
+    to these, not to the learned transform): achieved algorithmic GB/s from HIP events on the launch stream."""
+    import torch
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.entropy_models import EntropyBottleneck
 
+    def timeit(fn, iters=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+    x = torch.rand(B, 3, S, S, device=dev)
+    npx = B * 3 * S * S
+    y = ops.rgb_to_ycc(x).reshape(1, B, 3, S, S).contiguous()
+    out = []
 
-T0 = time.perf_counter()
+    def add(name, nbytes, t, what):
+        out.append({"kernel": name, "bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "ms": t * 1e3, "algorithmic_bytes": nbytes, "what": what})
+    t = timeit(lambda: ops.cdf97_forward(y, 4))
+    add("cdf97_forward L=4 (k_cdf97_*)", 2 * npx * 4, t, "%dx3x%dx%d: read the image, write all subbands (8 B/sample)" % (B, S, S))
+    ll, yh = ops.cdf97_forward(y, 4)
+    t = timeit(lambda: ops.cdf97_inverse(ll, yh))
+    add("cdf97_inverse L=4", 2 * npx * 4, t, "same volume, inverse")
+    cf = torch.randn(3, B, 3, S // 2, S // 2, device=dev) * 3
+    prm = torch.rand(3, B, 6, S // 2, S // 2, device=dev) * 2
+    t = timeit(lambda: ops.gauss_rate(cf, prm))
+    add("k_gauss_rate", cf.numel() * 16, t, "level-0 subbands: read x, sigma, mu; write bits (16 B/coefficient)")
+    eb = torch.stack([EntropyBottleneck(3).packed() for _ in range(3)], 0).to(dev)
+    t = timeit(lambda: ops.factorized_rate(cf, eb))
+    add("k_factorized_rate", cf.numel() * 12, t, "level-0 subbands: read x; write bits and q (12 B/coefficient)")
+    t = timeit(lambda: ops.rgb_to_ycc(x))
+    add("k_rgb_to_ycc", 2 * npx * 4, t, "read RGB, write YCbCr planes")
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--height", type=int, default=0, help="non-square input (e.g. 2160 x 3840 for BASELINE configs[4]); default: --size")
-    ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--levels", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=2,
-                    help="extra (not part of `value`): time this many full training steps (fwd + hand-written bwd + "
-                         "gradient all-reduce + Adam) on the same workload; 0 disables")
-    a = ap.parse_args()
-    H_, W_ = (a.height or a.size), (a.width or a.size)
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)                                   # does not return
+    env_world = int(os.environ.get("WORLD_SIZE", 1))
+    if env_world != a.gpus:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a mislabelled line"
+              % (a.gpus, env_world), file=sys.stderr)
+        sys.exit(2)
+    if a.plc_mode:
+        os.environ["LLDWT_PLC_MODE"] = a.plc_mode
 
+    import torch
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
     rank, world, local = parallel.env_rank()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     parallel.init("nccl", dev)                               # backend "nccl" == RCCL over xGMI; no-op for N == 1
+    world_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    assert world_seen == a.gpus, (world_seen, a.gpus)
 
-    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops, tiling
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import rate_planes
-    log("building model")
-    net, sd, cfg = build_model(a.levels, dev)
-    log("model ready")
+    c = resolve_workload(a)
+    log("building model: %s" % workload_string(c, a))
+    net, sd, cfg = build_model(c, dev)
     nets = net.nets()
-    x = torch.rand(a.batch, 3, H_, W_, device=dev, generator=torch.Generator(device=dev).manual_seed(parallel.rank_seed(1337, rank)))
+    gen = torch.Generator(device=dev).manual_seed(parallel.rank_seed(1337, rank))
+    x = torch.rand(c["batch"], 3, c["H"], c["W"], device=dev, generator=gen)
+    if c["strips"]:
+        x = tiling.split_strips(x, c["strips"])              # (batch*strips, 3, H, W/strips): independent images
+    Bx, _, Hx, Wx = x.shape
     bit_acc = torch.zeros(1, dtype=torch.float64, device=dev)
 
-    # HIP events around the dominant kernel (plc second conv, 243 -> 243 3x3, LiftingBasedDWT_net.py:271-272): the
-    # kernels run on torch's current stream, which is the stream handed to the C-ABI.
-    dom = {"events": [], "flops": 0.0, "on": False}
-    conv2d_orig = ops.conv2d
-
-    def conv2d_timed(x_, w, bias, K, **kw):
-        is_dom = dom["on"] and K == 3 and w.shape[1] == 243 and w.shape[2] == 243 and not kw.get("transposed")
-        if not is_dom:
-            return conv2d_orig(x_, w, bias, K, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = conv2d_orig(x_, w, bias, K, **kw)
-        e1.record()
-        P, B, _, h, wd = x_.shape
-        dom["events"].append((e0, e1))
-        dom["flops"] += 2.0 * 243 * 243 * 9 * P * B * h * wd
-        return out
-    ops.conv2d = conv2d_timed
+    # ---- HIP events around the dominant kernel; the kernels run on torch's current stream = the stream handed to the C-ABI
+    dom = {"events": [], "work": 0.0, "on": False}
+    lifting = c["netType"] != "CDF97"
+    has_plc = c["entropy_layer"] in ("conditioned2ZTsepSubbands", "onlyEZWT")
     import imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net as M
-    M.ops.conv2d = conv2d_timed
+    import imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.layers.lifting_dwt_nets as LN
+
+    def timed(fn, work_of):
+        def wrapper(*args, **kw):
+            w = work_of(*args, **kw) if dom["on"] else None
+            if not w:
+                return fn(*args, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*args, **kw)
+            e1.record()
+            dom["events"].append((e0, e1))
+            dom["work"] += w
+            return out
+        return wrapper
+    if has_plc:
+        # plc second conv, 243 -> 243 3x3 (LiftingBasedDWT_net.py:271-272,793-795): 2*243*243*9 FLOP per output pixel
+        def plc_work(x_, w, bias, K, **kw):
+            if K == 3 and w.shape[1] == 243 and w.shape[2] == 243 and not kw.get("transposed"):
+                P, B, _, h, wd = x_.shape
+                return 2.0 * 243 * 243 * 9 * P * B * h * wd
+            return 0.0
+        wrapped = timed(ops.conv2d, plc_work)
+        ops.conv2d = wrapped
+        M.ops.conv2d = wrapped
+        roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS,
+                "kernel": "plc conv 243->243 3x3 (tree context model; the largest share of the step's FLOPs)"}
+    elif lifting:
+        # whole learned-lifting forward (all levels, the k_lift_* launches): SURVEY 8d MAC / plane-pixel x 2
+        mac = {3: 71416, 4: 72266}.get(c["levels"], 72266)
+
+        def lift_work(x_, *args, **kw):
+            P, B, _, H, W = x_.shape
+            return 2.0 * mac * P * B * H * W
+        wrapped = timed(ops.lifting_forward, lift_work)
+        ops.lifting_forward = wrapped
+        LN.ops.lifting_forward = wrapped
+        roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS,
+                "kernel": "learned lifting forward, %d levels (k_lift_* launches of one lldwt_lifting_forward call)" % c["levels"]}
+    else:
+        def cdf_work(x_, levels, **kw):
+            return 2.0 * 4 * x_.numel()                  # read the image + write all subbands
+        wrapped = timed(ops.cdf97_forward, cdf_work)
+        ops.cdf97_forward = wrapped
+        LN.ops.cdf97_forward = wrapped
+        roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "kernel": "fixed CDF 9/7 %d-level forward (k_cdf97_* launches of one call)" % c["levels"]}
 
     def step():
         with torch.no_grad():
@@ -184,43 +371,57 @@ def main():
     dt = parallel.max_over_ranks(dt, dev)                    # the slowest rank defines the step time
 
     traffic, traffic_src = None, None
-    tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath) and a.batch == 8 and a.size == 512 and a.levels == 4:
+    tpath = os.path.join(REPO, "profiles", "traffic_current.json")
+    if os.path.exists(tpath) and a.config == 2 and not c["overrides"]:
         with open(tpath) as f:
             tj = json.load(f)
-        traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
+        if tj.get("plc_mode", "f32") == ops.plc_mode():
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source")
     dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom["events"])
     n_launch = max(len(dom["events"]), 1)
-    achieved = dom["flops"] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    pixels = a.batch * H_ * W_ * world * a.steps
+    scale = 1e12 if roof["unit"] == "TFLOP/s" else 1e9
+    achieved = dom["work"] / (dom_ms * 1e-3) / scale if dom_ms > 0 else 0.0
+    pixels = Bx * Hx * Wx * world_seen * a.steps
+    roof.update({"achieved": achieved, "frac": achieved / roof["peak"], "traffic": traffic, "traffic_source": traffic_src,
+                 "avg_launch_ms": dom_ms / n_launch, "launches": len(dom["events"]),
+                 ("algorithmic_flop_per_launch" if roof["unit"] == "TFLOP/s" else "algorithmic_bytes_per_launch"):
+                     dom["work"] / n_launch})
+    if has_plc:
+        mode = ops.plc_mode()
+        roof["arithmetic"] = mode
+        if mode != "f32":
+            # the split-bf16 path issues 3 bf16 MFMAs per fp32 product: report against BOTH peaks
+            roof["peak_note"] = ("frac is against the fp32 MFMA peak (%.1f TF, the reference arithmetic's roof); "
+                                 "the kernel runs 3 bf16 MFMA products per fp32 product" % F32_MFMA_PEAK_TFLOPS)
+            roof["frac_of_bf16_peak_issued"] = 3.0 * achieved / BF16_MFMA_PEAK_TFLOPS
     out = {
         "metric": "Mpixels/sec (lifting DWT + entropy-model fwd) at 512x512 RGB",
-        "value": pixels / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": pixels / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world_seen, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: learned %d-level lifting (k=5,16ch) + SubbandAutoEncoder + "
-                               "conditioned2ZTsepSubbands, %dx3x%dx%d per GPU, eval" % (a.levels, a.batch, H_, W_),
-                   "per_gpu_batch": a.batch, "sharding": "batch over ranks, no data-path collective"},
-        "roofline": {"bound": "mfma", "kernel": "plc conv 243->243 3x3 (tree context, 61% of the step's FLOPs)",
-                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "avg_launch_ms": dom_ms / n_launch, "launches": len(dom["events"]),
-                     "algorithmic_flop_per_launch": dom["flops"] / n_launch},
+        "config": {"workload": workload_string(c, a), "note": c["note"], "per_gpu_images": Bx, "image_hw": [Hx, Wx],
+                   "sharding": "batch over ranks, no data-path collective",
+                   "backend": parallel.backend_name(), "world_size_seen": world_seen},
+        "roofline": roof,
     }
-    # ---- extra, reported beside the metric: the training step of the same workload (north_star: fwd/bwd path, batch
-    # sharded over ranks, ONE flat-bucket gradient all-reduce over RCCL per step)
     if a.train_steps > 0:
         try:
-            out["train"] = train_leg(a, dev, rank, world, x)
+            out["train"] = train_leg(a, c, dev, rank, world_seen, x)
         except Exception as e:       # never lose the metric line because of the extra leg
             out["train"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sd, cfg, min(a.size, 256))
+    if rank == 0 and not a.no_hbm_kernels:
+        try:
+            out["roofline_hbm"] = hbm_kernels(dev, 8, 512)
+        except Exception as e:
+            out["roofline_hbm"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    if rank == 0 and world_seen == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sd, cfg, min(Hx, Wx, 256))
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if world_seen > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

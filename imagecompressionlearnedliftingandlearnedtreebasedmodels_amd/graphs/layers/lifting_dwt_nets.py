@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from ... import ops
+from ...packed_cache import PackedOwnerMixin, cached
 from .P_block_v2 import P_block_v2
 from .gdn import GDN
 from .wavelet_forward_v2 import wavelet_forward_v2
@@ -38,23 +39,7 @@ def get_cdf97_filters(oned_or_twod="2D"):
 
 
 # ------------------------------------------------------------------------------------------------ parameter cache
-class _Cache:
-    """Stacked / packed device parameters, rebuilt only when a source tensor changed (version counter)."""
-
-    def __init__(self):
-        self.store = {}
-
-    def get(self, tag, tensors, build):
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
-        hit = self.store.get(tag)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        val = build()
-        self.store[tag] = (key, val)
-        return val
-
-
-_cache = _Cache()
+# stacked / packed device parameters live on the owning module (packed_cache.py): rebuilt when a source tensor changed
 
 
 def _stack(mods, get):
@@ -62,11 +47,12 @@ def _stack(mods, get):
 
 
 # ------------------------------------------------------------------------------------------------ subband auto-encoders
-class SubbandAutoEncoder(nn.Module):
+class SubbandAutoEncoder(PackedOwnerMixin, nn.Module):
     """Per-coefficient scalar MLP (grouped 1x1 convs, tanh): lifting_dwt_nets.py:82-124."""
 
     def __init__(self, in_ch):
         super().__init__()
+        self._init_packed_owner()
         iC, H = in_ch, 32
         self.in_ch, self.H = iC, H
         self.ae_down = nn.Sequential(
@@ -84,11 +70,12 @@ class SubbandAutoEncoder(nn.Module):
         return ae_planes([self], y_hat[None].contiguous(), True)[0]
 
 
-class SubbandAutoEncoderBerk(nn.Module):
+class SubbandAutoEncoderBerk(PackedOwnerMixin, nn.Module):
     """3x3 convs + GDN (lifting_dwt_nets.py:126-164)."""
 
     def __init__(self, in_ch):
         super().__init__()
+        self._init_packed_owner()
         iC, H, K, P = in_ch, 64, 3, 1
         self.in_ch = iC
         self.ae_down = nn.Sequential(
@@ -111,33 +98,35 @@ class SubbandAutoEncoderBerk(nn.Module):
 def ae_planes(aes, x, decode):
     """Run the same-shaped subband auto-encoders ``aes`` (one per plane) on x (P,B,C,h,w)."""
     seq = [(a.ae_up if decode else a.ae_down) for a in aes]
-    tag = ("ae", id(aes[0]), decode)
+    tag = ("ae", decode)
+    own = aes[0]
     if isinstance(aes[0], SubbandAutoEncoder):
         convs = [[s[n] for s in seq] for n in (0, 2, 4, 6)]
         srcs = [p for layer in convs for m in layer for p in (m.weight, m.bias)]
-        ws = _cache.get(tag, srcs, lambda: [t for layer in convs for t in (
+        ws = cached(own, tag, srcs, lambda: [t for layer in convs for t in (
             _stack(layer, lambda m: m.weight).flatten(1), _stack(layer, lambda m: m.bias))])
         return ops.subband_mlp(x, *ws, transposed=decode, hidden=aes[0].H)
     t = x
     for n in (0, 2, 4, 6):
         layer = [s[n] for s in seq]
-        w, b = _cache.get(tag + (n,), [p for m in layer for p in (m.weight, m.bias)],
+        w, b = cached(own, tag + (n,), [p for m in layer for p in (m.weight, m.bias)],
                           lambda: (_stack(layer, lambda m: m.weight), _stack(layer, lambda m: m.bias)))
         t = ops.conv2d(t, w, b, 3, transposed=decode)
         if n != 6:
             g = [s[n + 1] for s in seq]
-            beta, gamma = _cache.get(tag + (n, "g"), [p for m in g for p in (m.beta, m.gamma)],
+            beta, gamma = cached(own, tag + (n, "g"), [p for m in g for p in (m.beta, m.gamma)],
                                      lambda: (_stack(g, lambda m: m.beta), _stack(g, lambda m: m.gamma)))
             t = ops.gdn(t, beta, gamma, inverse=decode, beta_min=g[0].beta_min)
     return t
 
 
 # ------------------------------------------------------------------------------------------------ CDF 9/7 layer
-class DWTPytorchWaveletsLayer(nn.Module):
+class DWTPytorchWaveletsLayer(PackedOwnerMixin, nn.Module):
     """Fixed CDF 9/7 (bior4.4, periodization) + SubbandAutoEncoder per subband (lifting_dwt_nets.py:212-277)."""
 
     def __init__(self, config):
         super().__init__()
+        self._init_packed_owner()
         self.dwtlevels = config.dwtlevels
         self.clrch = config.clrch
         self.Yl_ae = SubbandAutoEncoder(in_ch=1 * config.clrch)
@@ -152,11 +141,12 @@ class DWTPytorchWaveletsLayer(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ learned lifting
-class LiftingBasedNeuralWaveletv4(nn.Module):
+class LiftingBasedNeuralWaveletv4(PackedOwnerMixin, nn.Module):
     """Learned lifting auto-encoder (lifting_dwt_nets.py:646-827)."""
 
     def __init__(self, config):
         super().__init__()
+        self._init_packed_owner()
         self.waveletLevel = config.dwtlevels
         self.liftingLevel = config.num_lifting_perlayer
         self.blockprop = config.block_property
@@ -241,7 +231,7 @@ def _lifting_params(nets):
             nh = _stack(nets, lambda n: lifting_coeff[4] + n.nh.reshape(()) * 0.1)
             nl = _stack(nets, lambda n: lifting_coeff[5] + n.nl.reshape(()) * 0.1)
         return taps.contiguous(), packed, nh, nl
-    return _cache.get(("lift", id(n0)), srcs, build)
+    return cached(n0, ("lift", tuple(id(n) for n in nets[1:])), srcs, build)
 
 
 def lifting_forward_planes(nets, x, levels=None, first_level=0):

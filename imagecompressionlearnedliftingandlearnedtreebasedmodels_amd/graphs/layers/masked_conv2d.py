@@ -2,11 +2,13 @@
 import torch.nn as nn
 
 from ... import ops
+from ...packed_cache import PackedOwnerMixin, invalidate_packed
 
 
-class MaskedConv2d(nn.Conv2d):
+class MaskedConv2d(PackedOwnerMixin, nn.Conv2d):
     def __init__(self, mask_type, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        self._init_packed_owner()
         assert mask_type in ("A", "B")
         self.mask_type = mask_type
         self.register_buffer("mask", self.weight.data.clone())
@@ -30,7 +32,8 @@ class MaskedConv2d(nn.Conv2d):
         # the reference mutates weight.data in place on every forward (masked_conv2d.py:20).  Masking is idempotent, so
         # it is re-applied only when the weight tensor changed since the last masking (keeps the packed-weight cache hot)
         if getattr(self, "_masked_version", None) != (self.weight.data_ptr(), self.weight._version):
-            self.weight.data *= self.mask
+            self.weight.data *= self.mask          # a .data write: no version bump -> drop this module's packs explicitly
+            invalidate_packed(self)
             self._masked_version = (self.weight.data_ptr(), self.weight._version)
 
     def forward(self, x):

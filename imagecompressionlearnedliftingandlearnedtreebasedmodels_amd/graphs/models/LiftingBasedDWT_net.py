@@ -15,7 +15,8 @@ from torch import nn
 from ... import autograd as ag
 from ... import ops
 from ...entropy_models import EntropyBottleneck, GaussianConditional
-from ..layers.lifting_dwt_nets import (DWTPytorchWaveletsLayer, LiftingBasedNeuralWaveletv4, _cache, _stack,
+from ...packed_cache import PackedOwnerMixin, cached
+from ..layers.lifting_dwt_nets import (DWTPytorchWaveletsLayer, LiftingBasedNeuralWaveletv4, _stack,
                                        decode_planes, encode_planes)
 from ..layers.masked_conv2d import MaskedConv2d
 
@@ -34,7 +35,7 @@ def _conv_params(mods, tag):
     def build():
         w = _stack(mods, lambda m: m.weight)
         return w, _stack(mods, lambda m: m.bias), ops.conv_pack(w, m0.kernel_size[0], m0.groups, tap_mask=mask), mask
-    return _cache.get(("conv", id(m0), tag), [p for m in mods for p in (m.weight, m.bias)], build)
+    return cached(m0, ("conv", tag), [p for m in mods for p in (m.weight, m.bias)], build)
 
 
 def _conv(mods, x, act=ops.ACT_NONE, upsample2=False, **kw):
@@ -57,12 +58,12 @@ def _seq_stack(seqs, x, idxs):
 
 
 def _eb_packed(ebs):
-    return _cache.get(("eb", id(ebs[0])), [p for e in ebs for p in e.parameters()],
+    return cached(ebs[0], ("eb",), [p for e in ebs for p in e.parameters()],
                       lambda: torch.stack([e.packed() for e in ebs], 0).contiguous())
 
 
 # ------------------------------------------------------------------------------------------------ entropy layers
-class _EntropyLayerBase(nn.Module):
+class _EntropyLayerBase(PackedOwnerMixin, nn.Module):
     def _level_channels(self, config):
         self.num_lifting_layers = config.dwtlevels
         assert self.num_lifting_layers > 0
@@ -82,6 +83,7 @@ class DWTFactorizedEntropyLayer(_EntropyLayerBase):
 
     def __init__(self, config):
         super().__init__()
+        self._init_packed_owner()
         self._level_channels(config)
         self.ent_out_xo_list = nn.ModuleList()
         self.scl_out_xo_list = nn.ParameterList()     # present in the reference's state_dict, unused in forward (:205-211)
@@ -117,6 +119,7 @@ class onlyEZWT(_EntropyLayerBase):
 
     def __init__(self, config):
         super().__init__()
+        self._init_packed_owner()
         self._level_channels(config)
         self.config = config
         self.plc_list = nn.ModuleList()
@@ -157,6 +160,7 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
 
     def __init__(self, config):
         super().__init__()
+        self._init_packed_owner()
         self._level_channels(config)
         self.config = config
         L = self.num_lifting_layers
@@ -226,7 +230,7 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
             # (:357-359) is pure data movement, so its 81 channels per subband are folded into layer 0:
             #   W0[:, csc half] . Wcsc -> 12 extra input columns = the live taps of the quantised subband itself,
             # gathered inside the fused kernel.  The csc conv, its 243-channel output and half of layer 0's MACs disappear.
-            packed, dims = _cache.get(("cgp_ctx", id(cg[0])),
+            packed, dims = cached(cg[0], ("cgp_ctx",),
                                       [p for layer in convs for m in layer for p in (m.weight, m.bias)] +
                                       [p for m in cs for p in (m.weight, m.bias)],
                                       lambda: _fold_csc_into_cgp(convs, cs, so))
@@ -245,6 +249,7 @@ class DWTConditioned2EntropyLayerZTBlock(_EntropyLayerBase):
 
     def __init__(self, config):
         super().__init__()
+        self._init_packed_owner()
         self._level_channels(config)
         self.dwtLevels = config.dwtlevels
         self.multiplier = 8
@@ -636,9 +641,10 @@ def rate_planes(nets, x, training=False):
     return si_xe, si_xo
 
 
-class LiftingBasedDWTNet(nn.Module):
+class LiftingBasedDWTNet(PackedOwnerMixin, nn.Module):
     def __init__(self, config):
         super().__init__()
+        self._init_packed_owner()
         self.clrch = config.clrch
         if config.netType not in _TRANSFORM:
             raise ValueError("netType %r is not on the hot path (SURVEY.md 2: BasicWavelet/AttentionWavelet* are dead "
@@ -657,9 +663,10 @@ class LiftingBasedDWTNet(nn.Module):
         return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
 
 
-class LiftingBasedDWTNetWrapper(nn.Module):
+class LiftingBasedDWTNetWrapper(PackedOwnerMixin, nn.Module):
     def __init__(self, config):
         super().__init__()
+        self._init_packed_owner()
         self.clrch = config.clrch
         if self.clrch == 3:
             self.model = LiftingBasedDWTNet(config)

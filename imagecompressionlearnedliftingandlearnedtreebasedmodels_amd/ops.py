@@ -14,6 +14,17 @@ from ._lib import (ACT_LRELU, ACT_NONE, ACT_TANH, EPI_LRELU_BWD, EPI_NONE, EPI_T
 _ws = {}
 
 
+def plc_mode():
+    """Arithmetic of the dense 243 -> 243 3x3 tree-context conv (LiftingBasedDWT_net.py:271-272): 'f32' = fp32 MFMA
+    (reference arithmetic), 'bf16x3' = split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate).
+    Environment variable LLDWT_PLC_MODE; read on every call so tests can switch it."""
+    import os
+    m = os.environ.get("LLDWT_PLC_MODE", "f32")
+    if m not in ("f32", "bf16x3"):
+        raise _lib.LLDWTError("LLDWT_PLC_MODE must be 'f32' or 'bf16x3' (got %r)" % m)
+    return m
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -27,6 +27,11 @@ def init(backend=None, device=None):
     return rank, world
 
 
+def backend_name():
+    """'nccl' (= RCCL over xGMI on ROCm), 'gloo', or 'none' when the job is a single process."""
+    return dist.get_backend() if dist.is_initialized() else "none"
+
+
 def shard_range(n_items, rank, world):
     """Contiguous shard [lo, hi) of n_items for ``rank``; sizes differ by at most one (ragged batches allowed)."""
     base, rem = divmod(n_items, world)

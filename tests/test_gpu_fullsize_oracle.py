@@ -7,8 +7,10 @@ oracle runs at ~0.3 Mpixel/s on the box's cores, i.e. a few seconds per case.
 
 Scheme (same two stages as test_gpu_model.py::test_wrapper_vs_reference):
   (1) encode from pixels: subband coefficients within 1e-4 of the oracle's (north_star's bar);
-  (2) entropy model on the ORACLE's coefficients (identical quantisation input): per-coefficient bits within 5e-4 and the
-      estimated rate within 1e-4 relative.  round(x - mu) is discontinuous: where the oracle's residual x - mu sits within
+  (2) entropy model on the ORACLE's coefficients (identical quantisation input): per-coefficient bits within
+      5e-4 + 1e-4 * bits (the relative term matters only for tail coefficients costing > 5 bits, where d bits / d sigma
+      reaches hundreds of bits per unit and the context CNN's own 1e-5 output noise is amplified) and the estimated rate
+      within 1e-4 relative.  round(x - mu) is discontinuous: where the oracle's residual x - mu sits within
       1e-3 of a half-integer the two sides may legitimately round apart ("rounding flip").  Flips are COUNTED and bounded,
       never hidden: every position whose bits differ by more than 5e-4 must be such a boundary case.
 """
@@ -66,17 +68,17 @@ def _oracle(y, sd, cfg):
 
 
 def _check_bits(name, got, ref, resid, stats):
-    """Per-coefficient bits within 5e-4, except at rounding flips (residual within 1e-3 of a half-integer)."""
+    """Per-coefficient bits within 5e-4 + 1e-4*bits, except at rounding flips (residual within 1e-3 of a half-integer)."""
     d = (got - ref).abs()
-    bad = d > 5e-4
+    bad = d > 5e-4 + 1e-4 * ref
     nbad = int(bad.sum())
     stats["n"] += ref.numel()
     if nbad:
         assert resid is not None, "%s: %d coefficients differ by > 5e-4 (max %.3g) and the layer has no learned mean" % (
             name, nbad, float(d.max()))
         fr = (resid[bad] - torch.floor(resid[bad]) - 0.5).abs()
-        assert float(fr.max()) < 1e-3, "%s: bits differ at a coefficient that is NOT a rounding boundary (frac-0.5 = %.3g)" % (
-            name, float(fr.max()))
+        assert float(fr.max()) < 1e-3, ("%s: bits differ at a coefficient that is NOT a rounding boundary (frac-0.5 = %.3g); "
+                                        "worst: d=%s ref=%s") % (name, float(fr.max()), d[bad][:8].tolist(), ref[bad][:8].tolist())
         stats["flips"] += nbad
         stats["flip_bits"] += float(d[bad].sum())
     stats["sum_got"] += float(got[~bad].double().sum())
