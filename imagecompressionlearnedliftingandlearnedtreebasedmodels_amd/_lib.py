@@ -49,6 +49,7 @@ SIGNATURES = {
     "lldwt_version": (_i, []),
     "lldwt_device_ok": (_i, []),
     "lldwt_rgb_to_ycc": (_i, [_p, _p, _i64, _i64, _i64, _p]),
+    "lldwt_u8hwc_to_f32chw": (_i, [_p, _p, _i64, _i64, _i64, _p]),
     "lldwt_ycc_to_rgb": (_i, [_p, _p, _i64, _i64, _i64, _i, _p]),
     "lldwt_pblock_packed_floats": (_i64, [_i, _i]),
     "lldwt_pack_pblock": (_i, [_p] * 9 + [_i, _i, _i, _p]),

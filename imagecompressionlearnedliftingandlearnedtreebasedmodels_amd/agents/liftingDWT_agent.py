@@ -14,33 +14,9 @@ from ..graphs.losses.rate_dist import TrainDLoss, TrainRDLoss
 from .. import autograd as ag
 from .. import parallel
 from ..graphs.models.LiftingBasedDWT_net import LiftingBasedDWTNetWrapper, forward_planes, forward_planes_train
+from ..dataloaders.image_dl import ImageDataLoader, SyntheticLoader  # noqa: F401  (SyntheticLoader: re-export)
 from ..loggers import RDLogger
 from .base import BaseAgent
-
-
-class SyntheticLoader:
-    """Stand-in for dataloaders/image_dl.py when no image folder is configured: seeded uniform RGB crops in [0,1]
-    (ToTensor range, dataloaders/image_dl.py:81), generated on the device."""
-
-    def __init__(self, n_batches, batch, size, device, seed):
-        self.n, self.b, self.s, self.dev, self.seed = n_batches, batch, size, device, seed
-
-    def __iter__(self):
-        g = torch.Generator(device=self.dev).manual_seed(self.seed)
-        for _ in range(self.n):
-            yield torch.rand(self.b, 3, self.s, self.s, device=self.dev, generator=g)
-
-    def __len__(self):
-        return self.n
-
-
-class _Loaders:
-    def __init__(self, config, device):
-        n = int(config.get("synthetic_batches", 2))
-        self.train_loader = SyntheticLoader(n, config.batch_size, config.patch_size, device, config.seed)
-        self.valid_loader = SyntheticLoader(n, config.get("val_batch_size", 1), config.get("val_patch_size", config.patch_size),
-                                            device, config.seed + 1)
-        self.test_loader = self.valid_loader
 
 
 class LiftingBasedDWTAgent(BaseAgent):
@@ -55,7 +31,7 @@ class LiftingBasedDWTAgent(BaseAgent):
                                                               threshold_mode="rel", cooldown=0, min_lr=1e-06, eps=1e-08)
         self.grad_acc_iters = config.grad_acc_iters
         self.loss_prnt_iters = config.loss_prnt_iters
-        self.data_loader = _Loaders(config, self.device)
+        self.data_loader = ImageDataLoader(config, self.device)       # folder datasets when configured, else synthetic
         self.lambda_ = config.lambda_
         self.loss_switch_thr = config.loss_switch_thr
         self.training_loss_switch = config.training_loss_switch
@@ -64,10 +40,12 @@ class LiftingBasedDWTAgent(BaseAgent):
         self.train_logger, self.trnit_logger = RDLogger(), RDLogger()
         self.aux_logger, self.valid_logger, self.test_logger = RDLogger(), RDLogger(), RDLogger()
         self._bucket = None
-        if config.mode in ("test", "validate") and "checkpoint_dir" in config:
-            self.load_checkpoint("model_best.pth.tar")
+        self.imshow_validation = False
+        if config.mode in ("test", "validate", "validate_recu_reco") and "checkpoint_dir" in config:
+            self.load_checkpoint("model_best.pth.tar")                           # :65-67
         elif config.get("resume_training") and "checkpoint_dir" in config:
-            self.load_checkpoint(config.checkpoint_file)
+            self.load_checkpoint(config.checkpoint_file)                         # :68-69
+        self.model_size_estimation()                                             # :73
 
     def batch_forward(self, x, loss_fn, clamp=False):
         """x (B,3,H,W) RGB in [0,1] -> (loss, mse, rate1, rate2, xhat)."""
@@ -104,7 +82,10 @@ class LiftingBasedDWTAgent(BaseAgent):
         return loss, mse, r1, r2
 
     def train_one_epoch(self):
-        """agents/liftingDWT_agent.py:75-111."""
+        """agents/liftingDWT_agent.py:75-111.  Data-parallel: only the gradients are all-reduced inside train_step, so
+        every decision that steers training -- the D -> RD loss switch (:104-109) and the ReduceLROnPlateau step (:111)
+        -- is taken on the MEAN OVER RANKS of the logged value; with rank-local values the replicas would run different
+        losses / learning rates and drift apart.  All ranks see the same number of batches (loader contract)."""
         self.model.train()
         for x in self.data_loader.train_loader:
             x = x.to(self.device)
@@ -114,10 +95,13 @@ class LiftingBasedDWTAgent(BaseAgent):
             self.trnit_logger(*vals)
             if (self.current_iteration + 1) % self.loss_prnt_iters == 0:
                 _, trnit_mse, _, _ = self.trnit_logger.display(lr=self.optimizer.param_groups[0]["lr"], typ="it")
+                trnit_mse, = parallel.mean_over_ranks([trnit_mse], self.device)
                 if trnit_mse < self.loss_switch_thr and self.training_loss_switch == 0:     # :104-109
                     self.train_loss = TrainRDLoss(self.lambda_)
+                    print("Switching training loss to Rate+lambda*Distortion (it was only lambda*Distortion up to here)")
                     self.training_loss_switch = 1
         train_rd_loss, _, _, _ = self.train_logger.display(lr=self.optimizer.param_groups[0]["lr"], typ="tr")
+        train_rd_loss, = parallel.mean_over_ranks([train_rd_loss], self.device)
         self.scheduler.step(train_rd_loss)                                      # :111
 
     @torch.no_grad()
@@ -133,9 +117,31 @@ class LiftingBasedDWTAgent(BaseAgent):
             r1s.append(r1.item())
             r2s.append(r2.item())
         valid_rd_loss, _, _, _ = self.valid_logger.display(lr=0.0, typ="va")
-        m = lambda v: float(torch.tensor(v).mean())
-        print(" avg_psnr = %.2f, rate_1 = %g, rate_2 = %g, total_rate = %g" % (m(psnr), m(r1s), m(r2s), m(r1s) + m(r2s)))
+        m = lambda v: float(torch.tensor(v).mean()) if v else 0.0
+        # mean over ranks: is_best / best_valid_loss (agents/base.py:161-164) must agree on every replica
+        valid_rd_loss, ps, a1, a2 = parallel.mean_over_ranks([valid_rd_loss, m(psnr), m(r1s), m(r2s)], self.device)
+        print(" avg_psnr = %.2f, rate_1 = %g, rate_2 = %g, total_rate = %g" % (ps, a1, a2, a1 + a2))
         return valid_rd_loss
+
+    def model_size_estimation(self, print_params=False):
+        """agents/liftingDWT_agent.py:313-366: parameter + buffer bytes of the model (and the post-processing net)."""
+        def size(mod):
+            ps = sum(p.nelement() * p.element_size() for p in mod.parameters())
+            bs = sum(b.nelement() * b.element_size() for b in mod.buffers())
+            if print_params:
+                for n, t in list(mod.named_parameters()) + list(mod.named_buffers()):
+                    print(n, type(t), t.size())
+            return ps, bs
+        ps, bs = size(self.model)
+        if parallel.is_rank0():
+            print(" model param+buffer=total size: %.2f+%.2f=%.2fMB" % (ps / 2 ** 20, bs / 2 ** 20, (ps + bs) / 2 ** 20))
+        post = getattr(self, "postprocess", None)
+        if post is not None:
+            pp, pb = size(post)
+            if parallel.is_rank0():
+                print(" postprocess param+buffer=total size: %.2f+%.2f=%.2fMB" % (pp / 2 ** 20, pb / 2 ** 20, (pp + pb) / 2 ** 20))
+            ps, bs = ps + pp, bs + pb
+        return ps + bs
 
     def test(self):
         raise NotImplementedError("real entropy coding (rANS, LiftingBasedDWT_net.py:458-556) is outside the hot path "

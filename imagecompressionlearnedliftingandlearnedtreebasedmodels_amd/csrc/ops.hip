@@ -34,6 +34,19 @@ __global__ void k_rgb_to_ycc(const float* __restrict__ rgb, float* __restrict__ 
     }
 }
 
+// uint8 HWC image batch (as decoded by PIL) -> float NCHW in [0,1]: torchvision ToTensor semantics (x / 255 in fp32),
+// dataloaders/image_dl.py:81.  One thread per pixel: reads 3 consecutive bytes, writes three coalesced planes.
+__global__ void k_u8hwc_to_f32chw(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t B, int64_t hw) {
+    const int64_t n = B * hw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / hw, p = i - b * hw;
+        const uint8_t* s = src + i * 3;
+        dst[(b * 3 + 0) * hw + p] = (float)s[0] / 255.0f;
+        dst[(b * 3 + 1) * hw + p] = (float)s[1] / 255.0f;
+        dst[(b * 3 + 2) * hw + p] = (float)s[2] / 255.0f;
+    }
+}
+
 __global__ void k_ycc_to_rgb(const float* __restrict__ ycc, float* __restrict__ rgb, int64_t B, int64_t hw, int clamp) {
     const int64_t n = B * hw;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -731,6 +744,11 @@ extern "C" int lldwt_rgb_to_ycc(const float* rgb, float* ycc, int64_t B, int64_t
     LLDWT_REQUIRE(rgb && ycc && B > 0 && H > 0 && W > 0, "rgb_to_ycc: bad arguments");
     hipLaunchKernelGGL(k_rgb_to_ycc, dim3(ew_grid(B * H * W)), dim3(256), 0, (hipStream_t)stream, rgb, ycc, B, H * W);
     return check_launch("rgb_to_ycc");
+}
+extern "C" int lldwt_u8hwc_to_f32chw(const uint8_t* src, float* dst, int64_t B, int64_t H, int64_t W, void* stream) {
+    LLDWT_REQUIRE(src && dst && B > 0 && H > 0 && W > 0, "u8hwc_to_f32chw: bad arguments");
+    hipLaunchKernelGGL(k_u8hwc_to_f32chw, dim3(ew_grid(B * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst, B, H * W);
+    return check_launch("u8hwc_to_f32chw");
 }
 extern "C" int lldwt_ycc_to_rgb(const float* ycc, float* rgb, int64_t B, int64_t H, int64_t W, int clamp, void* stream) {
     LLDWT_REQUIRE(rgb && ycc && B > 0 && H > 0 && W > 0, "ycc_to_rgb: bad arguments");

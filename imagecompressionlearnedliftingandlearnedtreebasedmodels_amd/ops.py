@@ -60,6 +60,17 @@ def rgb_to_ycc(x):
     return y
 
 
+def u8hwc_to_f32chw(src):
+    """(B,H,W,3) uint8 device tensor -> (B,3,H,W) fp32 in [0,1] (ToTensor semantics, dataloaders/image_dl.py:81)."""
+    if not (isinstance(src, torch.Tensor) and src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+            and src.dim() == 4 and src.shape[3] == 3):
+        raise _lib.LLDWTError("u8hwc_to_f32chw: expected a contiguous (B,H,W,3) uint8 device tensor")
+    B, H, W, _ = src.shape
+    dst = torch.empty(B, 3, H, W, device=src.device, dtype=torch.float32)
+    check(_lib.load().lldwt_u8hwc_to_f32chw(C.c_void_p(src.data_ptr()), _chk(dst), B, H, W, _stream()), "u8hwc_to_f32chw")
+    return dst
+
+
 def ycc_to_rgb(y, clamp=False):
     """plane-major (3,B,1,H,W) -> (B,3,H,W) RGB-0.5 (agents/liftingDWT_agent.py:90-94, clamp :181)."""
     lib = _lib.load()

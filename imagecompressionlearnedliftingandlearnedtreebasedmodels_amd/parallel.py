@@ -62,6 +62,30 @@ def max_over_ranks(value, device="cpu"):
     return float(t)
 
 
+def mean_over_ranks(values, device="cpu"):
+    """Mean over ranks of a few host scalars (logged means, validation loss) -> list of floats, identical on every
+    rank.  Decisions that steer training (ReduceLROnPlateau step, the D -> RD loss switch, is_best) must be taken on
+    these, never on a rank's local value, or the replicas drift apart."""
+    vals = [float(v) for v in values]
+    if not dist.is_initialized():
+        return vals
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return (t / dist.get_world_size()).tolist()
+
+
+def is_rank0():
+    return (not dist.is_initialized()) or dist.get_rank() == 0
+
+
+def broadcast_parameters(module, src=0):
+    """Make every rank's replica identical to rank ``src``'s (after a checkpoint load on rank 0, or at start-up)."""
+    if dist.is_initialized():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.numel():
+                dist.broadcast(t.data, src=src)
+
+
 def sum_over_ranks(t):
     """In-place all-reduce(sum) of a tensor (scalars that are logged, or the flat gradient bucket)."""
     if dist.is_initialized():

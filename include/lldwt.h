@@ -61,6 +61,11 @@ int lldwt_ycc_to_rgb(const float* ycc, float* rgb, int64_t B, int64_t H, int64_t
 /* backward of lldwt_ycc_to_rgb without clamp (training): grgb (B,3,H,W) -> gycc plane-major (3,B,1,H,W). */
 int lldwt_ycc_to_rgb_bwd(const float* grgb, float* gycc, int64_t B, int64_t H, int64_t W, void* stream);
 
+/* Input pipeline (dataloaders/image_dl.py:63-105: PIL decode, crop, ToTensor): the host decodes and crops to uint8
+ * HWC (3 B/pixel over PCIe instead of 12); this converts a (B,H,W,3) uint8 batch to (B,3,H,W) fp32 in [0,1] with
+ * ToTensor's arithmetic (x / 255 in fp32), bit-exact.                                                          */
+int lldwt_u8hwc_to_f32chw(const uint8_t* src, float* dst, int64_t B, int64_t H, int64_t W, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * P/U block parameters (graphs/layers/P_block_v2.py:15-33) packed for the kernels.
  * lldwt_pack_pblock: in = the four conv weights/biases of `planes` stacked blocks in PyTorch layout

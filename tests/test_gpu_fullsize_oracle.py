@@ -12,7 +12,12 @@ Scheme (same two stages as test_gpu_model.py::test_wrapper_vs_reference):
       reaches hundreds of bits per unit and the context CNN's own 1e-5 output noise is amplified) and the estimated rate
       within 1e-4 relative.  round(x - mu) is discontinuous: where the oracle's residual x - mu sits within
       1e-3 of a half-integer the two sides may legitimately round apart ("rounding flip").  Flips are COUNTED and bounded,
-      never hidden: every position whose bits differ by more than 5e-4 must be such a boundary case.
+      never hidden: every position whose bits differ by more than the tolerance must be such a boundary case.
+      onlyEZWT feeds round(x - mu) + mu of level i+1 into the tree CNN of level i (LiftingBasedDWT_net.py:832-835), so one
+      flip moves the parent by 1.0 and legitimately changes (sigma, mu) inside its receptive field one level down
+      (two 3x3 convs on the 2x-upsampled parent: 5x5 fine pixels around the 2x2 children), and so on down the pyramid.
+      Those positions ("downstream of a flip": the parents differ by > 1e-3 somewhere in the receptive field) are
+      excluded from the strict comparison, counted, and bounded to a small fraction; everything else is held to the bar.
 """
 import pytest
 import torch
@@ -61,18 +66,31 @@ def _oracle(y, sd, cfg):
             oxe, oxo = omodel.encode(y[:, c:c + 1], omodel.sub(s, "autoencoder."), dict(cfg))
             gxe, gxo = oxe * GAIN, [t * GAIN for t in oxo]
             dbg = {}
-            si_xe, si_xo, _, _ = ENTROPY_LAYERS[cfg["entropy_layer"]](gxe, gxo, omodel.sub(s, "entropymodel."), dict(cfg),
-                                                                     False, None, dbg=dbg)
+            si_xe, si_xo, _, q_xo = ENTROPY_LAYERS[cfg["entropy_layer"]](gxe, gxo, omodel.sub(s, "entropymodel."), dict(cfg),
+                                                                        False, None, dbg=dbg)
+            dbg["q"] = q_xo
             out.append((oxe, oxo, gxe, gxo, si_xe, si_xo, dbg))
     return out
 
 
-def _check_bits(name, got, ref, resid, stats):
-    """Per-coefficient bits within 5e-4 + 1e-4*bits, except at rounding flips (residual within 1e-3 of a half-integer)."""
+def _downstream(q_got, q_ref):
+    """Fine-level mask (B,1,2h,2w) of positions whose tree-CNN receptive field holds a parent that differs (> 1e-3)."""
+    bad = ((q_got - q_ref).abs() > 1e-3).any(dim=1, keepdim=True).float()
+    up = bad.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    return F.max_pool2d(up, 5, stride=1, padding=2) > 0
+
+
+def _check_bits(name, got, ref, resid, stats, skip=None):
+    """Per-coefficient bits within 5e-4 + 1e-4*bits, except at rounding flips (residual within 1e-3 of a half-integer)
+    and, for the tree model, downstream of a flip (``skip``)."""
     d = (got - ref).abs()
     bad = d > 5e-4 + 1e-4 * ref
-    nbad = int(bad.sum())
     stats["n"] += ref.numel()
+    if skip is not None:
+        skip = skip.expand_as(bad)
+        stats["downstream"] += int(skip.sum())
+        bad = bad & ~skip
+    nbad = int(bad.sum())
     if nbad:
         assert resid is not None, "%s: %d coefficients differ by > 5e-4 (max %.3g) and the layer has no learned mean" % (
             name, nbad, float(d.max()))
@@ -81,8 +99,9 @@ def _check_bits(name, got, ref, resid, stats):
                                         "worst: d=%s ref=%s") % (name, float(fr.max()), d[bad][:8].tolist(), ref[bad][:8].tolist())
         stats["flips"] += nbad
         stats["flip_bits"] += float(d[bad].sum())
-    stats["sum_got"] += float(got[~bad].double().sum())
-    stats["sum_ref"] += float(ref[~bad].double().sum())
+    keep = ~bad if skip is None else ~(bad | skip)
+    stats["sum_got"] += float(got[keep].double().sum())
+    stats["sum_ref"] += float(ref[keep].double().sum())
 
 
 def _parity(cfg, x, coef_tol=1e-4):
@@ -108,19 +127,25 @@ def _parity(cfg, x, coef_tol=1e-4):
         oxe = torch.stack([ora[c][2] for c in range(3)], 0).to(DEV).contiguous()
         oxo = [torch.stack([ora[c][3][i] for c in range(3)], 0).to(DEV).contiguous() for i in range(L)]
         em = [n.entropymodel for n in nets]
-        si_xe, si_xo, _, _ = type(em[0]).forward_planes(em, oxe, oxo, False)
-        stats = {"n": 0, "flips": 0, "flip_bits": 0.0, "sum_got": 0.0, "sum_ref": 0.0}
+        si_xe, si_xo, _, q_xo = type(em[0]).forward_planes(em, oxe, oxo, False)
+        stats = {"n": 0, "flips": 0, "flip_bits": 0.0, "sum_got": 0.0, "sum_ref": 0.0, "downstream": 0}
+        tree_feeds_means = cfg.entropy_layer == "onlyEZWT"
         for c in range(3):
             dbg = ora[c][6]
             _check_bits("p%d xe" % c, si_xe[c].cpu(), ora[c][4], dbg.get("xe"), stats)
             for i in range(L):
-                _check_bits("p%d xo%d" % (c, i), si_xo[i][c].cpu(), ora[c][5][i], dbg.get(i), stats)
+                skip = None
+                if tree_feeds_means and i < L - 1:
+                    skip = _downstream(q_xo[i + 1][c].cpu(), dbg["q"][i + 1])
+                _check_bits("p%d xo%d" % (c, i), si_xo[i][c].cpu(), ora[c][5][i], dbg.get(i), stats, skip)
     assert abs(stats["sum_got"] - stats["sum_ref"]) < 1e-4 * stats["sum_ref"], stats      # estimated rate, 1e-4 relative
     assert stats["flips"] <= max(4, 2e-5 * stats["n"]), stats                             # flips stay a counted handful
     assert stats["flip_bits"] < 1e-4 * stats["sum_ref"], stats                            # ... and cannot move the rate
-    print("\n[fullsize parity] %s %s: max|coef-oracle|=%.2e, round(coef) flips=%d, rate-domain flips=%d of %d, "
-          "sum bits %.1f vs %.1f" % (cfg.entropy_layer, tuple(x.shape), worst, quant_flips, stats["flips"], stats["n"],
-                                     stats["sum_got"], stats["sum_ref"]))
+    assert stats["downstream"] <= 0.01 * stats["n"], stats                                # tree model: < 1 % sit below a flip
+    print("\n[fullsize parity] %s %s: max|coef-oracle|=%.2e, round(coef) flips=%d, rate-domain flips=%d of %d "
+          "(%d downstream of a flip, excluded), sum bits %.1f vs %.1f" % (
+              cfg.entropy_layer, tuple(x.shape), worst, quant_flips, stats["flips"], stats["n"], stats["downstream"],
+              stats["sum_got"], stats["sum_ref"]))
     return net, sd, ora
 
 

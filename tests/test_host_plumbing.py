@@ -1,0 +1,363 @@
+"""CPU (no GPU): host logic added in round 2 -- per-module packed-parameter cache, logger / checkpoint schema compatible
+with the reference's, JSON config plumbing, the folder dataset, rank-consistent training decisions (gloo, world 2 with a
+real autograd tape through FlatGradBucket)."""
+import json
+import os
+import queue
+import socket
+import threading
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
+from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.packed_cache import cached, invalidate_packed
+
+PKG = "imagecompressionlearnedliftingandlearnedtreebasedmodels_amd"
+
+
+# ------------------------------------------------------------------------------------------------ packed cache
+def _ae():
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.layers.lifting_dwt_nets import SubbandAutoEncoder
+    return SubbandAutoEncoder(1)
+
+
+def test_packed_cache_lives_and_dies_with_the_module():
+    calls = []
+
+    def pack(m):
+        w = m.ae_down[0].weight
+        return cached(m, ("t",), [w], lambda: calls.append(1) or w.detach().clone())
+    a = _ae()
+    v1 = pack(a)
+    assert pack(a) is v1 and len(calls) == 1                         # hit
+    with torch.no_grad():
+        a.ae_down[0].weight.add_(1.0)                                # in-place, autograd-visible: version bump
+    v2 = pack(a)
+    assert len(calls) == 2 and torch.equal(v2, a.ae_down[0].weight)
+    # a .data write does NOT bump the version: stale until invalidate_packed (documented contract)
+    a.ae_down[0].weight.data.mul_(2.0)
+    assert pack(a) is v2
+    invalidate_packed(a)
+    v3 = pack(a)
+    assert len(calls) == 3 and torch.equal(v3, a.ae_down[0].weight)
+    # free + rebuild with different weights: the new module starts with an empty cache whatever id()/pointers it got
+    del a
+    for _ in range(20):
+        b = _ae()
+        n0 = len(calls)
+        vb = pack(b)
+        assert len(calls) == n0 + 1 and torch.equal(vb, b.ae_down[0].weight)
+        del b
+
+
+def test_load_state_dict_and_apply_invalidate_packs():
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.layers.masked_conv2d import MaskedConv2d
+    a = _ae()
+    calls = []
+    get = lambda: cached(a, ("t",), [a.ae_down[0].weight], lambda: calls.append(1) or a.ae_down[0].weight.detach().clone())
+    get()
+    sd = {k: v.clone() + 1 for k, v in a.state_dict().items()}
+    a.load_state_dict(sd)                                            # post-hook drops the packs
+    assert torch.equal(get(), sd["ae_down.0.weight"]) and len(calls) == 2
+    a.double()                                                       # _apply drops them too
+    assert "_lldwt_packed" not in a.__dict__
+    # MaskedConv2d.apply_mask_ writes through .data and invalidates its own packs
+    m = MaskedConv2d("A", 3, 6, 5, 1, 2, groups=3)
+    hits = []
+    getm = lambda: cached(m, ("w",), [m.weight], lambda: hits.append(1) or m.weight.detach().clone())
+    with torch.no_grad():
+        m.weight.fill_(1.0)
+    getm()                                                           # packed BEFORE masking (dead taps still 1)
+    m.apply_mask_()
+    w = getm()
+    assert len(hits) == 2 and float(w[0, 0, 2, 2]) == 0.0 and float(w[0, 0, 4, 4]) == 0.0 and float(w[0, 0, 0, 0]) == 1.0
+
+
+# ------------------------------------------------------------------------------------------------ loggers / checkpoints
+def test_rdlogger_schema_is_the_reference_one():
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.loggers import RDLogger
+    lg = RDLogger()
+    lg(1.0, 0.5, 0.25, 0.125)
+    lg(3.0, 1.5, 0.75, 0.0)                   # rate2 == 0 is not recorded (loggers/rate.py:64-65)
+    sd = lg.state_dict()
+    assert set(sd) == {"loss", "mse", "rate", "rate2", "it", "ep"} and sd["it"] == 2 and sd["rate2"] == [0.125]
+    lg2 = RDLogger()
+    lg2.load_state_dict(json.loads(json.dumps(sd)))                  # plain lists / numbers only
+    assert lg2.display(typ="va") == (2.0, 1.0, 0.5, 0.125)
+    assert lg2.current_epoch == 1 and lg2.loss == []
+    lg3 = RDLogger()
+    lg3.load_state_dict({"n": 4, "sums": [8.0, 4.0, 2.0, 1.0]})      # round-1 files of this repo
+    assert lg3.display() == (2.0, 1.0, 0.5, 0.25)
+
+
+def _cpu_agent(tmp_path, **over):
+    """An agent shell WITHOUT a GPU: bypasses BaseAgent.__init__ (which requires one) to test the host-side I/O."""
+    import logging
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.agents.liftingDWT_agent import (
+        LiftingBasedDWTAgent, configure_optimizers)
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import \
+        LiftingBasedDWTNetWrapper
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.loggers import RDLogger
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
+    cfg = make_config(dwtlevels=2, checkpoint_dir=str(tmp_path) + "/", **over)
+    ag = object.__new__(LiftingBasedDWTAgent)
+    ag.config, ag.logger, ag.device = cfg, logging.getLogger("Agent"), torch.device("cpu")
+    ag.best_valid_loss, ag.current_epoch, ag.current_iteration = float("inf"), 0, 0
+    ag.model = LiftingBasedDWTNetWrapper(cfg)
+    ag.optimizer = configure_optimizers(ag.model, 1e-4)
+    ag.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(ag.optimizer, factor=0.5, patience=5)
+    for n in ("train_logger", "trnit_logger", "valid_logger", "test_logger"):
+        setattr(ag, n, RDLogger())
+    return ag
+
+
+def test_checkpoint_round_trip_and_reference_shaped_file(tmp_path):
+    a = _cpu_agent(tmp_path)
+    a.current_epoch, a.current_iteration, a.best_valid_loss = 7, 1234, 0.75
+    a.train_logger(1.0, 2.0, 3.0, 4.0)
+    a.save_checkpoint(is_best=1)
+    assert os.path.exists(os.path.join(str(tmp_path), "model_best.pth.tar"))
+    # the file holds tensors + plain containers only: the weights-only unpickler accepts it
+    raw = torch.load(os.path.join(str(tmp_path), "checkpoint.pth.tar"), weights_only=True)
+    assert {"epoch", "iteration", "best_valid_loss", "state_dict", "optimizer", "scheduler", "train_logger", "trnit_logger",
+            "valid_logger", "test_logger"} <= set(raw)                # agents/base.py:99-110 key set
+    b = _cpu_agent(tmp_path)
+    with torch.no_grad():
+        for p in b.model.parameters():
+            p.add_(0.5)
+    assert b.load_checkpoint("model_best.pth.tar") is True
+    assert (b.current_epoch, b.current_iteration, b.best_valid_loss) == (7, 1234, 0.75)     # agents/base.py:70-72
+    for (k, v), (k2, v2) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2), k
+    assert b.train_logger.state_dict() == a.train_logger.state_dict()
+    # optimizer / scheduler state is present in the file but NOT restored (agents/base.py:74-75 are commented out)
+    assert not b.optimizer.state
+    # a dict shaped like a REFERENCE checkpoint: reference logger schema + python floats, full aliased key set
+    ref_like = dict(raw)
+    ref_like["train_logger"] = {"loss": [0.5, 1.5], "mse": [0.1, 0.3], "rate": [1.0, 2.0], "rate2": [], "it": 2, "ep": 3}
+    torch.save(ref_like, os.path.join(str(tmp_path), "ref_like.pth.tar"))
+    c = _cpu_agent(tmp_path)
+    assert c.load_checkpoint("ref_like.pth.tar")
+    assert c.train_logger.current_epoch == 3 and c.train_logger.loss == [0.5, 1.5]
+    assert c.load_checkpoint("does_not_exist.pth.tar") is False       # agents/base.py:91-95: logged, not fatal
+
+
+def test_checkpoint_of_another_architecture_is_an_error(tmp_path):
+    a = _cpu_agent(tmp_path)
+    a.save_checkpoint()
+    b = _cpu_agent(tmp_path, entropy_layer="factorized")
+    with pytest.raises(RuntimeError, match="does not match the model"):
+        b.load_checkpoint("checkpoint.pth.tar")
+
+
+def test_checkpoint_loader_refuses_pickled_code(tmp_path):
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    torch.save({"epoch": 0, "iteration": 0, "best_valid_loss": 0.0, "state_dict": {}, "x": Evil()},
+               os.path.join(str(tmp_path), "evil.pth.tar"))
+    a = _cpu_agent(tmp_path)
+    with pytest.raises(Exception) as e:
+        a.load_checkpoint("evil.pth.tar")
+    assert "Unsupported" in str(e.value) or "weights_only" in str(e.value) or "UnpicklingError" in type(e.value).__name__
+
+
+# ------------------------------------------------------------------------------------------------ config plumbing
+REFERENCE_JSON_KEYS = [   # liftingDWT.json:2-52 (key set only; the values below are this test's own)
+    "exp_name", "multi_exp_name", "agent", "mode", "resume_training", "imshow_validation", "cuda", "gpu_device", "seed",
+    "clrch", "netType", "entropy_layer", "autoencoder", "dwtlevels", "num_lifting_perlayer", "filtersize", "resnetlevel",
+    "block_property", "scale", "linearity_flag", "depth_scale", "res_connection_weight", "split_mode", "lif_prec_bits",
+    "batch_size", "patch_size", "grad_acc_iters", "loss_prnt_iters", "val_batch_size", "val_patch_size", "test_patch_size",
+    "multi_agent", "multi_param", "learning_rate", "gamma", "lambda_", "loss_switch_thr", "training_loss_switch",
+    "max_epoch", "log_interval", "validate_every", "test_every", "postprocess", "checkpoint_file", "num_train_dirs",
+    "train_data_1", "train_data_2", "train_data_3", "train_data_4", "test_data", "valid_data"]
+
+
+def reference_shaped_json(tmp_path, **over):
+    d = dict(exp_name="t_exp", multi_exp_name="t_multi", agent="LiftingBasedDWTAgent", mode="validate",
+             resume_training=False, imshow_validation=False, cuda=True, gpu_device=0, seed=7, clrch=1, netType="CDF97",
+             entropy_layer="conditioned2ZTsepSubbands", autoencoder="SubbandAutoEncoderBerk", dwtlevels=2,
+             num_lifting_perlayer=2, filtersize=5, resnetlevel=6, block_property="same", scale=0, linearity_flag=1,
+             depth_scale=2, res_connection_weight=0.1, split_mode="hv", lif_prec_bits=0, batch_size=2, patch_size=32,
+             grad_acc_iters=1, loss_prnt_iters=10, val_batch_size=1, val_patch_size=32, test_patch_size=0, multi_agent=False,
+             multi_param="lambda_", learning_rate=1e-4, gamma=1.0, lambda_=100, loss_switch_thr=0.0015,
+             training_loss_switch=1, max_epoch=1, log_interval=20, validate_every=1, test_every=1, postprocess="none",
+             checkpoint_file="checkpoint.pth.tar", num_train_dirs=1, train_data_1="/nonexistent/train",
+             train_data_2="/nonexistent/b", train_data_3="/nonexistent/c", train_data_4="/nonexistent/d",
+             test_data="/nonexistent/kodak", valid_data="/nonexistent/kodak")
+    d.update(over)
+    assert set(d) == set(REFERENCE_JSON_KEYS)
+    path = os.path.join(str(tmp_path), "cfg.json")
+    with open(path, "w") as f:
+        json.dump(d, f)
+    return path
+
+
+def test_json_through_process_config(tmp_path, monkeypatch):
+    """main.py:16-27: get_config_from_json -> process_config; unknown keys ride along, experiment dirs are created."""
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import (get_config_from_json,
+                                                                                            process_config)
+    monkeypatch.chdir(tmp_path)
+    path = reference_shaped_json(tmp_path)
+    config, d = get_config_from_json(path)
+    assert config.netType == "CDF97" and d["val_patch_size"] == 32
+    config = process_config(config)                                   # reference signature: takes the config object
+    for k in ("summary_dir", "checkpoint_dir", "out_dir", "log_dir"):
+        assert os.path.isdir(config[k]) and config[k].startswith(os.path.join("experiments", "t_exp"))
+    config2 = process_config(path)                                    # round-1 convenience form (a path) still works
+    assert config2.checkpoint_dir == config.checkpoint_dir
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import \
+        LiftingBasedDWTNetWrapper
+    net = LiftingBasedDWTNetWrapper(config)                           # the dispatch strings resolve
+    assert type(net.model0.autoencoder).__name__ == "DWTPytorchWaveletsLayer"
+    bad = reference_shaped_json(tmp_path, exp_name=None)
+    with pytest.raises(SystemExit):
+        process_config(get_config_from_json(bad)[0])                  # utils/config.py:83-89: exp_name is mandatory
+
+
+# ------------------------------------------------------------------------------------------------ folder dataset
+def _make_images(folder, sizes, seed=0):
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    arrs = []
+    for k, (w, h) in enumerate(sizes):
+        a = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        Image.fromarray(a).save(os.path.join(folder, "img%02d.png" % k))
+        arrs.append(a)
+    with open(os.path.join(folder, "notes.txt"), "w") as f:          # non-image files are ignored (:66)
+        f.write("x")
+    return arrs
+
+
+def test_folder_dataset_crops(tmp_path):
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.dataloaders.image_dl import (ImageDataset,
+                                                                                                 ImageDataset_test)
+    arrs = _make_images(str(tmp_path / "tr"), [(48, 40), (64, 64), (20, 50)])
+    ds = ImageDataset(str(tmp_path / "tr"), 32, train=True)
+    assert len(ds) == 3
+    rng = np.random.default_rng(5)
+    c = ds.get(0, rng)
+    assert c.shape == (32, 32, 3) and c.dtype == np.uint8
+    found = any(np.array_equal(c, arrs[0][t:t + 32, l:l + 32]) for t in range(40 - 32 + 1) for l in range(48 - 32 + 1))
+    assert found                                                      # RandomCrop: an exact window of the source image
+    te = ImageDataset_test(str(tmp_path / "tr"), 32)
+    cc = te.get(1, rng)
+    assert np.array_equal(cc, arrs[1][16:48, 16:48])                  # CenterCrop
+    assert te.get(2, rng).shape == (32, 32, 3)                        # 20 px wide: ImageOps.fit up to 32 first (:87-99)
+    full = ImageDataset_test(str(tmp_path / "tr"), 0)
+    assert np.array_equal(full.get(0, rng), arrs[0])                  # size 0: the whole image
+    t = te[1]
+    assert t.shape == (3, 32, 32) and float(t.max()) <= 1.0 and torch.equal(t, torch.from_numpy(cc.copy()).permute(2, 0, 1).float() / 255)
+    with pytest.raises(FileNotFoundError):
+        ImageDataset(str(tmp_path / "empty_does_not_exist"), 32)
+
+
+def test_batch_producer_and_rank_sharding(tmp_path):
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.dataloaders.image_dl import (DeviceBatchLoader,
+                                                                                                 ImageDataLoader, ImageDataset)
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
+    _make_images(str(tmp_path / "tr"), [(40, 40)] * 7)
+    ds = ImageDataset(str(tmp_path / "tr"), 16, train=True)
+    cpu = torch.device("cpu")
+    ld = [DeviceBatchLoader(ds, 2, True, cpu, seed=3, drop_last=True, rank=r, world=2) for r in range(2)]
+    i0, i1 = ld[0]._indices(), ld[1]._indices()
+    assert len(i0) == len(i1) == 3 and not set(i0) & set(i1)          # disjoint, equal length (7 // 2)
+    assert len(ld[0]) == len(ld[1]) == 1                              # same number of batches on every rank
+    q = queue.Queue()
+    ld[0]._produce(i0, q, threading.Event())
+    batches = []
+    while True:
+        it = q.get_nowait()
+        if it is None:
+            break
+        batches.append(it)
+    assert len(batches) == 1 and batches[0].shape == (2, 16, 16, 3) and batches[0].dtype == torch.uint8
+    # the agent-facing loader falls back to the synthetic generator when the configured folders do not exist
+    cfg = make_config(train_data_1="/nonexistent", test_data="/nonexistent", num_train_dirs=1)
+    assert ImageDataLoader(cfg, cpu).synthetic
+    cfg = make_config(train_data_1=str(tmp_path / "tr"), test_data=str(tmp_path / "tr"), num_train_dirs=1, patch_size=16,
+                      test_patch_size=0)
+    dl = ImageDataLoader(cfg, cpu)
+    assert not dl.synthetic and len(dl.train_loader) == 2 and len(dl.valid_loader) == 7   # batch 4 -> ceil(7/4); batch 1
+
+
+# ------------------------------------------------------------------------------------------------ gloo, world 2
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Shared(nn.Module):
+    """Two 'levels' that share one block (like the P/U blocks shared by every lifting level) + a private head."""
+
+    def __init__(self):
+        super().__init__()
+        self.block = nn.Linear(4, 4)
+        self.levels = nn.ModuleList([self.block, self.block])          # the same module registered twice
+        self.head = nn.Linear(4, 1)
+
+    def forward(self, x):
+        for l in self.levels:
+            x = torch.tanh(l(x))
+        return self.head(x)
+
+
+def _train_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init(backend="gloo")
+    torch.manual_seed(0)                                               # replicated init
+    net = _Shared()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0, threshold=0.0)
+    bucket = parallel.FlatGradBucket(net.parameters())
+    assert len(bucket.params) == 4                                     # shared block counted once
+    g = torch.Generator().manual_seed(parallel.rank_seed(11, rank))    # different data per rank
+    local_losses = []
+    for epoch in range(3):
+        for _ in range(4):
+            bucket.zero_()
+            x = torch.randn(8, 4, generator=g)
+            loss = (net(x) - x.sum(1, keepdim=True)).pow(2).mean() * (1.0 + 3.0 * rank)   # rank-dependent loss scale
+            loss.backward()                                            # AccumulateGrad writes INTO the flat bucket views
+            for p in net.parameters():
+                assert p.grad.data_ptr() >= bucket.flat.data_ptr() and \
+                    p.grad.data_ptr() < bucket.flat.data_ptr() + bucket.flat.numel() * 4     # still aliased
+            bucket.all_reduce_mean()
+            opt.step()
+            local_losses.append(float(loss))
+        # the plateau scheduler must see the SAME value on every rank, or the LRs diverge
+        ep_loss = sum(local_losses[-4:]) / 4
+        # rank 1 pretends it got worse, rank 0 better: with rank-local values the LRs would differ
+        ep_loss = ep_loss * (1.0 + (0.5 if rank == 1 else -0.5) * epoch)
+        consensus, = parallel.mean_over_ranks([ep_loss])
+        sched.step(consensus)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    q.put((rank, flat.tolist(), opt.param_groups[0]["lr"], consensus))
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_real_autograd_through_flat_bucket_keeps_replicas_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w0, lr0, c0), (_, w1, lr1, c1) = res
+    assert w0 == w1                                                   # bit-identical parameters after 12 steps
+    assert lr0 == lr1 and c0 == c1                                    # same plateau decisions
