@@ -1,0 +1,372 @@
+// conv_f16x3.hip -- dense 3x3 convolution with fp32-level accuracy on the fp16 matrix cores ("split-fp16", f16x3).
+//
+// Target: the tree-context conv 243 -> 243, 3x3 (LiftingBasedDWT_net.py:271-272, :793-795) -- 61 % of the headline
+// step's FLOPs and, on the fp32 MFMA (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD), bound at 157 TFLOP/s.  The fp16 MFMA
+// (v_mfma_f32_32x32x16_f16) runs 16x that rate.  Every fp32 operand is split EXACTLY-to-2^-22 into two fp16 values
+//     v = s * x  (s a power of two chosen so that max|v| is in [2^14, 2^15): no overflow, lo stays a normal number)
+//     hi = fp16(v),  lo = fp16(v - hi)            |v - hi - lo| <= 2^-22 |v|
+// and the product is accumulated in fp32 from three MFMAs:  x*w ~ hi_x*hi_w + hi_x*lo_w + lo_x*hi_w  (the dropped
+// lo*lo term is 2^-22 relative).  fp16 x fp16 products are exact in fp32, so the result carries ~2^-21 relative error
+// per product -- the same order as the fp32 fmaf chain's own accumulation error at K = 2187 (3.5e-7) -- at 16/3 = 5.3x
+// fewer matrix cycles.  bf16 would not do: its 8-bit mantissa gives 2^-16 per split pair, 64x worse.
+// The scales are powers of two, so applying 1/(s_x*s_w) to the accumulator is exact.
+//   s_w: per plane, fixed at pack time (lldwt_conv_f16x3_pack).   s_x: per plane, from the |x| maximum of the input
+//   tensor, produced on the device by lldwt_absmax_slots (no host sync) and read by the conv kernel.
+//
+// Kernel shape (one 256-thread workgroup per CU, ONE wave per SIMD with the whole 512-entry register file):
+//   workgroup tile = 128 output channels x (8 rows x 32 pixels); wave w owns channels 32w..32w+31 x all 256 pixels
+//   = 8 accumulator tiles of 32x32 (128 VGPRs).  K loop = 8 chunks of 32 input channels x 9 taps x 2 k-steps of 16.
+//   B (activations): fp32 planes -> registers -> split -> LDS image [10x34 pixels][32 ch] fp16, pixel pitch 80 B
+//      (20 dwords: 16 lanes of a ds_read_b128 group hit 64 distinct banks), hi and lo images, double-buffered, so the
+//      global loads of chunk c+1 fly during the MFMAs of chunk c and there is one barrier per chunk.
+//   A (weights): pre-split, pre-packed in lane order per (wave, chunk, tap, k-step): each wave streams ITS fragments
+//      straight from L2 into registers (1 KB coalesced per instruction, no LDS), two k-steps ahead.
+#include "common.h"
+
+namespace lldwt {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int F3_CK = 32;                       // input channels per chunk
+constexpr int F3_TH = 8, F3_TW = 32;            // output pixels per workgroup
+constexpr int F3_IH = F3_TH + 2, F3_IW = F3_TW + 2, F3_NPX = F3_IH * F3_IW;   // 10 x 34 = 340 staged pixels
+constexpr int F3_PITCH = F3_CK * 2 + 16;        // 80 B per pixel
+constexpr int F3_PART = F3_NPX * F3_PITCH;      // 27,200 B: one image (hi or lo)
+constexpr int F3_BUF = 2 * F3_PART;             // hi + lo
+constexpr int F3_LDS = 2 * F3_BUF + 64;         // double buffer: 108,800 B + a 64-B dump slot for dead staging tasks
+constexpr int F3_OCB = 128;                     // output channels per workgroup
+constexpr int F3_STEP_BYTES = 2048;             // one (tap, k-step) of one wave: hi fragment + lo fragment, 1 KB each
+constexpr int F3_CHUNK_BYTES = 9 * 2 * F3_STEP_BYTES;
+constexpr int F3_HDR = 256;                     // per-plane header: [0] = s_w
+constexpr int F3_NTASK = F3_NPX * (F3_CK / 8);  // staging tasks (pixel, group of 8 channels) per chunk
+constexpr int F3_R = (F3_NTASK + 255) / 256;    // per thread: 6
+
+static inline int f3_nch(int cin) { return (int)cdiv(cin, F3_CK); }
+static inline int f3_nocb(int cout) { return (int)cdiv(cout, F3_OCB); }
+static inline int64_t f3_plane_bytes(int cin, int cout) {
+    // + 5 steps of padding: the kernel prefetches weight fragments 5 steps ahead without a bounds branch
+    return F3_HDR + (int64_t)f3_nocb(cout) * 4 * f3_nch(cin) * F3_CHUNK_BYTES + 5 * F3_STEP_BYTES;
+}
+
+__device__ __forceinline__ float pow2_scale_for(float amax) {
+    // power of two s with amax * s in [2^14, 2^15); 1 for amax == 0 / non-finite
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(amax, &e);                      // amax = m * 2^e, m in [0.5, 1)
+    int k = 15 - e;
+    k = k > 120 ? 120 : (k < -120 ? -120 : k);
+    return ldexpf(1.f, k);
+}
+
+// ---- |x| maximum per plane into 64 slots (spreads the atomics; the consumer takes the max of the 64)
+__global__ void k_absmax_slots(const float* __restrict__ x, int64_t n_per_plane, float* __restrict__ slots, int vec) {
+    const int plane = blockIdx.y;
+    const float* xp = x + (int64_t)plane * n_per_plane;
+    float m = 0.f;
+    if (vec) {                     // every plane base is 16-byte aligned and n_per_plane % 4 == 0 (checked by the host)
+        const float4* p = reinterpret_cast<const float4*>(xp);
+        const int64_t n4 = n_per_plane >> 2;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 v = p[i];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_per_plane; i += (int64_t)gridDim.x * blockDim.x)
+            m = fmaxf(m, fabsf(xp[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f)
+        atomicMax(reinterpret_cast<int*>(slots + plane * 64 + (blockIdx.x & 63)), __float_as_int(m));   // m >= 0: int order == float order
+}
+
+// ---- weight pack: (planes, cout, cin, 3, 3) fp32 -> per plane [hdr][ocb][wave][chunk][tap][ks][hi|lo][lane][8 x fp16]
+__global__ void k_f3_wmax(const float* __restrict__ w, int64_t n_per_plane, float* __restrict__ hdr_base, int64_t plane_bytes) {
+    const int plane = blockIdx.y;
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_per_plane; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[(int64_t)plane * n_per_plane + i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    float* hdr = reinterpret_cast<float*>(reinterpret_cast<char*>(hdr_base) + (int64_t)plane * plane_bytes);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(hdr + 1), __float_as_int(m));   // hdr[1] = max|w|
+}
+
+__global__ void k_f3_pack(const float* __restrict__ w, uint8_t* __restrict__ packed, int cin, int cout, int64_t plane_bytes) {
+    const int plane = blockIdx.y;
+    uint8_t* pp = packed + (int64_t)plane * plane_bytes;
+    float* hdr = reinterpret_cast<float*>(pp);
+    const float sw = pow2_scale_for(hdr[1]);
+    const int nch = (cin + F3_CK - 1) / F3_CK, nocb = (cout + F3_OCB - 1) / F3_OCB;
+    const int64_t nfrag_elems = (int64_t)nocb * 4 * nch * 9 * 2 * 64 * 8;       // (hi, lo) pairs
+    const float* wp = w + (int64_t)plane * cout * cin * 9;
+    _Float16* out = reinterpret_cast<_Float16*>(pp + F3_HDR);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nfrag_elems; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int j = (int)(r % 8); r /= 8;
+        const int lane = (int)(r % 64); r /= 64;
+        const int ks = (int)(r % 2); r /= 2;
+        const int tap = (int)(r % 9); r /= 9;
+        const int chunk = (int)(r % nch); r /= nch;
+        const int wv = (int)(r % 4); r /= 4;
+        const int ocb = (int)r;
+        const int oc = ocb * F3_OCB + wv * 32 + (lane & 31);                    // A[row = lane&31][k = 8*(lane>>5) + j]
+        const int ic = chunk * F3_CK + ks * 16 + 8 * (lane >> 5) + j;
+        float v = 0.f;
+        if (oc < cout && ic < cin) v = wp[((int64_t)oc * cin + ic) * 9 + tap] * sw;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const int64_t step = ((((int64_t)(ocb * 4 + wv) * nch + chunk) * 9 + tap) * 2 + ks);
+        out[step * 1024 + lane * 8 + j] = hi;                                   // 1024 halves = 2048 B per step
+        out[step * 1024 + 512 + lane * 8 + j] = lo;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = sw;
+}
+
+struct F3Args {
+    const float* x;
+    float* y;
+    const uint8_t* packed;
+    const float* bias;
+    const float* slots;
+    int cin, cout, act, batch, h, w, tiles_x, nch;
+    int64_t plane_bytes;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv3_f16x3(F3Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / a.batch);
+    const int ocb = blockIdx.y;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    const int y0 = ty * F3_TH, x0 = tx * F3_TW;
+    const int h = a.h, w = a.w;
+    const int64_t hw = (int64_t)h * w;
+
+    // ---- scales (exact powers of two)
+    float amax = a.slots[plane * 64 + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float sx = pow2_scale_for(amax);
+    const uint8_t* pp = a.packed + (int64_t)plane * a.plane_bytes;
+    const float sw = *reinterpret_cast<const float*>(pp);
+    const float out_scale = (1.f / sx) * (1.f / sw);
+
+    // ---- staging tasks of this thread: (pixel p of the 10x34 patch, group of 8 channels icg).  Branch-free: padding
+    // pixels and dead tasks load pixel 0 of a real plane and are zeroed at the split; dead tasks store to a dump slot.
+    unsigned pix[F3_R];         // byte offset of the pixel inside a channel plane (0 for padding / dead tasks)
+    int icg8[F3_R];             // first channel of the task's group inside the chunk
+    int woff[F3_R];             // LDS byte offset inside a part
+    bool inimg[F3_R];
+#pragma unroll
+    for (int r = 0; r < F3_R; ++r) {
+        const int task = tid + r * 256;
+        const bool live = task < F3_NTASK;
+        const int icg = live ? task / F3_NPX : 0, p = live ? task - icg * F3_NPX : 0;
+        const int ly = p / F3_IW, lx = p - ly * F3_IW;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        const bool in = live && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        inimg[r] = in;
+        icg8[r] = icg * 8;
+        woff[r] = p * F3_PITCH + icg * 16;
+        pix[r] = in ? 4u * (unsigned)(gy * w + gx) : 0u;
+    }
+    const float* xg = a.x + z * (int64_t)a.cin * hw;
+    const unsigned hw4 = 4u * (unsigned)hw;
+    float xin[F3_R][8];
+
+    // loads of staging task R of the chunk whose first channel is C1 (channels past cin-1 read plane cin-1, zeroed later)
+#define F3_TASK_LOAD(R, C1)                                                                                           \
+    {                                                                                                                 \
+        const char* cb_ = reinterpret_cast<const char*>(xg + (int64_t)(C1) * hw);       /* wave-uniform */            \
+        const unsigned rcmax_ = (unsigned)(a.cin - 1 - (C1));                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
+            const unsigned rc_ = min((unsigned)(icg8[R] + j), rcmax_);                                                \
+            xin[R][j] = *reinterpret_cast<const float*>(cb_ + (rc_ * hw4 + pix[R]));                                  \
+        }                                                                                                             \
+    }
+    // split + store of channels 4*HALF .. 4*HALF+3 of staging task R into the LDS buffer at DST
+#define F3_TASK_STORE(R, HALF, C1, DST)                                                                               \
+    {                                                                                                                 \
+        typedef _Float16 half4_ __attribute__((ext_vector_type(4)));                                                  \
+        half4_ hi_, lo_;                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+            const bool ok_ = inimg[R] && ((C1) + icg8[R] + (HALF) * 4 + j) < a.cin;                                   \
+            const float v_ = ok_ ? xin[R][(HALF) * 4 + j] * sx : 0.f;                                                 \
+            const _Float16 hh_ = (_Float16)v_;                                                                        \
+            hi_[j] = hh_;                                                                                             \
+            lo_[j] = (_Float16)(v_ - (float)hh_);                                                                     \
+        }                                                                                                             \
+        const bool dead_ = (tid + (R) * 256) >= F3_NTASK;                                                             \
+        uint8_t* d_ = dead_ ? lds + 2 * F3_BUF + (HALF) * 8 : (DST) + woff[R] + (HALF) * 8;                           \
+        *reinterpret_cast<half4_*>(d_) = hi_;                                                                         \
+        *reinterpret_cast<half4_*>(d_ + (dead_ ? 16 : F3_PART)) = lo_;                                                \
+    }
+
+    floatx16 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[n][q] = 0.f;
+
+    const uint8_t* wbase = pp + F3_HDR + ((int64_t)(ocb * 4 + wave) * a.nch) * F3_CHUNK_BYTES + lane * 16;
+    const int boff = (lane & 31) * F3_PITCH + (lane >> 5) * 16;     // B fragment: pixel column lane&31, k half lane>>5
+
+    // ---- prologue: chunk 0 into buffer 0
+#pragma unroll
+    for (int r = 0; r < F3_R; ++r) F3_TASK_LOAD(r, 0)
+#pragma unroll
+    for (int r = 0; r < F3_R; ++r) {
+        F3_TASK_STORE(r, 0, 0, lds)
+        F3_TASK_STORE(r, 1, 0, lds)
+    }
+    __syncthreads();
+
+    // Per chunk: 36 units = (tap, k-step, half of the 8 pixel rows), 12 MFMAs each (384 matrix cycles).  Everything else
+    // is cut into per-unit pieces and interleaved BETWEEN the MFMAs with sched_group_barrier (one wave per SIMD: nothing
+    // else hides it): the 8 LDS fragment reads of unit u+1; the weight fragments of step st+5 (ring of 6, straight from
+    // L2, continuous across chunks, packed buffer padded by 5 steps); the 48 global loads of the next chunk's patch
+    // (units 0-5, 8 each, issued AFTER the unit's weight loads so that a later wait on a weight fragment never drags a
+    // younger HBM load along); the split + LDS store of the next chunk (units 24-35, half a task each).  The unit body
+    // has no branch (the last chunk re-loads itself and stores into the idle buffer), so each unit is one basic block
+    // for the scheduler.  One barrier per chunk.
+    half8 ah[6], al[6];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(wbase + i * F3_STEP_BYTES);
+        al[i] = *reinterpret_cast<const half8*>(wbase + i * F3_STEP_BYTES + 1024);
+    }
+    for (int chunk = 0; chunk < a.nch; ++chunk) {
+        const int buf = chunk & 1;
+        const uint8_t* wp = wbase + (int64_t)chunk * F3_CHUNK_BYTES;
+        const uint8_t* bb = lds + buf * F3_BUF + boff;
+        uint8_t* sdst = lds + (buf ^ 1) * F3_BUF;
+        const int c1 = (chunk + 1 < a.nch ? chunk + 1 : chunk) * F3_CK;     // chunk being staged (last: itself, unused)
+        half8 bh[2][4], bl[2][4];
+#define F3_BLOAD(U, SET)                                                                               \
+        {                                                                                              \
+            const int st_ = (U) >> 1, hf_ = (U) & 1;                                                   \
+            const int tap_ = st_ >> 1, ks_ = st_ & 1;                                                  \
+            const int dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;                                            \
+            _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                            \
+                const int off = ((hf_ * 4 + n + dy_) * F3_IW + dx_) * F3_PITCH + ks_ * 32;             \
+                bh[SET][n] = *reinterpret_cast<const half8*>(bb + off);                                \
+                bl[SET][n] = *reinterpret_cast<const half8*>(bb + F3_PART + off);                      \
+            }                                                                                          \
+        }
+        F3_BLOAD(0, 0)
+#pragma unroll
+        for (int u = 0; u < 36; ++u) {
+            const int st = u >> 1, hf = u & 1;
+            if (hf == 0) {                                      // weight fragments of step st+5 (may belong to the next chunk)
+                ah[(st + 5) % 6] = *reinterpret_cast<const half8*>(wp + (st + 5) * F3_STEP_BYTES);
+                al[(st + 5) % 6] = *reinterpret_cast<const half8*>(wp + (st + 5) * F3_STEP_BYTES + 1024);
+            }
+            if (u + 1 < 36) F3_BLOAD(u + 1, (u + 1) & 1)
+            if (u < F3_R) F3_TASK_LOAD(u, c1)
+            if (u >= 24) F3_TASK_STORE((u - 24) >> 1, (u - 24) & 1, c1, sdst)
+            const half8 A_h = ah[st % 6], A_l = al[st % 6];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_l, bh[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
+                acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, bl[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
+                acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, bh[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // one global load
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // a few vector ALU instructions
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // one LDS write
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef F3_BLOAD
+        __syncthreads();
+    }
+#undef F3_TASK_LOAD
+#undef F3_TASK_STORE
+
+    // ---- epilogue: D col = lane&31 (pixel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (channel of the wave's 32)
+    const int gx = x0 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int oc = ocb * F3_OCB + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (oc >= a.cout) continue;
+        const float bv = a.bias ? a.bias[plane * a.cout + oc] : 0.f;
+        float* yp = a.y + (z * a.cout + oc) * hw;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int gy = y0 + n;
+            if (gy < h && gx < w) yp[(int64_t)gy * w + gx] = act_apply(acc[n][q] * out_scale + bv, a.act);
+        }
+    }
+}
+
+}  // namespace lldwt
+using namespace lldwt;
+
+extern "C" int64_t lldwt_conv_f16x3_packed_bytes(int cin, int cout) {
+    if (cin <= 0 || cout <= 0) return -1;
+    return f3_plane_bytes(cin, cout);
+}
+
+extern "C" int lldwt_conv_f16x3_pack(const float* w, void* packed, int cin, int cout, int64_t planes, void* stream) {
+    LLDWT_REQUIRE(w && packed && cin > 0 && cout > 0 && planes > 0 && planes <= 65535, "conv_f16x3_pack: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t pb = f3_plane_bytes(cin, cout);
+    for (int64_t p = 0; p < planes; ++p)
+        if (hipMemsetAsync(reinterpret_cast<char*>(packed) + p * pb, 0, F3_HDR, st) != hipSuccess) {
+            set_error("conv_f16x3_pack: memset failed");
+            return LLDWT_EHIP;
+        }
+    const int64_t nw = (int64_t)cout * cin * 9;
+    hipLaunchKernelGGL(k_f3_wmax, dim3(64, (unsigned)planes), dim3(256), 0, st, w, nw, reinterpret_cast<float*>(packed), pb);
+    hipLaunchKernelGGL(k_f3_pack, dim3(1024, (unsigned)planes), dim3(256), 0, st, w, reinterpret_cast<uint8_t*>(packed), cin, cout, pb);
+    return check_launch("conv_f16x3_pack");
+}
+
+extern "C" int lldwt_absmax_slots(const float* x, int64_t planes, int64_t n_per_plane, float* slots, void* stream) {
+    LLDWT_REQUIRE(x && slots && planes > 0 && planes <= 65535 && n_per_plane > 0, "absmax_slots: bad arguments");
+    const int vec = (((uintptr_t)x) & 15) == 0 && (n_per_plane & 3) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(slots, 0, sizeof(float) * 64 * planes, st) != hipSuccess) {
+        set_error("absmax_slots: memset failed");
+        return LLDWT_EHIP;
+    }
+    int64_t gx = cdiv(n_per_plane / 4 + 1, 256 * 8);
+    gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
+    hipLaunchKernelGGL(k_absmax_slots, dim3((unsigned)gx, (unsigned)planes), dim3(256), 0, st, x, n_per_plane, slots, vec);
+    return check_launch("absmax_slots");
+}
+
+extern "C" int lldwt_conv3x3_f16x3(const float* x, float* y, const void* packed, const float* bias, const float* slots,
+                                   int cin, int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_,
+                                   void* stream) {
+    LLDWT_REQUIRE(x && y && packed && slots, "conv3x3_f16x3: null pointer");
+    LLDWT_REQUIRE(cin > 0 && cout > 0 && planes > 0 && batch > 0 && h > 0 && w_ > 0 && planes * batch <= 65535,
+                  "conv3x3_f16x3: bad dims");
+    LLDWT_REQUIRE(act == LLDWT_ACT_NONE || act == LLDWT_ACT_LRELU || act == LLDWT_ACT_TANH, "conv3x3_f16x3: bad activation");
+    LLDWT_REQUIRE((int64_t)F3_CK * h * w_ * 4 < (int64_t)1 << 32, "conv3x3_f16x3: image too large for 32-bit chunk offsets");
+    F3Args a;
+    a.x = x; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed); a.bias = bias; a.slots = slots;
+    a.cin = cin; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
+    a.tiles_x = (int)cdiv(w_, F3_TW);
+    a.nch = f3_nch(cin);
+    a.plane_bytes = f3_plane_bytes(cin, cout);
+    const int tiles_y = (int)cdiv(h, F3_TH);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess) {
+            set_error("conv3x3_f16x3: cannot reserve %d bytes of LDS", F3_LDS);
+            return LLDWT_EHIP;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)f3_nocb(cout), (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_conv3_f16x3, grid, dim3(256), F3_LDS, (hipStream_t)stream, a);
+    return check_launch("conv3x3_f16x3");
+}

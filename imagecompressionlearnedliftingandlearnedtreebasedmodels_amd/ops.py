@@ -16,12 +16,13 @@ _ws = {}
 
 def plc_mode():
     """Arithmetic of the dense 243 -> 243 3x3 tree-context conv (LiftingBasedDWT_net.py:271-272): 'f32' = fp32 MFMA
-    (reference arithmetic), 'bf16x3' = split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate).
+    (reference arithmetic), 'f16x3' = split-fp16 (power-of-two scaled hi*hi + hi*lo + lo*hi on the fp16 matrix cores, fp32
+    accumulate; ~2^-21 relative per product, csrc/conv_f16x3.hip).
     Environment variable LLDWT_PLC_MODE; read on every call so tests can switch it."""
     import os
     m = os.environ.get("LLDWT_PLC_MODE", "f32")
-    if m not in ("f32", "bf16x3"):
-        raise _lib.LLDWTError("LLDWT_PLC_MODE must be 'f32' or 'bf16x3' (got %r)" % m)
+    if m not in ("f32", "f16x3"):
+        raise _lib.LLDWTError("LLDWT_PLC_MODE must be 'f32' or 'f16x3' (got %r)" % m)
     return m
 
 
@@ -266,6 +267,37 @@ def conv2d(x, w, bias, K, groups=1, act=ACT_NONE, upsample2=False, transposed=Fa
     check(lib.lldwt_conv2d(_chk(x, "x"), _chk(out, "out"), _chk(packed, "packed"), _opt(bias, "bias"),
                            _opt(residual, "residual"), _opt(aux, "aux"), C.byref(d), P, B, h, wd, _stream()), "conv2d")
     return out
+
+
+def conv_f16x3_pack(w):
+    """(P,cout,cin,3,3) fp32 -> packed split-fp16 weights (uint8 tensor (P, bytes)) for conv3x3_f16x3."""
+    lib = _lib.load()
+    P, cout, cin, K, K2 = w.shape
+    if K != 3 or K2 != 3:
+        raise _lib.LLDWTError("conv_f16x3_pack: 3x3 kernels only")
+    nb = int(lib.lldwt_conv_f16x3_packed_bytes(cin, cout))
+    packed = torch.empty(P, nb, device=w.device, dtype=torch.uint8)
+    check(lib.lldwt_conv_f16x3_pack(_chk(w, "w"), C.c_void_p(packed.data_ptr()), cin, cout, P, _stream()), "conv_f16x3_pack")
+    return packed
+
+
+def absmax_slots(x):
+    """x (P, ...) -> slots (P,64) fp32 whose maximum per plane is max|x[p]| (device-side; feeds conv3x3_f16x3)."""
+    P = x.shape[0]
+    slots = torch.empty(P, 64, device=x.device, dtype=torch.float32)
+    check(_lib.load().lldwt_absmax_slots(_chk(x, "x"), P, x.numel() // P, _chk(slots), _stream()), "absmax_slots")
+    return slots
+
+
+def conv3x3_f16x3(x, packed, bias, cout, act=ACT_NONE, slots=None):
+    """Dense 3x3 conv on the fp16 matrix cores with split-fp16 operands (include/lldwt.h lldwt_conv3x3_f16x3)."""
+    P, B, cin, h, w = x.shape
+    if slots is None:
+        slots = absmax_slots(x)
+    y = torch.empty(P, B, cout, h, w, device=x.device, dtype=torch.float32)
+    check(_lib.load().lldwt_conv3x3_f16x3(_chk(x, "x"), _chk(y), C.c_void_p(packed.data_ptr()), _opt(bias, "bias"),
+                                         _chk(slots, "slots"), cin, cout, act, P, B, h, w, _stream()), "conv3x3_f16x3")
+    return y
 
 
 def conv2d_wgrad(x, dy, wshape, K, groups=1, upsample2=False, tap_mask=None, want_bias=True, oc_block=None, oc_stride=0,

@@ -237,6 +237,20 @@ int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, float* dbi
 int lldwt_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, void* stream);
 /* backward of the nearest-neighbour 2x upsampling: out (Z,C,h/2,w/2) = sum over each 2x2 block of g (Z,C,h,w). */
 int lldwt_downsum2(const float* g, float* out, int64_t zc, int64_t h, int64_t w_, void* stream);
+/* Dense 3x3 conv (groups 1, no placement, no upsampling) on the fp16 matrix cores with fp32-level accuracy
+ * ("f16x3", csrc/conv_f16x3.hip): every fp32 operand is scaled by a power of two and split into hi + lo fp16 values
+ * (|v - hi - lo| <= 2^-22 |v|), the product is hi*hi + hi*lo + lo*hi accumulated in fp32.  For the tree-context conv
+ * 243 -> 243 (LiftingBasedDWT_net.py:271-272, :793-795).  The fp32 engine above stays the reference arithmetic.
+ *   lldwt_conv_f16x3_pack : w (planes,cout,cin,3,3) -> packed (lldwt_conv_f16x3_packed_bytes(cin,cout) bytes per plane)
+ *   lldwt_absmax_slots    : slots (planes,64) <- max |x| of each plane's n_per_plane values (the activation scale is
+ *                           derived from it on the device; no host synchronisation)
+ *   lldwt_conv3x3_f16x3   : y (planes,batch,cout,h,w) = act(conv3x3(x (planes,batch,cin,h,w)) + bias (planes,cout)) */
+int64_t lldwt_conv_f16x3_packed_bytes(int cin, int cout);
+int lldwt_conv_f16x3_pack(const float* w, void* packed, int cin, int cout, int64_t planes, void* stream);
+int lldwt_absmax_slots(const float* x, int64_t planes, int64_t n_per_plane, float* slots, void* stream);
+int lldwt_conv3x3_f16x3(const float* x, float* y, const void* packed, const float* bias, const float* slots, int cin,
+                        int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+
 /* Same maths from the raw PyTorch-layout weights w, reference-order direct kernel (VALU); cross-checks the MFMA engine. */
 int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
                         int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
