@@ -106,6 +106,7 @@ struct ConvArgs {
     const float* bias;
     const float* residual;   // same layout as y (ytot channels) or null
     const float* aux;        // same layout as y: forward output for the gradient epilogue, or null
+    float* absmax;           // (planes,64) slots receiving max |y| of this launch (feeds the split-fp16 conv), or null
     lldwt_conv_desc d;
     ConvPlan p;
     int batch, h, w, tiles_x, tiles_y;
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
 #undef LLDWT_STAGE_STORE
     // ---- epilogue: bias, residual, activation, channel placement
     const int64_t hw = (int64_t)h * w;
+    float omax = 0.f;
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
 #pragma unroll
@@ -344,10 +346,18 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
                         v *= d.epi == LLDWT_EPI_TANH_BWD ? (1.f - av * av) : (av > 0.f ? 1.f : 0.01f);
                     }
                     if (rp) v += rp[(int64_t)gy * w + gx];
-                    yp[(int64_t)gy * w + gx] = act_apply(v, d.act);
+                    v = act_apply(v, d.act);
+                    yp[(int64_t)gy * w + gx] = v;
+                    omax = fmaxf(omax, fabsf(v));
                 }
             }
         }
+    }
+    if (a.absmax) {            // one atomic per wave, spread over 64 slots per plane (values >= 0: int order == float order)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_down(omax, o, 64));
+        if (lane == 0 && omax > 0.f)
+            atomicMax(reinterpret_cast<int*>(a.absmax + plane * 64 + ((blockIdx.x + wave) & 63)), __float_as_int(omax));
     }
 }
 
@@ -427,11 +437,21 @@ extern "C" int lldwt_conv_pack_ex(const float* w, float* packed, const lldwt_con
 extern "C" int lldwt_conv2d(const float* x, float* y, const float* packed, const float* bias, const float* residual,
                             const float* aux, const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h,
                             int64_t w_, void* stream) {
+    return lldwt_conv2d_absmax(x, y, packed, bias, residual, aux, nullptr, d, planes, batch, h, w_, stream);
+}
+
+extern "C" int lldwt_conv2d_absmax(const float* x, float* y, const float* packed, const float* bias, const float* residual,
+                                   const float* aux, float* absmax_slots, const lldwt_conv_desc* d, int64_t planes,
+                                   int64_t batch, int64_t h, int64_t w_, void* stream) {
     int r = conv_desc_ok("conv2d", d, planes, batch, h, w_);
     if (r) return r;
     LLDWT_REQUIRE(x && y && packed, "conv2d: null pointer");
+    if (absmax_slots && hipMemsetAsync(absmax_slots, 0, sizeof(float) * 64 * planes, (hipStream_t)stream) != hipSuccess) {
+        set_error("conv2d: memset of the absmax slots failed");
+        return LLDWT_EHIP;
+    }
     ConvArgs a;
-    a.x = x; a.y = y; a.packed = packed; a.bias = bias; a.residual = residual; a.aux = aux;
+    a.x = x; a.y = y; a.packed = packed; a.bias = bias; a.residual = residual; a.aux = aux; a.absmax = absmax_slots;
     a.d = *d;
     a.d.tap_mask &= (1u << (d->K * d->K)) - 1u;
     a.p = make_plan(a.d);

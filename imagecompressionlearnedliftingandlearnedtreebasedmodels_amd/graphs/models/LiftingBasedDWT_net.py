@@ -45,6 +45,24 @@ def _conv(mods, x, act=ops.ACT_NONE, upsample2=False, **kw):
                       packed=packed, **kw)
 
 
+def _plc_pair(first, second, parent, act2):
+    """The tree-context pair conv3x3(3 -> 243) on the 2x-upsampled parent, LeakyReLU, conv3x3(243 -> 243)
+    (LiftingBasedDWT_net.py:271-272,348,355 / :793-795,822).  The second, dense conv is 61 % of the headline step's
+    FLOPs: in mode 'f16x3' (ops.plc_mode) it runs on the fp16 matrix cores with split-fp16 operands (fp32-level
+    accuracy, csrc/conv_f16x3.hip); its activation scale comes from the first conv's epilogue (absmax slots)."""
+    if ops.plc_mode() != "f16x3":
+        t = _conv(first, parent, act=ops.ACT_LRELU, upsample2=True)
+        return _conv(second, t, act=act2)
+    m2 = second[0]
+    slots = torch.empty(parent.shape[0], 64, device=parent.device, dtype=torch.float32)
+    t = _conv(first, parent, act=ops.ACT_LRELU, upsample2=True, absmax=slots)
+
+    def build():
+        return _stack(second, lambda m: m.bias), ops.conv_f16x3_pack(_stack(second, lambda m: m.weight))
+    b2, packed16 = cached(m2, ("conv_f16x3",), [p for m in second for p in (m.weight, m.bias)], build)
+    return ops.conv3x3_f16x3(t, packed16, b2, m2.out_channels, act=act2, slots=slots)
+
+
 def _noise(t, training):
     return torch.empty_like(t).uniform_(-0.5, 0.5) if training else None
 
@@ -143,8 +161,7 @@ class onlyEZWT(_EntropyLayerBase):
         parent = q
         for i in range(L - 2, -1, -1):
             seqs = [l.plc_list[i] for l in layers]
-            t = _conv([s[0] for s in seqs], parent, act=ops.ACT_LRELU, upsample2=True)      # :822,835 + :793
-            t = _conv([s[2] for s in seqs], t, act=ops.ACT_LRELU)
+            t = _plc_pair([s[0] for s in seqs], [s[2] for s in seqs], parent, ops.ACT_LRELU)   # :822,835 + :793-794
             ms = _conv([s[4] for s in seqs], t)
             bits, q = ops.gauss_rate(out_xo_list[i], ms, _noise(out_xo_list[i], training), want_q=True)   # :832
             si_list.append(bits)
@@ -218,9 +235,7 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
             P, B, so, h, w = x.shape
             xo_q = ops.quantize(x, _noise(x, training))
             seqs = [l.plc_list[i] for l in layers]
-            t = _conv([s[0] for s in seqs], parent, act=ops.ACT_LRELU, upsample2=True)                       # :348,355
-            plc = _conv([s[2] for s in seqs], t)
-            del t
+            plc = _plc_pair([s[0] for s in seqs], [s[2] for s in seqs], parent, ops.ACT_NONE)                # :348,355
             cg = [l.cgp_out_xo_list[i] for l in layers]
             cs = [l.csc_list[i] for l in layers]
             convs = [[s[n] for s in cg] for n in (0, 2, 4, 6)]

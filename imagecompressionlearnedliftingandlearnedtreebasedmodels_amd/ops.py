@@ -18,9 +18,11 @@ def plc_mode():
     """Arithmetic of the dense 243 -> 243 3x3 tree-context conv (LiftingBasedDWT_net.py:271-272): 'f32' = fp32 MFMA
     (reference arithmetic), 'f16x3' = split-fp16 (power-of-two scaled hi*hi + hi*lo + lo*hi on the fp16 matrix cores, fp32
     accumulate; ~2^-21 relative per product, csrc/conv_f16x3.hip).
-    Environment variable LLDWT_PLC_MODE; read on every call so tests can switch it."""
+    Default 'f16x3' (parity-gated by tests/test_gpu_fullsize_oracle.py at the same bars as 'f32'); the fp32 kernel
+    stays available as the exact-arithmetic fallback.  Environment variable LLDWT_PLC_MODE; read on every call so tests
+    can switch it."""
     import os
-    m = os.environ.get("LLDWT_PLC_MODE", "f32")
+    m = os.environ.get("LLDWT_PLC_MODE", "f16x3")
     if m not in ("f32", "f16x3"):
         raise _lib.LLDWTError("LLDWT_PLC_MODE must be 'f32' or 'f16x3' (got %r)" % m)
     return m
@@ -239,10 +241,11 @@ def conv_pack(w, K, groups=1, transposed=False, tap_mask=None, swap_hw=False):
 
 def conv2d(x, w, bias, K, groups=1, act=ACT_NONE, upsample2=False, transposed=False, tap_mask=None, out=None,
            oc_block=None, oc_stride=0, oc_off=0, direct=False, packed=None, residual=None, aux=None, epi=0,
-           ic_block=0, ic_stride=0, ic_off=0, cin=None):
+           ic_block=0, ic_stride=0, ic_off=0, cin=None, absmax=None):
     """General conv layer (include/lldwt.h lldwt_conv2d).  x: (P,B,xtot,h,w); w: (P,cout,cin/groups,K,K)
     (transposed: (P,cin,cout/groups,K,K)).  ``out``: optional pre-allocated (P,B,ytot,h,w) tensor for channel placement.
-    ``packed``: result of conv_pack(w, ...) to skip re-packing; ``direct``: reference-order VALU kernel."""
+    ``packed``: result of conv_pack(w, ...) to skip re-packing; ``direct``: reference-order VALU kernel;
+    ``absmax``: optional (P,64) fp32 tensor that receives max|y| per plane (lldwt_conv2d_absmax)."""
     lib = _lib.load()
     P, B, xtot, hi, wi = x.shape
     if transposed:
@@ -264,6 +267,11 @@ def conv2d(x, w, bias, K, groups=1, act=ACT_NONE, upsample2=False, transposed=Fa
         return out
     if packed is None:
         packed = conv_pack(w, K, groups, transposed, tap_mask)
+    if absmax is not None:
+        check(lib.lldwt_conv2d_absmax(_chk(x, "x"), _chk(out, "out"), _chk(packed, "packed"), _opt(bias, "bias"),
+                                      _opt(residual, "residual"), _opt(aux, "aux"), _chk(absmax, "absmax"), C.byref(d), P, B,
+                                      h, wd, _stream()), "conv2d_absmax")
+        return out
     check(lib.lldwt_conv2d(_chk(x, "x"), _chk(out, "out"), _chk(packed, "packed"), _opt(bias, "bias"),
                            _opt(residual, "residual"), _opt(aux, "aux"), C.byref(d), P, B, h, wd, _stream()), "conv2d")
     return out

@@ -223,6 +223,12 @@ int lldwt_conv_pack_ex(const float* w, float* packed, const lldwt_conv_desc* d, 
 int lldwt_conv2d(const float* x, float* y, const float* packed, const float* bias, const float* residual,
                  const float* aux, const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_,
                  void* stream);
+/* As lldwt_conv2d; additionally absmax_slots (planes,64), if not null, receives max |y| of each plane spread over 64
+ * slots (the consumer takes their maximum): the activation scale of a following lldwt_conv3x3_f16x3, produced in the
+ * epilogue instead of by a separate pass over y.                                                                  */
+int lldwt_conv2d_absmax(const float* x, float* y, const float* packed, const float* bias, const float* residual,
+                        const float* aux, float* absmax_slots, const lldwt_conv_desc* d, int64_t planes, int64_t batch,
+                        int64_t h, int64_t w_, void* stream);
 /* Backward-weights: dw (planes,cout,cin/groups,K,K) += sum over batch and pixels of dy[.,oc,p] * x[.,ic,p+tap]
  * (dead taps of tap_mask are skipped), dbias (planes,cout) += sum dy (optional).  dy is read through the OUTPUT
  * placement (oc_*), x through upsample2 / the input placement.  Accumulates with float atomics: zero dw/dbias first. */

@@ -154,8 +154,11 @@ def _cfg(**over):
     return make_config(mode="validate", **over)
 
 
-def test_cfg3_conditioned2_512_L4():
-    """BASELINE configs[2] shape (the headline): 2x3x512x512, L=4, conditioned2ZTsepSubbands."""
+@pytest.mark.parametrize("plc_mode", ["f32", "f16x3"])
+def test_cfg3_conditioned2_512_L4(plc_mode, monkeypatch):
+    """BASELINE configs[2] shape (the headline): 2x3x512x512, L=4, conditioned2ZTsepSubbands; with the tree conv on the
+    fp32 MFMA (reference arithmetic) and on the split-fp16 path (same bars: no extra tolerance, flips counted)."""
+    monkeypatch.setenv("LLDWT_PLC_MODE", plc_mode)
     _parity(_cfg(dwtlevels=4, entropy_layer="conditioned2ZTsepSubbands"), natural_ish(2, 512, 512, 11))
 
 
@@ -164,8 +167,10 @@ def test_cfg2_factorized_256_L3():
     _parity(_cfg(dwtlevels=3, entropy_layer="factorized"), natural_ish(2, 256, 256, 12))
 
 
-def test_cfg4_onlyezwt_1024_L4():
+@pytest.mark.parametrize("plc_mode", ["f32", "f16x3"])
+def test_cfg4_onlyezwt_1024_L4(plc_mode, monkeypatch):
     """BASELINE configs[3] shape: 1x3x1024x1024, L=4, the inter-subband tree model."""
+    monkeypatch.setenv("LLDWT_PLC_MODE", plc_mode)
     _parity(_cfg(dwtlevels=4, entropy_layer="onlyEZWT"), natural_ish(1, 1024, 1024, 13))
 
 
