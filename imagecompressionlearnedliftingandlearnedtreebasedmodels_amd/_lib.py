@@ -109,6 +109,11 @@ SIGNATURES = {
     "lldwt_quantize": (_i, [_p, _p, _p, _i64, _p]),
     "lldwt_factorized_rate": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
     "lldwt_factorized_rate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
+    "lldwt_pmf_to_quantized_cdf": (_i, [_p, _i, _i, _p]),
+    "lldwt_rans_encode": (_i64, [_p, _p, _i64, _p, C.c_int32, C.c_int32, _p, _p, _p, _i64]),
+    "lldwt_rans_decoder_new": (_p, [_p, _i64]),
+    "lldwt_rans_decode": (_i, [_p, _p, _i64, _p, C.c_int32, C.c_int32, _p, _p, _p]),
+    "lldwt_rans_decoder_free": (None, [_p]),
     "lldwt_sq_err_sum": (_i, [_p, _p, _i64, _p, _p]),
     "lldwt_sum": (_i, [_p, _i64, _p, _p]),
     "lldwt_cdf97_ws_bytes": (_i64, [_i64, _i64, _i64]),

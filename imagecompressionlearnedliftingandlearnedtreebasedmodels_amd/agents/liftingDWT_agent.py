@@ -13,7 +13,8 @@ from .. import ops
 from ..graphs.losses.rate_dist import TrainDLoss, TrainRDLoss
 from .. import autograd as ag
 from .. import parallel
-from ..graphs.models.LiftingBasedDWT_net import LiftingBasedDWTNetWrapper, forward_planes, forward_planes_train
+from ..graphs.models.LiftingBasedDWT_net import (LiftingBasedDWTNetWrapper, byte_extractor, compress_planes,
+                                                  forward_planes, forward_planes_train)
 from ..dataloaders.image_dl import ImageDataLoader, SyntheticLoader  # noqa: F401  (SyntheticLoader: re-export)
 from ..loggers import RDLogger
 from .base import BaseAgent
@@ -143,9 +144,34 @@ class LiftingBasedDWTAgent(BaseAgent):
             ps, bs = ps + pp, bs + pb
         return ps + bs
 
+    @torch.no_grad()
     def test(self):
-        raise NotImplementedError("real entropy coding (rANS, LiftingBasedDWT_net.py:458-556) is outside the hot path "
-                                  "(SURVEY.md 8f.1)")
+        """agents/liftingDWT_agent.py:262-311: real entropy coding of the test set -- compress (range-ANS streams),
+        decompress FROM the streams, PSNR of the reconstruction, bits per pixel from the stream lengths."""
+        self.model.eval()
+        psnr, r_hi, r_lo = [], [], []
+        for x in self.data_loader.test_loader:
+            x = x.to(self.device)
+            if self.clrch != 1:
+                xs = (x - 0.5).contiguous()
+                xhat, byte_xe, byte_xo = self.model.compress(xs)
+            else:
+                y = ops.rgb_to_ycc(x.contiguous())                               # :281-283
+                yhat, s_xe, s_xo = compress_planes(self.model.nets(), y)
+                xhat = ops.ycc_to_rgb(yhat, clamp=True)                          # :286-294
+                n = x.shape[0] * x.shape[2] * x.shape[3]
+                byte_xe = 8.0 * sum(byte_extractor(r) for r in s_xe) / n
+                byte_xo = 8.0 * sum(byte_extractor(r) for lv in s_xo for r in lv) / n
+                xs = (x - 0.5).contiguous()
+            mse = float(torch.mean((xs - xhat.clamp(-0.5, 0.5)) ** 2))
+            psnr.append(10.0 * torch.log10(1.0 / torch.tensor(mse)))
+            r_hi.append(byte_xo)
+            r_lo.append(byte_xe)
+        m = lambda v: float(torch.tensor(v).mean()) if v else 0.0
+        ps, hi, lo = parallel.mean_over_ranks([m(psnr), m(r_hi), m(r_lo)], self.device)
+        print(" avg_psnr = %.2f, rate_high = %g, rate_low = %g, total_rate = %g" % (ps, hi, lo, hi + lo))
+        self.test_result = {"psnr": ps, "rate_high": hi, "rate_low": lo}
+        return True
 
 
 def configure_optimizers(net, lr):

@@ -1,10 +1,11 @@
 """Host-side mirrors of the two compressai==1.2.1 entropy models the reference uses (``EntropyBottleneck``,
 ``GaussianConditional``; imported at graphs/models/LiftingBasedDWT_net.py:3), running on the HIP rate kernels.
 
-Parameter / buffer names and shapes follow compressai so reference checkpoints load; the CDF tables used
-only by real entropy coding (``_offset``, ``_quantized_cdf``, ``_cdf_length``, ``scale_table``) are kept as empty
-buffers.  The arithmetic (likelihood + both LowerBounds + -log2) is one fused kernel: lldwt_gauss_rate /
-lldwt_factorized_rate (include/lldwt.h).
+Parameter / buffer names and shapes follow compressai so reference checkpoints load.  The arithmetic of
+rate estimation (likelihood + both LowerBounds + -log2) is one fused kernel: lldwt_gauss_rate / lldwt_factorized_rate
+(include/lldwt.h).  The CDF tables of real entropy coding (``_offset``, ``_quantized_cdf``, ``_cdf_length``,
+``scale_table``) are built by ``update_scale_table`` / ``update`` exactly as compressai 1.2.1 does (float32 pmf ->
+``pmf_to_quantized_cdf`` at 16 bits) and consumed by ans.py / graphs/models/entropy_coding.py.
 """
 import numpy as np
 import torch
@@ -41,17 +42,57 @@ class _EntropyModelBase(nn.Module):
         self.likelihood_bound = float(likelihood_bound)
         self.likelihood_lower_bound = LowerBound(likelihood_bound)     # state_dict: likelihood_lower_bound.bound
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kw):
+        # the CDF buffers change size with update(): take the incoming shapes (compressai: update_registered_buffers)
+        for name in ("_offset", "_quantized_cdf", "_cdf_length", "scale_table"):
+            key = prefix + name
+            buf = getattr(self, name, None)
+            if key in state_dict and buf is not None and tuple(state_dict[key].shape) != tuple(buf.shape):
+                setattr(self, name, torch.empty(state_dict[key].shape, dtype=buf.dtype, device=buf.device))
+        super()._load_from_state_dict(state_dict, prefix, *args, **kw)
+
+    # compressai exposes the tables under these names (read by compress_ar, LiftingBasedDWT_net.py:463-465)
+    @property
+    def offset(self):
+        return self._offset
+
+    @property
+    def quantized_cdf(self):
+        return self._quantized_cdf
+
+    @property
+    def cdf_length(self):
+        return self._cdf_length
+
+    def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
+        """EntropyModel._pmf_to_cdf: per row, (pmf[:length], tail mass) -> quantised CDF at 16 bits."""
+        from .ans import pmf_to_quantized_cdf
+        cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)
+        for i, p in enumerate(pmf):
+            prob = torch.cat((p[:int(pmf_length[i])], tail_mass[i]), dim=0)
+            c = pmf_to_quantized_cdf(prob, 16)
+            cdf[i, :len(c)] = torch.tensor(c, dtype=torch.int32)
+        return cdf
+
     def quantize(self, inputs, mode, means=None):
-        """compressai EntropyModel.quantize: 'noise' -> x + U(-.5,.5); 'dequantize' -> round(x - mu) + mu."""
+        """compressai EntropyModel.quantize: 'noise' -> x + U(-.5,.5); 'dequantize' -> round(x - mu) + mu;
+        'symbols' -> round(x - mu) as int32."""
         x = inputs.contiguous()
         if mode == "noise":
             noise = torch.empty_like(x).uniform_(-0.5, 0.5)
             return ops.quantize(x, noise)
-        if mode != "dequantize":
-            raise ValueError("only 'noise' / 'dequantize' are on the hot path (mode=%r)" % mode)
-        if means is None:
-            return ops.quantize(x)
-        return ops.quantize((x - means).contiguous()) + means
+        if mode not in ("dequantize", "symbols"):
+            raise ValueError("unknown quantisation mode %r" % mode)
+        r = ops.quantize(x if means is None else (x - means).contiguous())
+        if mode == "symbols":
+            return r.int()
+        return r if means is None else r + means
+
+    @staticmethod
+    def dequantize(inputs, means=None):
+        """symbols (int) -> float values, + means."""
+        out = inputs.float()
+        return out if means is None else out + means
 
 
 class GaussianConditional(_EntropyModelBase):
@@ -59,11 +100,54 @@ class GaussianConditional(_EntropyModelBase):
 
     def __init__(self, scale_table=None, scale_bound=0.11, tail_mass=1e-9, **kw):
         super().__init__(**kw)
+        self.tail_mass = float(tail_mass)
         if abs(float(scale_bound) - 0.11) > 1e-12:
             raise ValueError("the HIP rate kernel is built for scale_bound=0.11 (LiftingBasedDWT_net.py:291,307,318)")
         self.register_buffer("scale_table", torch.Tensor())
         self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]))
         self.lower_bound_scale = LowerBound(scale_bound)                # state_dict: lower_bound_scale.bound
+
+    @staticmethod
+    def _standardized_quantile(quantile):
+        from scipy.stats import norm
+        return float(norm.ppf(quantile))
+
+    def update_scale_table(self, scale_table, force=False):
+        """compressai GaussianConditional.update_scale_table (call site LiftingBasedDWT_net.py:462)."""
+        if self._offset.numel() > 0 and not force and self.scale_table.numel() == len(scale_table) and \
+                torch.equal(self.scale_table.cpu(), torch.as_tensor(scale_table).float().cpu()):
+            return False
+        dev = self.scale_bound.device
+        self.scale_table = torch.as_tensor(scale_table).float().to(dev)
+        self.update()
+        return True
+
+    def update(self):
+        """compressai GaussianConditional.update: one quantised CDF per scale-table entry (float32 on the host, once)."""
+        dev = self.scale_bound.device
+        table = self.scale_table.detach().float().cpu()
+        multiplier = -self._standardized_quantile(self.tail_mass / 2)
+        pmf_center = torch.ceil(table * multiplier).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = int(torch.max(pmf_length))
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+        samples_scale = table.unsqueeze(1)
+        cum = lambda z: 0.5 * torch.erfc(-(2 ** -0.5) * z)
+        upper = cum((0.5 - samples) / samples_scale)
+        lower = cum((-0.5 - samples) / samples_scale)
+        pmf = upper - lower
+        tail_mass = 2 * lower[:, :1]
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
+        self._offset = (-pmf_center).int().to(dev)
+        self._cdf_length = (pmf_length + 2).int().to(dev)
+
+    def build_indexes(self, scales):
+        """compressai GaussianConditional.build_indexes: index of the first scale-table entry >= max(scale, bound)
+        (= len(table)-1 minus the number of the first len-1 entries that are >= the bounded scale)."""
+        s = torch.clamp(scales, min=float(self.scale_bound))           # lower_bound_scale (forward value)
+        table = self.scale_table.to(s.device)
+        # entries t with s <= t among table[:-1]  ==  (len-1) - #(t < s)  ->  index = #(table[:-1] < s)
+        return torch.bucketize(s.contiguous(), table[:-1].contiguous(), right=False).int()
 
     def bits(self, inputs, params, noise=None, want_q=False, bit_sum=None):
         """Fused path: inputs (P,B,C,h,w), params (P,B,2C,h,w) -> (-log2 likelihood, quantised)."""

@@ -6,8 +6,12 @@ Same class names, constructor signature (one ``config`` object), dispatch string
 layout.  The three per-plane networks of ``clrch == 1`` are executed TOGETHER: every kernel launch covers the three
 planes and the whole batch (plane-major tensors, per-plane weights stacked), instead of three sequential sub-networks.
 
-Real entropy coding (``compress`` / ``test``, :136-152,374-556) is outside the hot path.
+Real entropy coding (``compress`` / ``test`` / ``compress_ar`` / ``decompress_ar``, :76-99,136-152,374-556) is built for
+the layer the reference builds it for, ``DWTConditioned2EntropyLayerZTsepSubbands``: the per-pixel Python loops become a
+wavefront schedule on the GPU (entropy_coding.py) and the range coder is the C-ABI's host rANS (ans.py).
 """
+import math
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -21,6 +25,21 @@ from ..layers.lifting_dwt_nets import (DWTPytorchWaveletsLayer, LiftingBasedNeur
 from ..layers.masked_conv2d import MaskedConv2d
 
 SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
+
+
+def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
+    """LiftingBasedDWT_net.py:32-33: 64 log-spaced Gaussian scales from 0.11 to 256."""
+    return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
+
+
+def byte_extractor(string):
+    """LiftingBasedDWT_net.py:15-17 (bytes of one stream; a list of per-image streams counts all of them)."""
+    return len(string) if isinstance(string, (bytes, bytearray)) else sum(len(s) for s in string)
+
+
+def byte_extractor_xo(strings):
+    """LiftingBasedDWT_net.py:19-31 for this layer's return value: one stream (or per-image list) per level."""
+    return sum(byte_extractor(s) for s in strings)
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -180,6 +199,7 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
         self._init_packed_owner()
         self._level_channels(config)
         self.config = config
+        self.scale_table = get_scale_table()              # plain attribute, as in the reference (:245)
         L = self.num_lifting_layers
         self.plc_list = nn.ModuleList()
         self.csc_list = nn.ModuleList()
@@ -256,6 +276,93 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
         q_list.reverse()
         si_list.reverse()
         return si_xe, si_list, xe_q, q_list
+
+
+    # ---------------------------------------------------------------- real entropy coding (:374-556)
+    def test(self, out_xe, out_xo_list):
+        """Reference signature (:374): (B,C,h,w) tensors of ONE plane -> (string_xe, [string_xo per level, finest first],
+        decoded xe, [decoded xo]).  Strings are ``bytes`` at batch 1 (as in the reference), lists of per-image bytes else."""
+        s_xe, s_xo, xe, xo = self.test_planes([self], out_xe[None].contiguous(), [t[None].contiguous() for t in out_xo_list])
+        one = lambda rows: rows[0][0] if len(rows[0]) == 1 else rows[0]
+        return one(s_xe), [one(r) for r in s_xo], xe[0], [t[0] for t in xo]
+
+    @staticmethod
+    def test_planes(layers, out_xe, out_xo_list):
+        """Encode, then decode FROM THE STRINGS (the reference returns the decoder's tensors, :419-456)."""
+        cls = DWTConditioned2EntropyLayerZTsepSubbands
+        s_xe, s_xo, _, _ = cls.compress_planes(layers, out_xe, out_xo_list)
+        xe, xo = cls.decompress_planes(layers, s_xe, s_xo, out_xe.shape, [t.shape for t in out_xo_list])
+        return s_xe, s_xo, xe, xo
+
+    @staticmethod
+    def _coding_setup(layers):
+        from .entropy_coding import _Tables
+        l0 = layers[0]
+        tabs = l0.__dict__.get("_rans_tables")
+        if tabs is None:
+            tabs = l0.__dict__["_rans_tables"] = _Tables(l0.ent_out_xe, l0.scale_table)
+        for l in layers:                                   # every Gaussian model carries the same table (:462)
+            for em in [l.ent_out_xe] + list(l.ent_out_xo_list):
+                em.update_scale_table(l.scale_table)
+        stack = lambda seqs, crop: _seq_stack(seqs, crop, (0, 2, 4, 6, 8))
+        return tabs, stack
+
+    @staticmethod
+    def _tree_context(layers, i, parent, so):
+        seqs = [l.plc_list[i] for l in layers]
+        plc = _plc_pair([s[0] for s in seqs], [s[2] for s in seqs], parent, ops.ACT_NONE)
+        cg = [l.cgp_out_xo_list[i] for l in layers]
+        cs = [l.csc_list[i] for l in layers]
+        convs = [[s[n] for s in cg] for n in (0, 2, 4, 6)]
+        for m in cs:
+            m.apply_mask_()
+        packed, dims = cached(cg[0], ("cgp_ctx",), [p for layer in convs for m in layer for p in (m.weight, m.bias)] +
+                              [p for m in cs for p in (m.weight, m.bias)], lambda: _fold_csc_into_cgp(convs, cs, so))
+        return plc, packed, dims, cs[0].kernel_size[0], cs[0].tap_bits()
+
+    @staticmethod
+    def compress_planes(layers, out_xe, out_xo_list):
+        """compress_ar for every tensor (:386-417): -> (strings_xe[p][b], [strings_xo[p][b]] finest first, xe_q, [xo_q])
+        with *_q = round(y - mu) + mu, the values the decoder reconstructs."""
+        from . import entropy_coding as ec
+        tabs, stack = DWTConditioned2EntropyLayerZTsepSubbands._coding_setup(layers)
+        L = len(out_xo_list)
+        with torch.no_grad():
+            s_xe, xe_q = ec.code_crop_stack(stack, [l.ent_out_xe for l in layers], [l.csc_xe for l in layers], out_xe,
+                                            out_xe.shape, tabs)
+            s, q = ec.code_crop_stack(stack, [l.ent_out_xo_list[L - 1] for l in layers], [l.csc_list[L - 1] for l in layers],
+                                      out_xo_list[L - 1], out_xo_list[L - 1].shape, tabs)
+            s_list, q_list = [s], [q]
+            for i in range(L - 2, -1, -1):
+                x = out_xo_list[i]
+                plc, packed, dims, K, bits = DWTConditioned2EntropyLayerZTsepSubbands._tree_context(layers, i, q, x.shape[2])
+                s, q = ec.code_tree_level([l.ent_out_xo_list[i] for l in layers], plc, packed, dims, K, bits, x, x.shape, tabs)
+                s_list.append(s)
+                q_list.append(q)
+        s_list.reverse()
+        q_list.reverse()
+        return s_xe, s_list, xe_q, q_list
+
+    @staticmethod
+    def decompress_planes(layers, strings_xe, strings_xo_list, shape_xe, shapes_xo):
+        """decompress_ar for every tensor (:419-454): strings -> (xe, [xo] finest first), bit-identical to compress_planes'
+        dequantised tensors."""
+        from . import entropy_coding as ec
+        tabs, stack = DWTConditioned2EntropyLayerZTsepSubbands._coding_setup(layers)
+        L = len(shapes_xo)
+        with torch.no_grad():
+            _, xe = ec.code_crop_stack(stack, [l.ent_out_xe for l in layers], [l.csc_xe for l in layers], None, shape_xe, tabs,
+                                       strings_xe)
+            _, q = ec.code_crop_stack(stack, [l.ent_out_xo_list[L - 1] for l in layers], [l.csc_list[L - 1] for l in layers],
+                                      None, shapes_xo[L - 1], tabs, strings_xo_list[L - 1])
+            q_list = [q]
+            for i in range(L - 2, -1, -1):
+                plc, packed, dims, K, bits = DWTConditioned2EntropyLayerZTsepSubbands._tree_context(layers, i, q, shapes_xo[i][2])
+                _, q = ec.code_tree_level([l.ent_out_xo_list[i] for l in layers], plc, packed, dims, K, bits, None, shapes_xo[i],
+                                          tabs, strings_xo_list[i])
+                q_list.append(q)
+        q_list.reverse()
+        return xe, q_list
 
 
 class DWTConditioned2EntropyLayerZTBlock(_EntropyLayerBase):
@@ -656,6 +763,19 @@ def rate_planes(nets, x, training=False):
     return si_xe, si_xo
 
 
+def compress_planes(nets, x):
+    """encode -> real entropy coding (compress + decompress from the strings) -> decode, for a list of per-plane nets;
+    x (P,B,C,H,W) -> (xhat, strings_xe[p][b], [strings_xo[p][b] per level])."""
+    em = [n.entropymodel for n in nets]
+    if not hasattr(type(em[0]), "test_planes"):
+        raise NotImplementedError("real entropy coding exists for conditioned2ZTsepSubbands only, as in the reference "
+                                  "(the other entropy layers have no test(); LiftingBasedDWT_net.py:145-146 would fail there too)")
+    out_xe, out_xo = encode_planes([n.autoencoder for n in nets], x)
+    s_xe, s_xo, xe_q, xo_q = type(em[0]).test_planes(em, out_xe, out_xo)
+    xhat = decode_planes([n.autoencoder for n in nets], xe_q, xo_q)
+    return xhat, s_xe, s_xo
+
+
 class LiftingBasedDWTNet(PackedOwnerMixin, nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -673,6 +793,12 @@ class LiftingBasedDWTNet(PackedOwnerMixin, nn.Module):
     def forward(self, x):
         xhat, si_xe, si_xo = forward_planes([self], x[None].contiguous(), self.training)
         return xhat[0], si_xe[0], [t[0] for t in si_xo]
+
+    def compress(self, x):
+        """LiftingBasedDWT_net.py:136-152: encode -> entropymodel.test (real coding, both directions) -> decode."""
+        xhat, s_xe, s_xo = compress_planes([self], x[None].contiguous())
+        one = lambda rows: rows[0][0] if len(rows[0]) == 1 else rows[0]
+        return xhat[0], one(s_xe), [one(r) for r in s_xo]
 
     def aux_loss(self):
         return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
@@ -708,6 +834,19 @@ class LiftingBasedDWTNetWrapper(PackedOwnerMixin, nn.Module):
         xhat, si_xe, si_xo = self.forward_planes(x_pm)
         si_list = [t[p] for p in range(3) for t in si_xo]               # extend(): plane 0 levels, plane 1 ..., :58-61
         return (xhat[:, :, 0].permute(1, 0, 2, 3).contiguous(), si_xe[:, :, 0].permute(1, 0, 2, 3).contiguous(), si_list)
+
+    def compress(self, x):
+        """LiftingBasedDWT_net.py:76-99: -> (xhat, bpp of the low-pass streams, bpp of the subband streams); bytes * 8 over
+        the pixels of the batch (the reference divides by H*W at its batch size of 1)."""
+        if self.clrch == 3:
+            return self.model.compress(x)
+        B, _, H, W = x.shape
+        x_pm = x.permute(1, 0, 2, 3).unsqueeze(2).contiguous()
+        xhat, s_xe, s_xo = compress_planes(self.nets(), x_pm)
+        self.last_strings = (s_xe, s_xo)
+        len_xe = sum(byte_extractor(row) for row in s_xe)
+        len_xo = sum(byte_extractor(row) for level in s_xo for row in level)
+        return (xhat[:, :, 0].permute(1, 0, 2, 3).contiguous(), len_xe * 8 / (B * H * W), len_xo * 8 / (B * H * W))
 
     def aux_loss(self):
         return sum(n.aux_loss() for n in self.nets())

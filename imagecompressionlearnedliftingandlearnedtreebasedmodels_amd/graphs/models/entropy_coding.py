@@ -1,0 +1,189 @@
+"""Real entropy coding of DWTConditioned2EntropyLayerZTsepSubbands -- replaces the per-pixel Python loops of the
+reference's ``test`` / ``compress_ar`` / ``decompress_ar`` (graphs/models/LiftingBasedDWT_net.py:374-556).
+
+What the reference does, per tensor: walk the pixels in raster order; at each pixel run the context CNN on a k x k crop of
+the values decoded so far, read (sigma, mu) at the crop's centre, code ``round(y - mu)`` with the Gaussian CDF selected by
+sigma (64-entry scale table), and write ``round(y - mu) + mu`` back for the pixels that follow.  That is O(pixels) tiny
+sequential CNN calls -- minutes per image.
+
+What this module does: the SAME per-pixel maths, scheduled as an anti-diagonal WAVEFRONT.  A pixel only depends on
+already-coded neighbours inside the causal footprint of its context model, so every pixel with the same
+``t = w + s*h`` is independent of the others once steps < t are done:
+  * 3x3-crop stacks (``csc_xe`` and the coarsest ``csc_list`` entry, :311-317,299-305): the crop reaches (h-1, w+1) -> s = 2;
+  * masked 5x5 type-A conv + tree context + cgp (:275-289): the mask reaches (h-1, w+2) -> s = 3.
+One wavefront step is evaluated for all planes, images, subbands and pixels of the step in a handful of launches of the
+kernels the rate path already has (conv engine on the batch of crops; fused cgp kernel with the context conv folded into
+its first layer on the gathered taps), so a 256 x 256 subband needs ~1 000 steps instead of 65 536 x 3 Python iterations.
+The tree-context conv (243 channels, the expensive part) does not depend on the tensor being coded and runs once, fully
+parallel, per level.
+
+Stream layout: one range-ANS stream per (plane, image, tensor) (the reference: per plane and tensor at batch 1), symbols
+in WAVEFRONT order -- step t ascending, inside a step h ascending, channels innermost -- because that is the order a
+parallel decoder can consume them in (the reference's raster order would serialise it again).  The coder itself is
+ans.py (host C++ behind the C-ABI); symbols and CDF indexes are produced on the GPU.  Encoder and decoder evaluate the
+context with the same kernels on the same operand shapes, so their (sigma, mu) agree bit for bit; not-yet-coded positions
+hold 0 on both sides (the reference's encoder holds the unquantised value there, which the masks multiply by 0).
+"""
+import numpy as np
+import torch
+
+from ... import ops
+from ...ans import BufferedRansEncoder, RansDecoder
+
+_WF_CACHE = {}
+
+
+def wavefront(H, W, slope, device):
+    """-> (hs, ws, starts): pixel coordinates sorted by (t = w + slope*h, h) as device int64 tensors, and the python
+    list of step boundaries (len = steps + 1)."""
+    key = (H, W, slope, str(device))
+    hit = _WF_CACHE.get(key)
+    if hit is None:
+        h = np.repeat(np.arange(H), W)
+        w = np.tile(np.arange(W), H)
+        t = w + slope * h
+        order = np.lexsort((h, t))
+        h, w, t = h[order], w[order], t[order]
+        nsteps = W + slope * (H - 1)
+        starts = np.searchsorted(t, np.arange(nsteps + 1)).tolist()
+        hit = (torch.from_numpy(h).to(device), torch.from_numpy(w).to(device), starts)
+        _WF_CACHE[key] = hit
+    return hit
+
+
+def _live_taps(mask_bits, K):
+    return [(t // K, t % K) for t in range(K * K) if (mask_bits >> t) & 1]
+
+
+class _Tables:
+    """The Gaussian CDF tables of one entropy model as host int32 arrays (shared by every stream of a tensor)."""
+
+    def __init__(self, emodel, scale_table):
+        emodel.update_scale_table(scale_table)
+        self.cdf = emodel.quantized_cdf.cpu().numpy().astype(np.int32)
+        self.sizes = emodel.cdf_length.cpu().numpy().astype(np.int32)
+        self.offsets = emodel.offset.cpu().numpy().astype(np.int32)
+
+
+class _Sink:
+    """Where the symbols of a tensor go (encoder) or come from (decoder), one stream per (plane, image)."""
+
+    def __init__(self, P, B, tables, strings=None):
+        self.P, self.B, self.t = P, B, tables
+        self.decoding = strings is not None
+        if self.decoding:
+            self.dec = [[RansDecoder() for _ in range(B)] for _ in range(P)]
+            for p in range(P):
+                for b in range(B):
+                    self.dec[p][b].set_stream(strings[p][b])
+        else:
+            self.sym, self.idx = [], []
+
+    def step(self, idx, sym=None):
+        """idx / sym: (P,B,N,g) int32 device tensors of one wavefront step.  Encoder: buffers them (device, no sync).
+        Decoder: pops the step's symbols from the streams -> (P,B,N,g) int32 device tensor (one host round trip)."""
+        if not self.decoding:
+            self.idx.append(idx)
+            self.sym.append(sym)
+            return sym
+        ih = idx.cpu().numpy()
+        out = np.empty(ih.shape, dtype=np.int32)
+        for p in range(self.P):
+            for b in range(self.B):
+                out[p, b] = self.dec[p][b].decode_stream(ih[p, b].reshape(-1), self.t.cdf, self.t.sizes, self.t.offsets,
+                                                         as_numpy=True).reshape(ih.shape[2:])
+        return torch.from_numpy(out).to(idx.device)
+
+    def flush(self):
+        """Encoder: -> strings[p][b]."""
+        idx = torch.cat(self.idx, 2).cpu().numpy()          # (P,B,Npix,g) in wavefront order
+        sym = torch.cat(self.sym, 2).cpu().numpy()
+        out = []
+        for p in range(self.P):
+            row = []
+            for b in range(self.B):
+                e = BufferedRansEncoder()
+                e.encode_with_indexes(sym[p, b].reshape(-1), idx[p, b].reshape(-1), self.t.cdf, self.t.sizes, self.t.offsets)
+                row.append(e.flush())
+            out.append(row)
+        return out
+
+
+def _finish_step(emodel, sink, sigma, mu, yv):
+    """sigma, mu (P,B,g,N); yv (P,B,g,N) or None when decoding -> dequantised values (P,B,g,N)."""
+    idx = emodel.build_indexes(sigma).permute(0, 1, 3, 2).contiguous()                 # (P,B,N,g)
+    sym = None
+    if yv is not None:
+        sym = torch.round(yv - mu).int().permute(0, 1, 3, 2).contiguous()              # quantize(..., "symbols", mu)
+    sym = sink.step(idx, sym)
+    return sym.permute(0, 1, 3, 2).float() + mu                                         # dequantize: symbol + mu
+
+
+def code_crop_stack(seq_stack, emodels, seqs, y, shape, tables, strings=None):
+    """The 3x3-crop context (LiftingBasedDWT_net.py:388-401 / :424-433 with compress_ar / decompress_ar at
+    network_kernel_size 3).  y: (P,B,g,H,W) coefficients (encoder) or None (decoder); -> (strings or None, dequantised)."""
+    P, B, g, H, W = shape
+    dev = y.device if y is not None else next(seqs[0].parameters()).device
+    hs, ws, starts = wavefront(H, W, 2, dev)
+    sink = _Sink(P, B, tables, strings)
+    yhat = torch.zeros(P, B, g, H + 2, W + 2, device=dev, dtype=torch.float32)       # 1-pixel zero frame = the crop padding
+    ar = torch.arange(3, device=dev)
+    for t in range(len(starts) - 1):
+        a, b = starts[t], starts[t + 1]
+        if a == b:
+            continue
+        h, w = hs[a:b], ws[a:b]
+        N = b - a
+        rows = (h[:, None, None] + ar[None, :, None]).expand(N, 3, 3)
+        cols = (w[:, None, None] + ar[None, None, :]).expand(N, 3, 3)
+        crop = yhat[:, :, :, rows, cols]                                              # (P,B,g,N,3,3)
+        crop = crop.permute(0, 1, 3, 2, 4, 5).reshape(P, B * N, g, 3, 3).contiguous()
+        ms = seq_stack(seqs, crop)[:, :, :, 1, 1].reshape(P, B, N, 2 * g)             # centre of every crop
+        sigma = ms[..., 0::2].permute(0, 1, 3, 2)                                     # (P,B,g,N): even = sigma, odd = mu
+        mu = ms[..., 1::2].permute(0, 1, 3, 2)
+        yv = y[:, :, :, h, w] if y is not None else None
+        yhat[:, :, :, h + 1, w + 1] = _finish_step(emodels[0], sink, sigma, mu, yv)
+    out = yhat[:, :, :, 1:-1, 1:-1].contiguous()
+    return (None if sink.decoding else sink.flush()), out
+
+
+def code_tree_level(emodels, plc, cgp_packed, cgp_dims, K, tap_bits, y, shape, tables, strings=None):
+    """A level with tree context + masked KxK context + cgp (:402-417 / :440-454 with kernel size 5).  plc: (P,B,G*81,H,W)
+    tree-context features of the (decoded) parent; cgp_packed/dims: the cgp stack with the masked conv folded into its
+    first layer (_fold_csc_into_cgp)."""
+    P, B, G, H, W = shape
+    dev = plc.device
+    R = K // 2
+    taps = _live_taps(tap_bits, K)
+    cpl = plc.shape[2] // G
+    hs, ws, starts = wavefront(H, W, R + 1, dev)
+    sink = _Sink(P, B, tables, strings)
+    yhat = torch.zeros(P, B, G, H + 2 * R, W + 2 * R, device=dev, dtype=torch.float32)
+    dy = torch.tensor([t[0] for t in taps], device=dev)
+    dx = torch.tensor([t[1] for t in taps], device=dev)
+    for t in range(len(starts) - 1):
+        a, b = starts[t], starts[t + 1]
+        if a == b:
+            continue
+        h, w = hs[a:b], ws[a:b]
+        N = b - a
+        ctx = yhat[:, :, :, h[None, :] + dy[:, None], w[None, :] + dx[:, None]]       # (P,B,G,ntaps,N): causal neighbours
+        feat = plc[:, :, :, h, w].reshape(P, B, G, cpl, N)                            # (P,B,G,81,N)
+        cat = torch.cat((feat, ctx), 3).reshape(P, B, G * (cpl + len(taps)), 1, N).contiguous()
+        yv = y[:, :, :, h, w] if y is not None else None
+        xarg = (yv if yv is not None else torch.zeros(P, B, G, N, device=dev)).reshape(P, B, G, 1, N).contiguous()
+        _, params = ops.cgp_rate(cat, xarg, cgp_packed, cgp_dims, want_params=True)   # (P,B,2G,1,N)
+        sigma, mu = params[:, :, 0::2, 0, :], params[:, :, 1::2, 0, :]
+        yhat[:, :, :, h + R, w + R] = _finish_step(emodels[0], sink, sigma, mu, yv)
+    out = yhat[:, :, :, R:-R, R:-R].contiguous()
+    return (None if sink.decoding else sink.flush()), out
+
+
+def ideal_bits(sym, idx, tables):
+    """Code length (bits) of integer symbols under the quantised tables; escapes are not modelled (returns their count)."""
+    cdf, sizes, offs = tables.cdf, tables.sizes, tables.offsets
+    v = sym - offs[idx]
+    inside = (v >= 0) & (v < sizes[idx] - 2)
+    vi = np.where(inside, v, 0)
+    freq = cdf[idx, vi + 1] - cdf[idx, vi]
+    return float(-np.log2(freq[inside] / 65536.0).sum()), int((~inside).sum())

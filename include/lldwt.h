@@ -280,6 +280,28 @@ int lldwt_nonneg_param_fwd(const float* x, float* y, int64_t n, float minimum, v
 int lldwt_nonneg_param_bwd(const float* x, const float* gy, float* gx, int64_t n, float minimum, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Real entropy coding (reference: compress_ar / decompress_ar, LiftingBasedDWT_net.py:458-556, on
+ * compressai.ans).  HOST functions (csrc/rans.hip): the range-ANS state machine is sequential byte work; the symbols
+ * and CDF indexes it consumes are produced on the GPU by the wavefront scheduler of graphs/models/entropy_coding.py.
+ *   lldwt_pmf_to_quantized_cdf : compressai `pmf_to_quantized_cdf` -- float pmf (n entries, tail mass last) -> n+1
+ *                                cumulative counts at `precision` bits, every symbol with a non-zero frequency.
+ *   lldwt_rans_encode          : BufferedRansEncoder.encode_with_indexes + flush (:466,502-505).  cdfs is an
+ *                                (ncdf, cdf_stride) int32 table, cdf_sizes[i] = used entries of row i (= pmf length + 2),
+ *                                offsets[i] = symbol value of slot 0.  Returns the number of bytes written to `out`
+ *                                (a multiple of 4, <= out_cap) or a negative error code.  Out-of-table symbols are
+ *                                escaped through the last slot and 4-bit bypass digits.
+ *   lldwt_rans_decoder_new / _decode / _free : RansDecoder.set_stream / decode_stream (:516-517,540-546): an opaque
+ *                                handle owning a copy of the stream; decode pops n symbols in coding order.        */
+int lldwt_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf);
+int64_t lldwt_rans_encode(const int32_t* symbols, const int32_t* indexes, int64_t n, const int32_t* cdfs, int32_t ncdf,
+                          int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, uint8_t* out,
+                          int64_t out_cap);
+void* lldwt_rans_decoder_new(const uint8_t* stream, int64_t nbytes);
+int lldwt_rans_decode(void* dec, const int32_t* indexes, int64_t n, const int32_t* cdfs, int32_t ncdf, int32_t cdf_stride,
+                      const int32_t* cdf_sizes, const int32_t* offsets, int32_t* symbols);
+void lldwt_rans_decoder_free(void* dec);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Rate estimation, fused quantise + likelihood + both LowerBounds + -log2 + sum of bits.
  * Gaussian (compressai GaussianConditional.forward as called at LiftingBasedDWT_net.py:334,345,364,832):
  *   v = mode==0 ? round(x - mu) + mu : x + noise       (noise: U(-.5,.5) tensor or NULL -> eval)
