@@ -52,6 +52,8 @@ SIGNATURES = {
     "lldwt_u8hwc_to_f32chw": (_i, [_p, _p, _i64, _i64, _i64, _p]),
     "lldwt_ycc_to_rgb": (_i, [_p, _p, _i64, _i64, _i64, _i, _p]),
     "lldwt_pblock_packed_floats": (_i64, [_i, _i]),
+    "lldwt_set_lift_mode": (_i, [_i]),
+    "lldwt_get_lift_mode": (_i, []),
     "lldwt_pack_pblock": (_i, [_p] * 9 + [_i, _i, _i, _p]),
     "lldwt_lift_step_ws_bytes": (_i64, [_i64, _i64, _i64, _i]),
     "lldwt_lift_step": (_i, [View, View, View, _i64, _i64, _i64, _i64, _p, _p, _i, _i, _i, _f, _f, _i, _p, _i64, _p]),
@@ -141,6 +143,10 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    mode = os.environ.get("LLDWT_LIFT_MODE", "f16x3")
+    if mode not in ("f16x3", "f32"):
+        raise LLDWTError("LLDWT_LIFT_MODE must be 'f16x3' or 'f32' (got %r)" % mode)
+    lib.lldwt_set_lift_mode(1 if mode == "f16x3" else 0)
     return lib
 
 

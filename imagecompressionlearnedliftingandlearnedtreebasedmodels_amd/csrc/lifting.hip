@@ -8,13 +8,16 @@
 // The polyphase split / merge is pure addressing through lldwt_view (no transposes, no copies); the horizontal
 // pass uses the (kh,kw)-transposed weights instead of transposing the data.
 #include "common.h"
+#include "lifting_f16.h"
 
 namespace lldwt {
+
+static int g_lift_mode = 1;      // 1: fused split-fp16 step kernel where it applies (eval, C=16, K=5, tanh); 0: fp32 MFMA kernels
 
 static inline __host__ __device__ int pad16(int n) { return (n + 15) & ~15; }
 
 struct PackOff {
-    int w1, b1, w2, b2, w3, b3, w4, b4, orient, total;
+    int w1, b1, w2, b2, w3, b3, w4, b4, orient, f16, total;   // f16: start of the split-fp16 section (lifting_f16.h)
 };
 static inline __host__ __device__ PackOff pack_off(int C, int K) {
     PackOff o;
@@ -28,7 +31,8 @@ static inline __host__ __device__ PackOff pack_off(int C, int K) {
     o.w4 = o.b3 + pad16(C);
     o.b4 = o.w4 + pad16(C * KK);
     o.orient = o.b4 + 16;
-    o.total = 2 * o.orient;
+    o.f16 = 2 * o.orient;
+    o.total = o.f16 + lift_f16_floats(C, K);
     return o;
 }
 
@@ -50,7 +54,7 @@ __global__ void k_pack_pblock(const float* __restrict__ w1, const float* __restr
     b2 += plane * C;
     b3 += plane * C;
     b4 += plane;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < o.total; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < o.f16; i += gridDim.x * blockDim.x) {
         int orient = i / o.orient;
         int j = i - orient * o.orient;
         float v = 0.f;
@@ -1184,6 +1188,15 @@ template <int C, int K>
 static int launch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, int64_t Z, int64_t batch, int64_t h,
                        int64_t w, const float* taps, const float* packed, int64_t pstride, int vertical, float sign,
                        float rw, int linear, const StepBufs& b, hipStream_t st) {
+    if constexpr (C == LF_C && K == LF_K) {
+        // eval path (no intermediates to save), tanh P-block: ONE fused launch on the fp16 matrix cores (lifting_f16.hip)
+        if (g_lift_mode == 1 && !linear && b.t1 == nullptr) {
+            LiftF16Views v{src.p, src.sz, src.sy, src.sx, dst_in.p, dst_in.sz, dst_in.sy, dst_in.sx,
+                           dst_out.p, dst_out.sz, dst_out.sy, dst_out.sx};
+            const PackOff o = pack_off(C, K);
+            return lift_f16_step(v, Z, batch, h, w, taps, packed, pstride, o.orient, o.f16, vertical, sign, rw, st);
+        }
+    }
     dim3 grid((unsigned)cdiv(w, TW), (unsigned)cdiv(h, TH), (unsigned)Z), block(NT);
     if constexpr (C == 16) {
         constexpr int R = K / 2, R2 = 2 * R, KK = K * K;
@@ -1410,6 +1423,13 @@ using namespace lldwt;
 
 extern "C" int64_t lldwt_pblock_packed_floats(int C, int K) { return pack_off(C, K).total; }
 
+extern "C" int lldwt_set_lift_mode(int mode) {
+    LLDWT_REQUIRE(mode == 0 || mode == 1, "set_lift_mode: 0 (fp32 MFMA kernels) or 1 (fused split-fp16 kernel)");
+    g_lift_mode = mode;
+    return LLDWT_OK;
+}
+extern "C" int lldwt_get_lift_mode(void) { return g_lift_mode; }
+
 extern "C" int lldwt_pack_pblock(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                  const float* b3, const float* w4, const float* b4, float* packed, int planes, int C,
                                  int K, void* stream) {
@@ -1419,6 +1439,10 @@ extern "C" int lldwt_pack_pblock(const float* w1, const float* b1, const float* 
     dim3 grid((unsigned)cdiv(o.total, 256), (unsigned)planes);
     hipLaunchKernelGGL(k_pack_pblock, grid, dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3, w4, b4, packed, C,
                        K);
+    if (lift_f16_floats(C, K) > 0) {
+        int r = lift_f16_pack(w1, w2, w3, w4, packed, o.total, o.f16, planes, (hipStream_t)stream);
+        if (r) return r;
+    }
     return check_launch("pack_pblock");
 }
 

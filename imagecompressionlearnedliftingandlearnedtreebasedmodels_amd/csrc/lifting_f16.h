@@ -1,0 +1,38 @@
+// lifting_f16.h -- shared between lifting.hip (pack layout, step dispatch) and lifting_f16.hip (the fused split-fp16
+// lifting-step kernel).  Internal to the library.
+#pragma once
+#include "common.h"
+
+namespace lldwt {
+
+// The fused kernel exists for the reference's configuration: 16 channels (depth_scale*8, liftingDWT.json:22), 5x5.
+constexpr int LF_C = 16, LF_K = 5, LF_KK = 25;
+constexpr int LF_KS = 13;                 // k-steps of 32 = 2 taps x 16 channels (25 taps -> 26, the last one zero)
+constexpr int LF_KS4 = 3;                 // conv4 as D[dx][px]: K = 5 dy x 16 ch = 80 -> 3 k-steps of 32
+constexpr int LF_FRAG = 1024;             // halves per k-step: (hi, lo) x 64 lanes x 8
+// per orientation, in HALVES: conv1 | conv2 | conv3 | conv4 fragments; then 16 floats: s_w1..s_w4, b1[16]... (see .hip)
+constexpr int LF_H_C1 = 0;
+constexpr int LF_H_C2 = LF_H_C1 + LF_FRAG;
+constexpr int LF_H_C3 = LF_H_C2 + LF_KS * LF_FRAG;
+constexpr int LF_H_C4 = LF_H_C3 + LF_KS * LF_FRAG;
+constexpr int LF_H_END = LF_H_C4 + LF_KS4 * LF_FRAG;          // 30 * 1024 halves
+constexpr int LF_ORIENT_FLOATS = LF_H_END / 2 + 16;           // + scales (4 floats, padded to 16)
+constexpr int LF_FLOATS = 2 * LF_ORIENT_FLOATS;               // both orientations
+
+static inline __host__ __device__ int lift_f16_floats(int C, int K) { return (C == LF_C && K == LF_K) ? LF_FLOATS : 0; }
+
+// pack the f16 section of one P/U block (called from lldwt_pack_pblock after the fp32 section is written)
+int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, float* packed, int64_t plane_stride,
+                  int f16_off, int planes, hipStream_t st);
+
+// one fused lifting step (eval): dst_out = dst_in + sign * (skip + rw * P(skip)); returns LLDWT_OK or an error
+struct LiftF16Views {
+    const float* src;  int64_t src_sz, src_sy, src_sx;
+    const float* din;  int64_t din_sz, din_sy, din_sx;
+    float* dout;       int64_t dout_sz, dout_sy, dout_sx;
+};
+int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, int64_t w, const float* taps,
+                  const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical, float sign, float rw,
+                  hipStream_t st);
+
+}  // namespace lldwt

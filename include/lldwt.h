@@ -74,6 +74,11 @@ int lldwt_u8hwc_to_f32chw(const uint8_t* src, float* dst, int64_t B, int64_t H, 
  *   (vertical pass uses W, horizontal pass uses W transposed in (kh,kw): conv(x^T,W)^T == conv(x,W^T), which
  *   removes every torch.transpose of wavelet_forward_v2.py:32,38-39,43,50-51).                           */
 int64_t lldwt_pblock_packed_floats(int C, int K);
+/* Arithmetic of the eval-path lifting step for C = 16, K = 5 (the reference's configuration): 1 (default) = ONE fused
+ * launch per step with the 16 -> 16 convolutions on the fp16 matrix cores, split-fp16 operands, intermediates in LDS
+ * (csrc/lifting_f16.hip); 0 = the three fp32-MFMA launches (exact fp32 products; also what training uses).       */
+int lldwt_set_lift_mode(int mode);
+int lldwt_get_lift_mode(void);
 int lldwt_pack_pblock(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                       const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
                       void* stream);
