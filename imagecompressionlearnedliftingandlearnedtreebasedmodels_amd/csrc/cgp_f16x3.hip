@@ -1,0 +1,390 @@
+// cgp_f16x3.hip -- the context-fusion MLP of the tree + intra-subband model (cgp_out_xo_list, reference
+// graphs/models/LiftingBasedDWT_net.py:282-289,357-365) on the fp16 matrix cores with split-fp16 operands, as ONE
+// register-resident chain per wave: no LDS, no barrier.
+//
+// Per subband g (groups = 3) and pixel:  [81 tree-context features | 12 causal taps of the quantised subband] (the masked
+// context conv folded into layer 0 on the host, _fold_csc_into_cgp)  -> 162 -> 54 -> 18 -> 2 = (sigma, mu), LeakyReLU(0.01)
+// between layers.  fp32 reference arithmetic: k_cgp_rate (cgp_fused.hip), which runs at 36 % of the fp32 MFMA roof.
+//
+// v_mfma_f32_32x32x16_f16, A = weights (32 output channels x 16 inputs per step), B = activations (16 inputs x 32 pixels):
+//   * layer 0's B fragments come STRAIGHT from global memory: lane (pixel = l & 31, half = l >> 5) of k-step s needs input
+//     channels 16 s + 8 half .. + 7 of ITS pixel -- 8 coalesced dword loads from the planar fp32 tensors, split to hi/lo
+//     fp16 in registers.  Every input element is loaded exactly once by exactly one lane.
+//   * a layer's 32x32 output tile D is, as it stands in the accumulator registers, the B operand of the next layer: registers
+//     8 s .. 8 s + 7 of a lane form the fragment of k-step s, with the k order inside the step permuted
+//     (k = 8 half + j  <->  output row 16 s + 8 (j >> 2) + 4 half + (j & 3); MI355X guide, "an accumulator tile as the next
+//     MFMA's operand").  The next layer's WEIGHTS are packed in that permuted order, so no lane ever moves a value:
+//     bias + LeakyReLU + split happen in place.
+//   * weight fragments are streamed per wave from L2 (1 KB coalesced per load, pre-packed in step order, ring of 4).
+// Scales: every operand tensor is multiplied by a power of two before the split so that it cannot overflow fp16; the
+// activations' bounds come from the wave's input maximum and the layers' max row L1 norms (fp16's exponent keeps the full
+// 22-bit split precision over 18 binades, so a loose bound costs nothing).
+// Output: params (planes, batch, 2*groups, h, w) = (sigma, mu) interleaved per subband, consumed by lldwt_gauss_rate.
+#include "common.h"
+
+namespace lldwt {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+// the reference's dimensions (after the fold): 93 -> 162 -> 54 -> 18 -> 2
+constexpr int C0 = 93, C1 = 162, C2 = 54, C3 = 18, C4 = 2, CPLC = 81;
+constexpr int NK0 = 6;                 // k-steps of layer 0 (96 >= 93)
+constexpr int NM0 = 6;                 // 32-channel output blocks of layer 0 (192 >= 162)
+constexpr int NM1 = 2;                 // layer 1 (64 >= 54)
+constexpr int NSTEP = NM0 * (NK0 + 2 * NM1) + 2 * NM1 + 2;     // 60 + 4 + 2 = 66 weight steps
+constexpr int STEP_BYTES = 2048;       // hi fragment + lo fragment
+constexpr int HDR_FLOATS = 64 + 192 + 64 + 32 + 32;            // scalars | b0 | b1 | b2 | b3
+constexpr int GROUP_BYTES = HDR_FLOATS * 4 + (NSTEP + 3) * STEP_BYTES;   // + 3 steps of padding for the prefetch ring
+constexpr int NB = 2;                  // pixel blocks of 32 per wave
+
+__device__ __forceinline__ float pow2_scale(float amax) {      // s = 2^k with amax * s in [2^14, 2^15)
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(amax, &e);
+    int k = 15 - e;
+    k = k > 120 ? 120 : (k < -120 ? -120 : k);
+    return ldexpf(1.f, k);
+}
+
+// row of a 32x32 D tile held by (register q, lane half h)
+__device__ __host__ __forceinline__ int drow(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+// ---- pack: one workgroup per (plane, group)
+__global__ void k_cgp16_pack(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1,
+                             const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                             const float* __restrict__ w3, const float* __restrict__ b3, uint8_t* __restrict__ packed, int groups) {
+    const int plane = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    // per-plane PyTorch layouts: w_l (groups*c_{l+1}, c_l), b_l (groups*c_{l+1})
+    const float* W[4] = {w0 + ((int64_t)plane * groups + g) * C1 * C0, w1 + ((int64_t)plane * groups + g) * C2 * C1,
+                         w2 + ((int64_t)plane * groups + g) * C3 * C2, w3 + ((int64_t)plane * groups + g) * C4 * C3};
+    const float* Bv[4] = {b0 + ((int64_t)plane * groups + g) * C1, b1 + ((int64_t)plane * groups + g) * C2,
+                          b2 + ((int64_t)plane * groups + g) * C3, b3 + ((int64_t)plane * groups + g) * C4};
+    const int cin[4] = {C0, C1, C2, C3}, cout[4] = {C1, C2, C3, C4};
+    uint8_t* dst = packed + ((int64_t)plane * groups + g) * GROUP_BYTES;
+    float* hdr = reinterpret_cast<float*>(dst);
+    __shared__ float red[3][4];
+    __shared__ float sc[4][3];           // per layer: max |w|, max row L1 norm, max |b|
+    for (int l = 0; l < 4; ++l) {
+        float mw = 0.f, ml1 = 0.f, mb = 0.f;
+        for (int r = tid; r < cout[l]; r += 256) {
+            float s = 0.f;
+            for (int c = 0; c < cin[l]; ++c) {
+                const float v = fabsf(W[l][r * cin[l] + c]);
+                s += v;
+                mw = fmaxf(mw, v);
+            }
+            ml1 = fmaxf(ml1, s);
+            mb = fmaxf(mb, fabsf(Bv[l][r]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+            ml1 = fmaxf(ml1, __shfl_xor(ml1, o, 64));
+            mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+        }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = mw; red[1][tid >> 6] = ml1; red[2][tid >> 6] = mb; }
+        __syncthreads();
+        if (tid < 3) sc[l][tid] = fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3]));
+        __syncthreads();
+    }
+    float sw[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) sw[l] = pow2_scale(sc[l][0]);
+    if (tid < 4) {
+        hdr[tid] = sw[tid];              // [0..3]  weight scales
+        hdr[4 + tid] = sc[tid][1];       // [4..7]  max row L1 norm
+        hdr[8 + tid] = sc[tid][2];       // [8..11] max |bias|
+    }
+    float* hb = hdr + 64;
+    for (int i = tid; i < 192; i += 256) hb[i] = i < C1 ? Bv[0][i] : 0.f;
+    for (int i = tid; i < 64; i += 256) hb[192 + i] = i < C2 ? Bv[1][i] : 0.f;
+    for (int i = tid; i < 32; i += 256) hb[256 + i] = i < C3 ? Bv[2][i] : 0.f;
+    for (int i = tid; i < 32; i += 256) hb[288 + i] = i < C4 ? Bv[3][i] : 0.f;
+    _Float16* fr = reinterpret_cast<_Float16*>(dst + HDR_FLOATS * 4);
+    for (int i = tid; i < (NSTEP + 3) * 512; i += 256) {       // one (hi, lo) pair per iteration
+        const int j = i & 7, lane = (i >> 3) & 63, step = i >> 9;
+        const int row = lane & 31, h = lane >> 5;
+        float v = 0.f;
+        if (step < NM0 * (NK0 + 2 * NM1)) {
+            const int m0 = step / (NK0 + 2 * NM1), r = step % (NK0 + 2 * NM1);
+            if (r < NK0) {               // layer 0: natural k order
+                const int oc = 32 * m0 + row, ic = 16 * r + 8 * h + j;
+                if (oc < C1 && ic < C0) v = W[0][oc * C0 + ic] * sw[0];
+            } else {                     // layer 1 fed by block m0 of layer 0: permuted k order
+                const int s = (r - NK0) / NM1, m1 = (r - NK0) % NM1;
+                const int oc = 32 * m1 + row, ic = 32 * m0 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+                if (oc < C2 && ic < C1) v = W[1][oc * C1 + ic] * sw[1];
+            }
+        } else if (step < NM0 * (NK0 + 2 * NM1) + 2 * NM1) {   // layer 2 fed by block m1 of layer 1
+            const int r = step - NM0 * (NK0 + 2 * NM1), m1 = r / 2, s = r % 2;
+            const int ic = 32 * m1 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+            if (row < C3 && ic < C2) v = W[2][row * C2 + ic] * sw[2];
+        } else if (step < NSTEP) {                              // layer 3
+            const int s = step - NM0 * (NK0 + 2 * NM1) - 2 * NM1;
+            const int ic = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+            if (row < C4 && ic < C3) v = W[3][row * C3 + ic] * sw[3];
+        }
+        const _Float16 hi = (_Float16)v;
+        fr[step * 1024 + lane * 8 + j] = hi;
+        fr[step * 1024 + 512 + lane * 8 + j] = (_Float16)(v - (float)hi);
+    }
+}
+
+struct Cgp16Args {
+    const float* plc;      // (Z, groups*81, h, w)
+    const float* xq;       // (Z, groups, h, w)
+    float* params;         // (Z, 2*groups, h, w)
+    const uint8_t* packed;
+    int batch, groups, h, w, K;
+    int ntaps;
+    int tap_dy[25], tap_dx[25];
+    int cols;              // 64-pixel columns per image
+};
+
+// bias + LeakyReLU + rescale + split of one D tile into the two B fragments (k-steps 0 and 1) of the next layer
+__device__ __forceinline__ void next_frags(const floatx16& acc, float inv, const float* __restrict__ bias, int h, float snext,
+                                           half8 (&bh)[2], half8 (&bl)[2]) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        float v = acc[q] * inv + bias[drow(q, h)];
+        v = v >= 0.f ? v : 0.01f * v;
+        v *= snext;
+        const _Float16 hh = (_Float16)v;
+        bh[q >> 3][q & 7] = hh;
+        bl[q >> 3][q & 7] = (_Float16)(v - (float)hh);
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_cgp16(Cgp16Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h5 = lane >> 5, pl = lane & 31;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / a.batch), g = blockIdx.y;
+    const int col = blockIdx.x * 4 + wave;
+    if (col >= a.cols) return;                                   // whole wave: no barrier in this kernel
+    const int64_t hw = (int64_t)a.h * a.w;
+    const uint8_t* grp = a.packed + ((int64_t)plane * a.groups + g) * GROUP_BYTES;
+    const float* hdr = reinterpret_cast<const float*>(grp);
+    const float* bias0 = hdr + 64, * bias1 = hdr + 256, * bias2 = hdr + 320, * bias3 = hdr + 352;
+    const uint8_t* wst = grp + HDR_FLOATS * 4 + lane * 16;
+
+    // ---- layer-0 B fragments straight from global memory
+    const float* plc = a.plc + (z * a.groups * CPLC + (int64_t)g * CPLC) * hw;
+    const float* xq = a.xq + (z * a.groups + g) * hw;
+    const int R = a.K / 2;
+    float xin[NB][NK0][8];
+    int pix[NB];
+    bool valid[NB];
+    float amax = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int64_t p = (int64_t)col * 64 + nb * 32 + pl;
+        valid[nb] = p < hw;
+        const int pc = (int)(valid[nb] ? p : hw - 1);
+        pix[nb] = pc;
+        const int y = pc / a.w, x = pc - y * a.w;
+#pragma unroll
+        for (int k = 0; k < NK0; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // channel of this element: 16k + j for the lanes of half 0, 16k + 8 + j for half 1.  Both are compile-time
+                // constants per branch, so the tap tables are read with constant indexes (scalar loads, no scratch).
+                constexpr int dummy_ = 0;
+                (void)dummy_;
+                const int c_lo = 16 * k + j, c_hi = 16 * k + 8 + j;
+                float v = 0.f;
+                auto fetch = [&](int c) -> float {          // c is a constant at every call site after unrolling
+                    if (c < CPLC) return plc[(int64_t)c * hw + pc];
+                    if (c < C0) {
+                        const int yy = y + a.tap_dy[c - CPLC] - R, xx = x + a.tap_dx[c - CPLC] - R;
+                        return (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) ? xq[(int64_t)yy * a.w + xx] : 0.f;
+                    }
+                    return 0.f;
+                };
+                if (c_hi < CPLC) {                          // both halves: tree-context features (one load, runtime channel)
+                    v = plc[(int64_t)(c_lo + 8 * h5) * hw + pc];
+                } else if (h5 == 0) {
+                    v = fetch(c_lo);
+                } else {
+                    v = fetch(c_hi);
+                }
+                xin[nb][k][j] = v;
+                amax = fmaxf(amax, fabsf(v));
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    // ---- scales: input from its maximum, hidden layers from bounds |h_l| <= |h_{l-1}|max * L1max_l + |b_l|max
+    const float s_in = pow2_scale(amax);
+    const float bound0 = amax * hdr[4] + hdr[8];
+    const float bound1 = bound0 * hdr[5] + hdr[9];
+    const float bound2 = bound1 * hdr[6] + hdr[10];
+    const float s1 = pow2_scale(bound0), s2 = pow2_scale(bound1), s3 = pow2_scale(bound2);
+    const float inv0 = (1.f / s_in) * (1.f / hdr[0]), inv1 = (1.f / s1) * (1.f / hdr[1]);
+    const float inv2 = (1.f / s2) * (1.f / hdr[2]), inv3 = (1.f / s3) * (1.f / hdr[3]);
+    half8 b0h[NB][NK0], b0l[NB][NK0];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int k = 0; k < NK0; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = xin[nb][k][j] * s_in;
+                const _Float16 hh = (_Float16)v;
+                b0h[nb][k][j] = hh;
+                b0l[nb][k][j] = (_Float16)(v - (float)hh);
+            }
+
+    // ---- weight stream: ring of 4 steps
+    half8 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(wst + i * STEP_BYTES);
+        al[i] = *reinterpret_cast<const half8*>(wst + i * STEP_BYTES + 1024);
+    }
+    int step = 0;
+#define CGP16_NEXT()                                                                                  \
+    {                                                                                                 \
+        ah[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * STEP_BYTES);          \
+        al[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * STEP_BYTES + 1024);   \
+    }
+#define CGP16_MMA(ACC, BH, BL)                                                                        \
+    {                                                                                                 \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[step & 3], BH, ACC, 0, 0, 0);                 \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[step & 3], BL, ACC, 0, 0, 0);                 \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[step & 3], BH, ACC, 0, 0, 0);                 \
+    }
+
+    floatx16 acc1[NB][NM1];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int m = 0; m < NM1; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc1[nb][m][q] = 0.f;
+
+#pragma unroll
+    for (int m0 = 0; m0 < NM0; ++m0) {
+        floatx16 acc0[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc0[nb][q] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK0; ++k) {
+            CGP16_NEXT()
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) CGP16_MMA(acc0[nb], b0h[nb][k], b0l[nb][k])
+            ++step;
+        }
+        half8 b1h[NB][2], b1l[NB][2];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) next_frags(acc0[nb], inv0, bias0 + 32 * m0, h5, s1, b1h[nb], b1l[nb]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m1 = 0; m1 < NM1; ++m1) {
+                CGP16_NEXT()
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) CGP16_MMA(acc1[nb][m1], b1h[nb][s], b1l[nb][s])
+                ++step;
+            }
+    }
+    // ---- layer 2 (54 -> 18)
+    floatx16 acc2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc2[nb][q] = 0.f;
+#pragma unroll
+    for (int m1 = 0; m1 < NM1; ++m1) {
+        half8 b2h[NB][2], b2l[NB][2];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) next_frags(acc1[nb][m1], inv1, bias1 + 32 * m1, h5, s2, b2h[nb], b2l[nb]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            CGP16_NEXT()
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) CGP16_MMA(acc2[nb], b2h[nb][s], b2l[nb][s])
+            ++step;
+        }
+    }
+    // ---- layer 3 (18 -> 2)
+    floatx16 acc3[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc3[nb][q] = 0.f;
+    {
+        half8 b3h[NB][2], b3l[NB][2];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) next_frags(acc2[nb], inv2, bias2, h5, s3, b3h[nb], b3l[nb]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            CGP16_NEXT()
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) CGP16_MMA(acc3[nb], b3h[nb][s], b3l[nb][s])
+            ++step;
+        }
+    }
+#undef CGP16_NEXT
+#undef CGP16_MMA
+    // ---- rows 0 (sigma) and 1 (mu) of the last tile: registers 0, 1 of the lanes with h == 0
+    if (h5 == 0) {
+        float* out = a.params + (z * 2 * a.groups + 2 * g) * hw;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            if (valid[nb]) {
+                out[pix[nb]] = acc3[nb][0] * inv3 + bias3[0];
+                out[hw + pix[nb]] = acc3[nb][1] * inv3 + bias3[1];
+            }
+    }
+}
+
+}  // namespace
+}  // namespace lldwt
+using namespace lldwt;
+
+extern "C" int64_t lldwt_cgp16_packed_bytes(int c0, int c1, int c2, int c3, int groups) {
+    if (c0 != C0 || c1 != C1 || c2 != C2 || c3 != C3 || groups <= 0) return -1;     // the reference's dimensions only
+    return (int64_t)groups * GROUP_BYTES;
+}
+
+extern "C" int lldwt_cgp16_pack(const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* w3, const float* b3, void* packed, int64_t planes, int c0,
+                                int c1, int c2, int c3, int groups, void* stream) {
+    LLDWT_REQUIRE(lldwt_cgp16_packed_bytes(c0, c1, c2, c3, groups) > 0, "cgp16_pack: built for 93 -> 162 -> 54 -> 18 -> 2 (got %d,%d,%d,%d)", c0, c1, c2, c3);
+    LLDWT_REQUIRE(w0 && b0 && w1 && b1 && w2 && b2 && w3 && b3 && packed && planes > 0 && planes <= 65535, "cgp16_pack: bad arguments");
+    hipLaunchKernelGGL(k_cgp16_pack, dim3((unsigned)groups, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, w0, b0, w1, b1,
+                       w2, b2, w3, b3, reinterpret_cast<uint8_t*>(packed), groups);
+    return check_launch("cgp16_pack");
+}
+
+extern "C" int lldwt_cgp16_params(const float* plc, const float* xq, const void* packed, float* params, int64_t planes,
+                                  int64_t batch, int64_t h, int64_t w_, int groups, int K, uint32_t tap_mask, void* stream) {
+    LLDWT_REQUIRE(plc && xq && packed && params && planes > 0 && batch > 0 && h > 0 && w_ > 0 && groups > 0, "cgp16_params: bad arguments");
+    LLDWT_REQUIRE(K == 3 || K == 5, "cgp16_params: K=%d unsupported", K);
+    LLDWT_REQUIRE(planes * batch <= 65535 && groups <= 65535, "cgp16_params: grid too large");
+    LLDWT_REQUIRE((int64_t)CPLC * h * w_ < ((int64_t)1 << 31), "cgp16_params: image too large for 32-bit offsets");
+    Cgp16Args a;
+    a.plc = plc; a.xq = xq; a.params = params; a.packed = reinterpret_cast<const uint8_t*>(packed);
+    a.batch = (int)batch; a.groups = groups; a.h = (int)h; a.w = (int)w_; a.K = K;
+    int n = 0;
+    for (int t = 0; t < K * K; ++t)
+        if ((tap_mask >> t) & 1u) {
+            LLDWT_REQUIRE(n < 25, "cgp16_params: too many taps");
+            a.tap_dy[n] = t / K;
+            a.tap_dx[n] = t % K;
+            ++n;
+        }
+    LLDWT_REQUIRE(n == C0 - CPLC, "cgp16_params: %d live taps, the folded first layer expects %d", n, C0 - CPLC);
+    a.ntaps = n;
+    a.cols = (int)cdiv(h * w_, 64);
+    dim3 grid((unsigned)cdiv(a.cols, 4), (unsigned)groups, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_cgp16, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("cgp16_params");
+}

@@ -134,6 +134,7 @@ struct LfArgs {
     int f16;              // float offset of this orientation's f16 section
     int batch, h, w, vertical;
     float sign, rw;
+    int dbg;              // diagnostics only (LLDWT_LF_DBG): bit i set = skip the tile loop of phase P(i+1); results are then wrong
 };
 
 // 13 k-steps of one 16-pixel tile: B fragments from a T-image (input region width WIN, NIN pixels), A fragments in registers
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int q = 0; q < 4; ++q) b1v[q] = bias[a.b1 + oc0 + q];
 
     // ---------------- P1: t1 = tanh(conv1(skip) + b1) on 28 x 44
-    for (int tile = wave; tile < NT1; tile += NWAVE) {
+    for (int tile = wave; tile < ((a.dbg & 1) ? 0 : NT1); tile += NWAVE) {
         const int p = tile * 16 + pl;
         const int r = p / R1W, c = p - r * R1W;
         const floatx4 acc = conv1_tile(S, r * SW + c, soff, s_skip, a1h, a1l);
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = bias[a.b2 + oc0 + q];
         const float inv2 = (1.f / ACT_SCALE) * (1.f / sw2);
-        for (int tile = wave; tile < NT2; tile += NWAVE) {
+        for (int tile = wave; tile < ((a.dbg & 2) ? 0 : NT2); tile += NWAVE) {
             const int p = tile * 16 + pl;
             const int r = p / R2W, c = p - r * R2W;
             const floatx4 acc = conv16_tile<R1W, N1>(lds + LDS_T1, (r * R1W + c) * 16 + halfsel * (N1 * 16), hi_tap, ah, al);
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int tile = wave + it * NWAVE;
 #pragma unroll
             for (int q = 0; q < 4; ++q) t3v[it][q] = 0.f;
-            if (tile < NT3) {
+            if (tile < ((a.dbg & 4) ? 0 : NT3)) {
                 const int p = tile * 16 + pl;
                 const int r = p / R3W, c = p - r * R3W;
                 const floatx4 acc = conv16_tile<R2W, N2>(lds + LDS_T2, (r * R2W + c) * 16 + halfsel * (N2 * 16), hi_tap, ah, al);
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         float* D = reinterpret_cast<float*>(lds + LDS_D);
         const uint8_t* img = lds + LDS_T3;
-        for (int tile = wave; tile < NTD; tile += NWAVE) {
+        for (int tile = wave; tile < ((a.dbg & 8) ? 0 : NTD); tile += NWAVE) {
             const int p = tile * 16 + pl;
             const int r = p / RDW, c = p - r * RDW;
             const int basein = (r * R3W + c) * 16 + halfsel * (N3 * 16);
@@ -439,6 +440,8 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
     a.f16 = f16_off + orient * LF_ORIENT_FLOATS;
     a.batch = (int)batch; a.h = (int)h; a.w = (int)w; a.vertical = vertical;
     a.sign = sign; a.rw = rw;
+    const char* dbg = getenv("LLDWT_LF_DBG");
+    a.dbg = dbg ? atoi(dbg) : 0;
     dim3 grid((unsigned)cdiv(w, TW), (unsigned)cdiv(h, TH), (unsigned)Z);
     hipLaunchKernelGGL(k_lift_fused_f16, grid, dim3(NTH), LDS_TOTAL, st, a);
     return check_launch("lift_f16_step");

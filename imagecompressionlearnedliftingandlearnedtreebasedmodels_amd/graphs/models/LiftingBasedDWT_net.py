@@ -265,11 +265,16 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
             # (:357-359) is pure data movement, so its 81 channels per subband are folded into layer 0:
             #   W0[:, csc half] . Wcsc -> 12 extra input columns = the live taps of the quantised subband itself,
             # gathered inside the fused kernel.  The csc conv, its 243-channel output and half of layer 0's MACs disappear.
-            packed, dims = cached(cg[0], ("cgp_ctx",),
-                                      [p for layer in convs for m in layer for p in (m.weight, m.bias)] +
-                                      [p for m in cs for p in (m.weight, m.bias)],
-                                      lambda: _fold_csc_into_cgp(convs, cs, so))
-            bits = ops.cgp_rate_ctx(plc, xo_q, x, packed, dims, cs[0].kernel_size[0], cs[0].tap_bits(), _noise(x, training))
+            packed, dims, packed16 = cached(cg[0], ("cgp_ctx",),
+                                            [p for layer in convs for m in layer for p in (m.weight, m.bias)] +
+                                            [p for m in cs for p in (m.weight, m.bias)],
+                                            lambda: _fold_csc_into_cgp(convs, cs, so))
+            if packed16 is not None and not training and ops.cgp_mode() == "f16x3":
+                # split-fp16 register chain -> (sigma, mu), then the fused Gaussian rate kernel
+                params = ops.cgp16_params(plc, xo_q, packed16, cs[0].kernel_size[0], cs[0].tap_bits())
+                bits, _ = ops.gauss_rate(x, params)
+            else:
+                bits = ops.cgp_rate_ctx(plc, xo_q, x, packed, dims, cs[0].kernel_size[0], cs[0].tap_bits(), _noise(x, training))
             si_list.append(bits)
             q_list.append(xo_q)
             parent = xo_q
@@ -316,8 +321,8 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
         convs = [[s[n] for s in cg] for n in (0, 2, 4, 6)]
         for m in cs:
             m.apply_mask_()
-        packed, dims = cached(cg[0], ("cgp_ctx",), [p for layer in convs for m in layer for p in (m.weight, m.bias)] +
-                              [p for m in cs for p in (m.weight, m.bias)], lambda: _fold_csc_into_cgp(convs, cs, so))
+        packed, dims, _ = cached(cg[0], ("cgp_ctx",), [p for layer in convs for m in layer for p in (m.weight, m.bias)] +
+                                 [p for m in cs for p in (m.weight, m.bias)], lambda: _fold_csc_into_cgp(convs, cs, so))
         return plc, packed, dims, cs[0].kernel_size[0], cs[0].tap_bits()
 
     @staticmethod
@@ -559,7 +564,9 @@ def _fold_csc_into_cgp(convs, cs, G):
         b0n.append(torch.cat(rows_b, 0).float())
     ws = [torch.stack(w0n, 0).contiguous()] + [_stack(layer, lambda m: m.weight) for layer in convs[1:]]
     bs = [torch.stack(b0n, 0).contiguous()] + [_stack(layer, lambda m: m.bias) for layer in convs[1:]]
-    return ops.cgp_pack(ws, bs, G)
+    packed, dims = ops.cgp_pack(ws, bs, G)
+    packed16 = ops.cgp16_pack(ws, bs, G) if ops.cgp16_supported(ws, G) else None       # split-fp16 fragments (eval path)
+    return packed, dims, packed16
 
 
 def _fold_csc_train(cg, cs, xq):

@@ -277,6 +277,47 @@ def conv2d(x, w, bias, K, groups=1, act=ACT_NONE, upsample2=False, transposed=Fa
     return out
 
 
+def cgp_mode():
+    """Arithmetic of the fused cgp stack on the eval path: 'f16x3' (default; split-fp16 register chain, csrc/cgp_f16x3.hip)
+    or 'f32' (fp32 MFMA kernel k_cgp_rate).  Environment variable LLDWT_CGP_MODE."""
+    import os
+    m = os.environ.get("LLDWT_CGP_MODE", "f16x3")
+    if m not in ("f32", "f16x3"):
+        raise _lib.LLDWTError("LLDWT_CGP_MODE must be 'f32' or 'f16x3' (got %r)" % m)
+    return m
+
+
+def cgp16_supported(ws, groups):
+    c = [ws[0].shape[2]] + [w.shape[1] // groups for w in ws]
+    return _lib.load().lldwt_cgp16_packed_bytes(c[0], c[1], c[2], c[3], groups) > 0 and c[4] == 2
+
+
+def cgp16_pack(ws, bs, groups):
+    """The four (folded) 1x1 weights (P, groups*c_{l+1}, c_l, 1, 1) + biases -> packed split-fp16 fragments (uint8 (P, bytes))."""
+    lib = _lib.load()
+    P = ws[0].shape[0]
+    c = [ws[0].shape[2]] + [w.shape[1] // groups for w in ws]
+    nb = int(lib.lldwt_cgp16_packed_bytes(c[0], c[1], c[2], c[3], groups))
+    if nb <= 0:
+        raise _lib.LLDWTError("cgp16_pack: dimensions %s not built (93 -> 162 -> 54 -> 18 -> 2 only)" % (c,))
+    packed = torch.empty(P, nb, device=ws[0].device, dtype=torch.uint8)
+    args = []
+    for w, b in zip(ws, bs):
+        args += [_chk(w, "w"), _chk(b, "b")]
+    check(lib.lldwt_cgp16_pack(*args, C.c_void_p(packed.data_ptr()), P, c[0], c[1], c[2], c[3], groups, _stream()), "cgp16_pack")
+    return packed
+
+
+def cgp16_params(plc, xq, packed16, K, tap_mask):
+    """(sigma, mu) of every coefficient from the tree-context features plc (P,B,G*81,h,w) and the quantised subbands xq
+    (P,B,G,h,w): -> params (P,B,2G,h,w) (include/lldwt.h lldwt_cgp16_params)."""
+    P, B, G, h, w = xq.shape
+    params = torch.empty(P, B, 2 * G, h, w, device=xq.device, dtype=torch.float32)
+    check(_lib.load().lldwt_cgp16_params(_chk(plc, "plc"), _chk(xq, "xq"), C.c_void_p(packed16.data_ptr()), _chk(params), P, B,
+                                        h, w, G, K, int(tap_mask), _stream()), "cgp16_params")
+    return params
+
+
 def conv_f16x3_pack(w):
     """(P,cout,cin,3,3) fp32 -> packed split-fp16 weights (uint8 tensor (P, bytes)) for conv3x3_f16x3."""
     lib = _lib.load()

@@ -284,6 +284,19 @@ int lldwt_lower_bound_bwd(const float* x, const float* gy, float* gx, int64_t n,
 int lldwt_nonneg_param_fwd(const float* x, float* y, int64_t n, float minimum, void* stream);
 int lldwt_nonneg_param_bwd(const float* x, const float* gy, float* gx, int64_t n, float minimum, void* stream);
 
+/* The cgp stack with the folded context (as lldwt_cgp_rate_ctx) on the fp16 matrix cores, split-fp16 operands
+ * (csrc/cgp_f16x3.hip): a register-resident chain per wave, layer l's accumulator tile is layer l+1's MFMA operand.  Built
+ * for the reference's dimensions after the fold, 93 -> 162 -> 54 -> 18 -> 2 per subband (LiftingBasedDWT_net.py:282-289);
+ * lldwt_cgp16_packed_bytes returns -1 for any other.  w_l: (planes, groups*c_{l+1}, c_l), b_l: (planes, groups*c_{l+1})
+ * -- the folded first layer from the host (_fold_csc_into_cgp).  params: (planes, batch, 2*groups, h, w), sigma on the
+ * even and mu on the odd channels, to be fed to lldwt_gauss_rate.                                                    */
+int64_t lldwt_cgp16_packed_bytes(int c0, int c1, int c2, int c3, int groups);
+int lldwt_cgp16_pack(const float* w0, const float* b0, const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* w3, const float* b3, void* packed, int64_t planes, int c0, int c1, int c2, int c3,
+                     int groups, void* stream);
+int lldwt_cgp16_params(const float* plc, const float* xq, const void* packed, float* params, int64_t planes, int64_t batch,
+                       int64_t h, int64_t w_, int groups, int K, uint32_t tap_mask, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Real entropy coding (reference: compress_ar / decompress_ar, LiftingBasedDWT_net.py:458-556, on
  * compressai.ans).  HOST functions (csrc/rans.hip): the range-ANS state machine is sequential byte work; the symbols

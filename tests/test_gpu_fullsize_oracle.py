@@ -244,8 +244,10 @@ def test_cgp_rate_ctx_large_vs_torch():
     cg, cs = lay.cgp_out_xo_list[0], lay.csc_list[0]
     cs.apply_mask_()
     convs = [[cg[n]] for n in (0, 2, 4, 6)]
-    packed, dims = _fold_csc_into_cgp(convs, [cs], 3)
+    packed, dims, packed16 = _fold_csc_into_cgp(convs, [cs], 3)
     bits = ops.cgp_rate_ctx(plc.to(DEV), xq.to(DEV), x.to(DEV), packed, dims, 5, cs.tap_bits())
+    params16 = ops.cgp16_params(plc.to(DEV), xq.to(DEV), packed16, 5, cs.tap_bits())          # split-fp16 register chain
+    bits16, _ = ops.gauss_rate(x.to(DEV), params16)
     with torch.no_grad():
         csc = F.conv2d(xq[0], cs.weight.cpu() * cs.mask.cpu(), cs.bias.cpu(), padding=2, groups=3)
         p0, p1, p2 = plc[0].chunk(3, 1)
@@ -259,9 +261,11 @@ def test_cgp_rate_ctx_large_vs_torch():
         _, lik = entropy.gaussian_conditional_forward(x[0], sg, mu, False)
         ref = -torch.log2(lik)
         resid = x[0] - mu
-    d = (bits[0].cpu() - ref).abs()
-    bad = d > 5e-4
-    if int(bad.sum()):
-        fr = (resid[bad] - torch.floor(resid[bad]) - 0.5).abs()
-        assert float(fr.max()) < 1e-3 and int(bad.sum()) < 20, (int(bad.sum()), float(fr.max()))
-    assert abs(float(bits[0].cpu()[~bad].double().sum()) - float(ref[~bad].double().sum())) < 1e-4 * float(ref.double().sum())
+    assert maxdiff(params16[0].cpu(), t) < 2e-5                       # (sigma, mu) themselves: fp32-level
+    for got in (bits, bits16):
+        d = (got[0].cpu() - ref).abs()
+        bad = d > 5e-4 + 1e-4 * ref
+        if int(bad.sum()):
+            fr = (resid[bad] - torch.floor(resid[bad]) - 0.5).abs()
+            assert float(fr.max()) < 1e-3 and int(bad.sum()) < 20, (int(bad.sum()), float(fr.max()))
+        assert abs(float(got[0].cpu()[~bad].double().sum()) - float(ref[~bad].double().sum())) < 1e-4 * float(ref.double().sum())
