@@ -158,6 +158,60 @@ __device__ __forceinline__ floatx4 conv16_tile(const uint8_t* __restrict__ img, 
     return acc;
 }
 
+// two tiles at once: the A fragments are shared, the two MFMA chains are independent.  The B fragments of k-step ks+1 are
+// read from LDS into a second register set BEFORE the 6 MFMAs of k-step ks (the sched_group_barrier sequence pins that
+// order and leaves room for 2 vector instructions of a neighbouring epilogue after every MFMA), so the matrix pipe never
+// waits for an LDS round trip.
+template <int WIN, int NIN>
+__device__ __forceinline__ void conv16_tile2(const uint8_t* __restrict__ img, int base0, int base1, bool hi_tap,
+                                             const half8 (&ah)[LF_KS], const half8 (&al)[LF_KS], floatx4& acc0, floatx4& acc1) {
+    acc0 = floatx4{0.f, 0.f, 0.f, 0.f};
+    acc1 = floatx4{0.f, 0.f, 0.f, 0.f};
+    half8 bh0[2], bl0[2], bh1[2], bl1[2];
+    auto load = [&](int ks, int set) {
+        const int ta = 2 * ks, tb = (2 * ks + 1) < LF_KK ? 2 * ks + 1 : LF_KK - 1;
+        const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16, offb = ((tb / LF_K) * WIN + tb % LF_K) * 16;
+        const int off = hi_tap ? offb : offa;
+        bh0[set] = *reinterpret_cast<const half8*>(img + base0 + off);
+        bl0[set] = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + base0 + off);
+        bh1[set] = *reinterpret_cast<const half8*>(img + base1 + off);
+        bl1[set] = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + base1 + off);
+    };
+    load(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < LF_KS; ++ks) {
+        const int c = ks & 1;
+        if (ks + 1 < LF_KS) load(ks + 1, c ^ 1);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh0[c], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh1[c], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl0[c], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl1[c], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh0[c], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh1[c], acc1, 0, 0, 0);
+        // this k-step is a scheduling region of its own (fenced): its 4 LDS reads can only be the NEXT step's, one after
+        // each of the first four MFMAs
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// scheduling hint for a region that holds NM MFMAs next to LDS reads and vector work: one MFMA, one LDS read, a few VALU
+template <int NM>
+__device__ __forceinline__ void interleave_hint() {
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+}
+
 // conv1 of one 16-pixel tile: gather this lane's 8 taps from the fp32 skip patch, split, 3 MFMAs
 __device__ __forceinline__ floatx4 conv1_tile(const float* __restrict__ S, int sbase, const int (&soff)[8], float s_skip,
                                               const half8& a1h, const half8& a1l) {
@@ -283,16 +337,45 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = bias[a.b2 + oc0 + q];
         const float inv2 = (1.f / ACT_SCALE) * (1.f / sw2);
-        for (int tile = wave; tile < ((a.dbg & 2) ? 0 : NT2); tile += NWAVE) {
-            const int p = tile * 16 + pl;
+        // software pipeline over PAIRS of tiles (wave + 16 it, wave + 16 it + 8): the MFMA chains of pair it+1 are issued
+        // next to the tanh / split / store work of pair it, so the vector ALU and the matrix pipe overlap inside one wave
+        constexpr int NIT2 = (NT2 + 2 * NWAVE - 1) / (2 * NWAVE);      // 4
+        auto tile_base = [&](int tile, int& p_out) {
+            const int tcl = tile < NT2 ? tile : NT2 - 1;               // past the end: the last tile again (same bytes stored twice)
+            const int p = tcl * 16 + pl;
             const int r = p / R2W, c = p - r * R2W;
-            const floatx4 acc = conv16_tile<R1W, N1>(lds + LDS_T1, (r * R1W + c) * 16 + halfsel * (N1 * 16), hi_tap, ah, al);
+            p_out = p;
+            return (r * R1W + c) * 16 + halfsel * (N1 * 16);
+        };
+        auto epilogue2 = [&](const floatx4& acc, int p) {              // branch-free: one basic block per pipeline stage
+            const int r = p / R2W, c = p - r * R2W;
             const int gy = y0 - 4 + r, gx = x0 - 4 + c;
             const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = in ? fast_tanh(acc[q] * inv2 + bv[q]) * ACT_SCALE : 0.f;
             timg_store<N2>(lds + LDS_T2, p, oc0, v);
+        };
+        if (!(a.dbg & 2)) {
+            floatx4 c0, c1;
+            int p0, p1;
+            {
+                const int b0 = tile_base(wave, p0), b1 = tile_base(wave + NWAVE, p1);
+                conv16_tile2<R1W, N1>(lds + LDS_T1, b0, b1, hi_tap, ah, al, c0, c1);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT2; ++it) {
+                floatx4 n0 = c0, n1 = c1;
+                int q0 = p0, q1 = p1;
+                if (it + 1 < NIT2) {
+                    const int b0 = tile_base(wave + 16 * (it + 1), q0), b1 = tile_base(wave + 16 * (it + 1) + NWAVE, q1);
+                    conv16_tile2<R1W, N1>(lds + LDS_T1, b0, b1, hi_tap, ah, al, n0, n1);
+                }
+                epilogue2(c0, p0);
+                epilogue2(c1, p1);
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = n0; c1 = n1; p0 = q0; p1 = q1;
+            }
         }
     }
     __syncthreads();
