@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
                 ("ic_stride", C.c_int), ("ic_off", C.c_int), ("xtot", C.c_int), ("epi", C.c_int)]
 
 
-ACT_NONE, ACT_TANH, ACT_LRELU = 0, 1, 2
+ACT_NONE, ACT_TANH, ACT_LRELU, ACT_RELU = 0, 1, 2, 3
 EPI_NONE, EPI_TANH_BWD, EPI_LRELU_BWD = 0, 1, 2
 EB_FLOATS = 59
 

@@ -27,7 +27,16 @@ class LiftingBasedDWTAgent(BaseAgent):
         self.lr = config.learning_rate
         self.model = LiftingBasedDWTNetWrapper(config).to(self.device)
         self.seed_noise_stream()
+        self.postprocessflag = config.get("postprocess", "none")
         self.optimizer = configure_optimizers(self.model, self.lr)
+        self.postprocess = None
+        if config.mode == "train_postprocess":                                   # :26-41
+            from ..graphs.layers.post_processing_networks import make_postprocess
+            self.postprocess = make_postprocess(config).to(self.device)
+            self.optimizer_postprocess = optim.Adam(self.postprocess.parameters(), lr=0.0001)
+            self.scheduler_postprocess = optim.lr_scheduler.ReduceLROnPlateau(
+                self.optimizer_postprocess, factor=0.5, patience=5, threshold=0.0001, threshold_mode="rel", cooldown=0,
+                min_lr=1e-06, eps=1e-08)
         self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, factor=0.5, patience=5, threshold=0.0001,
                                                               threshold_mode="rel", cooldown=0, min_lr=1e-06, eps=1e-08)
         self.grad_acc_iters = config.grad_acc_iters
@@ -104,6 +113,61 @@ class LiftingBasedDWTAgent(BaseAgent):
         train_rd_loss, _, _, _ = self.train_logger.display(lr=self.optimizer.param_groups[0]["lr"], typ="tr")
         train_rd_loss, = parallel.mean_over_ranks([train_rd_loss], self.device)
         self.scheduler.step(train_rd_loss)                                      # :111
+
+    # ---------------------------------------------------------------- mode train_postprocess (:113-153, :203-250)
+    def _postprocess_batch(self, x, train):
+        """Frozen codec (eval, no grad) -> reconstructed RGB -> post-processing net -> loss terms."""
+        with torch.no_grad():
+            if self.clrch == 1:
+                y = ops.rgb_to_ycc(x.contiguous())
+                yhat, si_xe, si_xo = forward_planes(self.model.nets(), y, False)
+                xrec = ops.ycc_to_rgb(yhat) + 0.5                              # RGB in [0,1] (:131-132)
+            else:
+                xh, si_xe, si_xo = self.model((x - 0.5).contiguous())
+                xrec = xh + 0.5
+        xhat = self.postprocess(xrec) - 0.5                                    # :134, then the -0.5 shift (:137)
+        xs = (x - 0.5).contiguous()
+        if not train:
+            xhat = xhat.clamp(-0.5, 0.5)
+            return self.valid_loss.forward3(xs, xhat.contiguous(), si_xe, si_xo)
+        return self.train_loss.forward3_train(xs, xhat.contiguous(), si_xe, si_xo)
+
+    def train_one_epoch_postprocess(self):
+        """agents/liftingDWT_agent.py:113-153: the codec is frozen (eval), only the post-processing net trains, on the MSE."""
+        self.model.eval()
+        self.postprocess.train()
+        for x in self.data_loader.train_loader:
+            x = x.to(self.device)
+            self.optimizer_postprocess.zero_grad()
+            loss, mse, r1, r2 = self._postprocess_batch(x, True)
+            (mse / self.grad_acc_iters).float().backward()                      # :141
+            self.optimizer_postprocess.step()
+            self.current_iteration += 1
+            vals = (loss.item(), mse.item(), r1.item(), r2.item())
+            self.train_logger(*vals)
+            self.trnit_logger(*vals)
+        _, train_mse, _, _ = self.train_logger.display(lr=self.optimizer.param_groups[0]["lr"], typ="tr")
+        train_mse, = parallel.mean_over_ranks([train_mse], self.device)
+        self.scheduler_postprocess.step(train_mse)                             # :153
+
+    @torch.no_grad()
+    def validate_postprocess(self):
+        """agents/liftingDWT_agent.py:203-250."""
+        self.model.eval()
+        self.postprocess.eval()
+        psnr, r1s, r2s = [], [], []
+        for x in self.data_loader.valid_loader:
+            x = x.to(self.device)
+            loss, mse, r1, r2 = self._postprocess_batch(x, False)
+            self.valid_logger(loss.item(), mse.item(), r1.item(), r2.item())
+            psnr.append(10.0 * torch.log10(1.0 / torch.tensor(mse.item())))
+            r1s.append(r1.item())
+            r2s.append(r2.item())
+        valid_rd_loss, _, _, _ = self.valid_logger.display(lr=0.0, typ="va")
+        m = lambda v: float(torch.tensor(v).mean()) if v else 0.0
+        valid_rd_loss, ps, a1, a2 = parallel.mean_over_ranks([valid_rd_loss, m(psnr), m(r1s), m(r2s)], self.device)
+        print(" avg_psnr = %.2f, rate_1 = %g, rate_2 = %g, total_rate = %g" % (ps, a1, a2, a1 + a2))
+        return valid_rd_loss
 
     @torch.no_grad()
     def validate(self):

@@ -51,6 +51,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == LLDWT_ACT_TANH) return fast_tanh(v);
     if (act == LLDWT_ACT_LRELU) return v >= 0.f ? v : 0.01f * v;
+    if (act == LLDWT_ACT_RELU) return v > 0.f ? v : 0.f;
     return v;
 }
 

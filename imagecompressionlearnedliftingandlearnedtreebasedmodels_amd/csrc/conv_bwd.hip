@@ -713,7 +713,8 @@ __global__ void k_act_bwd(const float* __restrict__ dy, const float* __restrict_
                           int act) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float yv = y[i], g = dy[i];
-        dx[i] = act == LLDWT_ACT_TANH ? g * (1.f - yv * yv) : (act == LLDWT_ACT_LRELU ? (yv > 0.f ? g : 0.01f * g) : g);
+        dx[i] = act == LLDWT_ACT_TANH ? g * (1.f - yv * yv)
+                                     : (act == LLDWT_ACT_LRELU ? (yv > 0.f ? g : 0.01f * g) : (act == LLDWT_ACT_RELU ? (yv > 0.f ? g : 0.f) : g));
     }
 }
 

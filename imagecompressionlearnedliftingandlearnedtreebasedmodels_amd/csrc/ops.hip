@@ -417,29 +417,60 @@ __device__ __forceinline__ void block_accumulate(double v, double* out) {
 
 // ------------------------------------------------------------------------------------------ Gaussian rate
 // compressai GaussianConditional.forward/_likelihood as called at LiftingBasedDWT_net.py:334,345,364,832
+// grid: x over the pixels of one channel plane (4 per lane when aligned), y over (image, channel) -- no per-element
+// division (the first version's two 64-bit divisions per element cost more than the two erfc)
 __global__ __launch_bounds__(256) void k_gauss_rate(const float* __restrict__ x, const float* __restrict__ params,
                                                     const float* __restrict__ noise, float* __restrict__ bits,
                                                     float* __restrict__ qout, double* __restrict__ bit_sum, int C,
-                                                    int64_t hw, int64_t n) {
+                                                    int64_t hw, int64_t ZC) {
     double local = 0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t zc = i / hw, p = i - zc * hw;
-        const int64_t z = zc / C;
-        const int c = (int)(zc - z * C);
-        const float sg = params[(z * 2 * C + 2 * c) * hw + p];
-        const float mu = params[(z * 2 * C + 2 * c + 1) * hw + p];
-        const float xv = x[i];
-        const float v = noise ? xv + noise[i] : rintf(xv - mu) + mu;
+    auto one = [&](float xv, float sg, float mu, float nz, bool train, float& b, float& v) {
+        v = train ? xv + nz : rintf(xv - mu) + mu;
         const float a = fabsf(v - mu);
         const float s = fmaxf(sg, 0.11f);
         const float cst = -0.70710678118654752440f;
         const float up = 0.5f * erfcf(cst * ((0.5f - a) / s));
         const float lo = 0.5f * erfcf(cst * ((-0.5f - a) / s));
         const float lik = fmaxf(up - lo, 1e-9f);
-        const float b = -log2f(lik);
-        if (bits) bits[i] = b;
-        if (qout) qout[i] = v;
-        local += (double)b;
+        b = -log2f(lik);
+    };
+    const bool train = noise != nullptr;
+    for (int64_t zc = blockIdx.y; zc < ZC; zc += gridDim.y) {
+        const int64_t z = zc / C;
+        const int c = (int)(zc - z * C);
+        const float* ps = params + (z * 2 * C + 2 * c) * hw;
+        const float* pm = ps + hw;
+        const float* xp = x + zc * hw;
+        const float* np = train ? noise + zc * hw : nullptr;
+        float* bp = bits ? bits + zc * hw : nullptr;
+        float* qp = qout ? qout + zc * hw : nullptr;
+        const bool vec = (hw & 3) == 0 && ((((uintptr_t)xp) | ((uintptr_t)ps) | ((uintptr_t)(bp ? bp : xp)) |
+                                            ((uintptr_t)(qp ? qp : xp)) | ((uintptr_t)(np ? np : xp))) & 15) == 0;
+        if (vec) {
+            for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < (hw >> 2); p += (int64_t)gridDim.x * blockDim.x) {
+                const float4 xv = reinterpret_cast<const float4*>(xp)[p];
+                const float4 sg = reinterpret_cast<const float4*>(ps)[p];
+                const float4 mu = reinterpret_cast<const float4*>(pm)[p];
+                float4 nz = {0.f, 0.f, 0.f, 0.f};
+                if (train) nz = reinterpret_cast<const float4*>(np)[p];
+                float4 b, v;
+                one(xv.x, sg.x, mu.x, nz.x, train, b.x, v.x);
+                one(xv.y, sg.y, mu.y, nz.y, train, b.y, v.y);
+                one(xv.z, sg.z, mu.z, nz.z, train, b.z, v.z);
+                one(xv.w, sg.w, mu.w, nz.w, train, b.w, v.w);
+                if (bp) reinterpret_cast<float4*>(bp)[p] = b;
+                if (qp) reinterpret_cast<float4*>(qp)[p] = v;
+                local += (double)b.x + (double)b.y + (double)b.z + (double)b.w;
+            }
+        } else {
+            for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+                float b, v;
+                one(xp[p], ps[p], pm[p], train ? np[p] : 0.f, train, b, v);
+                if (bp) bp[p] = b;
+                if (qp) qp[p] = v;
+                local += (double)b;
+            }
+        }
     }
     if (bit_sum) block_accumulate(local, bit_sum);
 }
@@ -549,9 +580,7 @@ __global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict
     const float med = e[58];
     const int64_t base = (z * C + c) * hw;
     double local = 0;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
-        const float xv = x[base + p];
-        const float v = noise ? xv + noise[base + p] : rintf(xv - med) + med;
+    auto bits_of = [&](float v) {
         const float lower = eb_logits(e, v - 0.5f);
         const float upper = eb_logits(e, v + 0.5f);
         const float sm = lower + upper;
@@ -559,10 +588,55 @@ __global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict
         const float su = 1.f / (1.f + expf(-sign * upper));
         const float sl = 1.f / (1.f + expf(-sign * lower));
         const float lik = fmaxf(fabsf(su - sl), 1e-9f);
-        const float b = -log2f(lik);
-        if (bits) bits[base + p] = b;
-        if (qout) qout[base + p] = v;
-        local += (double)b;
+        return -log2f(lik);
+    };
+    if (!noise) {
+        // Eval: v = round(x - median) + median takes one value per integer offset, so the 24 tanh + 2 exp + log of the
+        // chain are evaluated ONCE per offset and channel into an LDS table (the same arithmetic as the direct path, so the
+        // values are identical) and the element loop is load -> round -> table -> store: HBM-bound, 16 bytes per lane.
+        constexpr int TR = 127;                                  // offsets -127 .. 127 from the table, the rest direct
+        __shared__ float tab[2 * TR + 1];
+        if (threadIdx.x < 2 * TR + 1) tab[threadIdx.x] = bits_of((float)((int)threadIdx.x - TR) + med);
+        __syncthreads();
+        auto one = [&](float xv, float& b, float& q) {
+            const float r = rintf(xv - med);
+            q = r + med;
+            b = fabsf(r) <= (float)TR ? tab[(int)r + TR] : bits_of(q);
+        };
+        const bool vec = (hw & 3) == 0 && ((((uintptr_t)(x + base)) | ((uintptr_t)(bits ? bits + base : x + base)) |
+                                            ((uintptr_t)(qout ? qout + base : x + base))) & 15) == 0;
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(x + base);
+            float4* b4 = bits ? reinterpret_cast<float4*>(bits + base) : nullptr;
+            float4* q4 = qout ? reinterpret_cast<float4*>(qout + base) : nullptr;
+            for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < (hw >> 2); p += (int64_t)gridDim.x * blockDim.x) {
+                const float4 xv = x4[p];
+                float4 b, q;
+                one(xv.x, b.x, q.x);
+                one(xv.y, b.y, q.y);
+                one(xv.z, b.z, q.z);
+                one(xv.w, b.w, q.w);
+                if (b4) b4[p] = b;
+                if (q4) q4[p] = q;
+                local += (double)b.x + (double)b.y + (double)b.z + (double)b.w;
+            }
+        } else {
+            for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+                float b, q;
+                one(x[base + p], b, q);
+                if (bits) bits[base + p] = b;
+                if (qout) qout[base + p] = q;
+                local += (double)b;
+            }
+        }
+    } else {
+        for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+            const float v = x[base + p] + noise[base + p];
+            const float b = bits_of(v);
+            if (bits) bits[base + p] = b;
+            if (qout) qout[base + p] = v;
+            local += (double)b;
+        }
     }
     if (bit_sum) block_accumulate(local, bit_sum);
 }
@@ -855,9 +929,11 @@ extern "C" int lldwt_nonneg_param_bwd(const float* x, const float* gy, float* gx
 extern "C" int lldwt_gauss_rate(const float* x, const float* params, const float* noise, float* bits, float* qout,
                                 double* bit_sum, int64_t Z, int C, int64_t hw, void* stream) {
     LLDWT_REQUIRE(x && params && Z > 0 && C > 0 && hw > 0, "gauss_rate: bad arguments");
-    const int64_t n = Z * C * hw;
-    hipLaunchKernelGGL(k_gauss_rate, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, params, noise, bits, qout,
-                       bit_sum, C, hw, n);
+    const int64_t ZC = Z * C;
+    int64_t gx = cdiv(hw, 1024);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(k_gauss_rate, dim3((unsigned)gx, (unsigned)(ZC > 65535 ? 65535 : ZC)), dim3(256), 0, (hipStream_t)stream, x, params, noise, bits, qout,
+                       bit_sum, C, hw, ZC);
     return check_launch("gauss_rate");
 }
 extern "C" int lldwt_quantize(const float* x, const float* noise, float* q, int64_t n, void* stream) {
@@ -870,7 +946,7 @@ extern "C" int lldwt_factorized_rate(const float* x, const float* eb, const floa
                                      double* bit_sum, int64_t planes, int64_t batch, int C, int64_t hw, void* stream) {
     LLDWT_REQUIRE(x && eb && planes > 0 && batch > 0 && C > 0 && hw > 0, "factorized_rate: bad arguments");
     LLDWT_REQUIRE(planes * batch <= 65535 && C <= 65535, "factorized_rate: grid too large");
-    int64_t gx = cdiv(hw, 256);
+    int64_t gx = cdiv(hw, noise ? 256 : 1024);      // eval: 4 elements per lane per iteration
     if (gx > 1024) gx = 1024;
     dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
     hipLaunchKernelGGL(k_factorized_rate, grid, dim3(256), 0, (hipStream_t)stream, x, eb, noise, bits, qout, bit_sum,

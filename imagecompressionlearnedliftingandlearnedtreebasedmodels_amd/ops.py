@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_LRELU, ACT_NONE, ACT_TANH, EPI_LRELU_BWD, EPI_NONE, EPI_TANH_BWD, ConvDesc, View,  # noqa: F401
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_LRELU_BWD, EPI_NONE, EPI_TANH_BWD, ConvDesc, View,  # noqa: F401
                    check)
 
 _ws = {}

@@ -36,6 +36,7 @@ extern "C" {
 #define LLDWT_ACT_NONE 0
 #define LLDWT_ACT_TANH 1
 #define LLDWT_ACT_LRELU 2   /* LeakyReLU(0.01) */
+#define LLDWT_ACT_RELU 3    /* ReLU (post-processing networks, post_processing_networks.py:45,60-70) */
 
 const char* lldwt_last_error(void);
 int lldwt_version(void);

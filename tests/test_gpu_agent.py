@@ -115,3 +115,55 @@ def test_train_step_inside_nccl_group():
         assert parallel.mean_over_ranks([2.5], ag.device) == [2.5]
     finally:
         dist.destroy_process_group()
+
+
+def test_postprocess_iwave_forward_backward_and_agent_mode(tmp_path):
+    """PostProcessingiWave (post_processing_networks.py:54-77) on the conv engine vs the same module's torch maths, its
+    gradients vs torch autograd, and the agent's train_postprocess mode (frozen codec, MSE-only training, :113-153)."""
+    import torch.nn.functional as F
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.layers.post_processing_networks import \
+        PostProcessingiWave
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
+    cfg = make_config(resnetlevel=2, postprocess="iwave")
+    torch.manual_seed(3)
+    net = PostProcessingiWave(cfg)
+    for blk in net.resNetList:                         # the reference's 0.01 init makes the blocks ~identity: use a livelier one
+        for m in (blk.resNet[0], blk.resNet[2]):
+            torch.nn.init.normal_(m.weight, std=0.05)
+            torch.nn.init.normal_(m.bias, std=0.05)
+    assert sorted(k for k in net.state_dict() if "resNetList.1" in k) == [
+        "resNetList.1.resNet.0.bias", "resNetList.1.resNet.0.weight", "resNetList.1.resNet.2.bias", "resNetList.1.resNet.2.weight"]
+    x = torch.rand(2, 3, 24, 40)
+
+    def torch_forward(m, inp):
+        c = lambda conv, t: F.conv2d(t, conv.weight, conv.bias, padding=1)
+        t1 = c(m.convFilter, inp)
+        t2 = t1
+        for blk in m.resNetList:
+            t2 = c(blk.resNet[2], F.relu(c(blk.resNet[0], t2))) + t2
+        return c(m.outputConvFilter, c(m.interConvFilter, t2) + t1) + inp
+    import copy
+    ref = copy.deepcopy(net).double()
+    xr = x.double().requires_grad_(True)
+    yr = torch_forward(ref, xr)
+    (yr ** 2).sum().backward()
+    net = net.to(DEV).train()
+    xg = x.to(DEV).requires_grad_(True)
+    yg = net(xg)
+    assert float((yg.detach().cpu().double() - yr.detach()).abs().max()) < 2e-5
+    (yg ** 2).sum().backward()
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 2e-3 * float(xr.grad.abs().max())
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert float((p.grad.cpu().double() - q.grad).abs().max()) < 2e-3 * float(q.grad.abs().max()) + 1e-6, n
+    net.eval()
+    with torch.no_grad():
+        assert float((net(x.to(DEV)).cpu().double() - yr.detach()).abs().max()) < 2e-5       # eval path (cached packs)
+    ag = _agent(dwtlevels=2, mode="train_postprocess", postprocess="iwave", resnetlevel=1, patch_size=32, batch_size=2,
+                val_patch_size=32, checkpoint_dir=str(tmp_path) + "/", entropy_layer="factorized")
+    before = [p.detach().clone() for p in ag.postprocess.parameters()]
+    codec = [p.detach().clone() for p in ag.model.parameters()]
+    ag.run()
+    assert any(not torch.equal(a, b) for a, b in zip(before, ag.postprocess.parameters()))   # the post-filter trained
+    assert all(torch.equal(a, b) for a, b in zip(codec, ag.model.parameters()))              # the codec did not
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint.pth.tar"), weights_only=True)
+    assert "state_dict_postprocess" in ck                                                     # agents/base.py:112-124
