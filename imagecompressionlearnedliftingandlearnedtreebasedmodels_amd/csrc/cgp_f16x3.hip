@@ -21,6 +21,7 @@
 // 22-bit split precision over 18 binades, so a loose bound costs nothing).
 // Output: params (planes, batch, 2*groups, h, w) = (sigma, mu) interleaved per subband, consumed by lldwt_gauss_rate.
 #include "common.h"
+#include "split_f16.h"
 
 namespace lldwt {
 
@@ -148,13 +149,15 @@ struct Cgp16Args {
 __device__ __forceinline__ void next_frags(const floatx16& acc, float inv, const float* __restrict__ bias, int h, float snext,
                                            half8 (&bh)[2], half8 (&bl)[2]) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        float v = acc[q] * inv + bias[drow(q, h)];
-        v = v >= 0.f ? v : 0.01f * v;
-        v *= snext;
-        const _Float16 hh = (_Float16)v;
-        bh[q >> 3][q & 7] = hh;
-        bl[q >> 3][q & 7] = (_Float16)(v - (float)hh);
+    for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = acc[8 * s + j] * inv + bias[drow(8 * s + j, h)];
+            t = t >= 0.f ? t : 0.01f * t;
+            v[j] = t * snext;
+        }
+        split8v(v, bh[s], bl[s]);
     }
 }
 
@@ -230,14 +233,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int k = 0; k < NK0; ++k)
+        for (int k = 0; k < NK0; ++k) {
+            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = xin[nb][k][j] * s_in;
-                const _Float16 hh = (_Float16)v;
-                b0h[nb][k][j] = hh;
-                b0l[nb][k][j] = (_Float16)(v - (float)hh);
-            }
+            for (int j = 0; j < 8; ++j) v[j] = xin[nb][k][j] * s_in;
+            split8v(v, b0h[nb][k], b0l[nb][k]);
+        }
 
     // ---- weight stream: ring of 4 steps
     half8 ah[4], al[4];

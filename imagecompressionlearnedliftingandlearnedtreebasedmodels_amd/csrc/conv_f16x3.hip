@@ -22,6 +22,7 @@
 //   A (weights): pre-split, pre-packed in lane order per (wave, chunk, tap, k-step): each wave streams ITS fragments
 //      straight from L2 into registers (1 KB coalesced per instruction, no LDS), two k-steps ahead.
 #include "common.h"
+#include "split_f16.h"
 
 namespace lldwt {
 
@@ -192,13 +193,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {                                                                                                                 \
         typedef _Float16 half4_ __attribute__((ext_vector_type(4)));                                                  \
         half4_ hi_, lo_;                                                                                              \
+        float v4_[4];                                                                                                 \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
             const bool ok_ = inimg[R] && ((C1) + icg8[R] + (HALF) * 4 + j) < a.cin;                                   \
-            const float v_ = ok_ ? xin[R][(HALF) * 4 + j] * sx : 0.f;                                                 \
-            const _Float16 hh_ = (_Float16)v_;                                                                        \
-            hi_[j] = hh_;                                                                                             \
-            lo_[j] = (_Float16)(v_ - (float)hh_);                                                                     \
+            v4_[j] = ok_ ? xin[R][(HALF) * 4 + j] * sx : 0.f;                                                         \
         }                                                                                                             \
+        split4v(v4_, hi_, lo_);                                                                                       \
         const bool dead_ = (tid + (R) * 256) >= F3_NTASK;                                                             \
         uint8_t* d_ = dead_ ? lds + 2 * F3_BUF + (HALF) * 8 : (DST) + woff[R] + (HALF) * 8;                           \
         *reinterpret_cast<half4_*>(d_) = hi_;                                                                         \

@@ -22,6 +22,7 @@
 // shifted sum, 9 MFMAs per 16 pixels instead of 39.
 // LDS: skip 6 KB + T1 77 KB + T2 60 KB (+ T3 aliasing T1, D aliasing T2) = 143 KB: one 512-thread workgroup per CU.
 #include "lifting_f16.h"
+#include "split_f16.h"
 
 namespace lldwt {
 
@@ -57,14 +58,7 @@ __device__ __forceinline__ float pow2_scale(float amax) {             // s = 2^k
     return ldexpf(1.f, k);
 }
 
-__device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const _Float16 h = (_Float16)v[j];
-        hi[j] = h;
-        lo[j] = (_Float16)(v[j] - (float)h);
-    }
-}
+__device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo) { split4v(v, hi, lo); }
 
 // effective tap t = dy*5+dx of an orientation -> index into the PyTorch (kh,kw) weight
 __device__ __forceinline__ int srctap(int t, int orient) { return orient == 0 ? t : (t % LF_K) * LF_K + t / LF_K; }
@@ -216,13 +210,10 @@ __device__ __forceinline__ void interleave_hint() {
 __device__ __forceinline__ floatx4 conv1_tile(const float* __restrict__ S, int sbase, const int (&soff)[8], float s_skip,
                                               const half8& a1h, const half8& a1l) {
     half8 bh, bl;
+    float g[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = S[sbase + soff[j]] * s_skip;
-        const _Float16 h = (_Float16)v;
-        bh[j] = h;
-        bl[j] = (_Float16)(v - (float)h);
-    }
+    for (int j = 0; j < 8; ++j) g[j] = S[sbase + soff[j]] * s_skip;
+    split8v(g, bh, bl);
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bl, acc, 0, 0, 0);

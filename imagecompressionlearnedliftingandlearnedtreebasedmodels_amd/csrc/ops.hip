@@ -946,7 +946,9 @@ extern "C" int lldwt_factorized_rate(const float* x, const float* eb, const floa
                                      double* bit_sum, int64_t planes, int64_t batch, int C, int64_t hw, void* stream) {
     LLDWT_REQUIRE(x && eb && planes > 0 && batch > 0 && C > 0 && hw > 0, "factorized_rate: bad arguments");
     LLDWT_REQUIRE(planes * batch <= 65535 && C <= 65535, "factorized_rate: grid too large");
-    int64_t gx = cdiv(hw, noise ? 256 : 1024);      // eval: 4 elements per lane per iteration
+    // eval: every workgroup first builds the per-offset table (255 chain evaluations), so give it >= 8192 elements to
+    // stream afterwards (4 per lane per iteration)
+    int64_t gx = noise ? cdiv(hw, 256) : cdiv(hw, 8192);
     if (gx > 1024) gx = 1024;
     dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
     hipLaunchKernelGGL(k_factorized_rate, grid, dim3(256), 0, (hipStream_t)stream, x, eb, noise, bits, qout, bit_sum,
