@@ -1,0 +1,75 @@
+"""Summarise the passes of tools/profile_round2.sh into profiles/r02_*.{csv,json} (per-kernel averages per launch)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(R, "profiles")
+
+
+def short(n):
+    return re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "")).replace("void ", "").strip()[:80]
+
+
+def counters(tag):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    seen = set()
+    for f in glob.glob(os.path.join(R, "gpurun_out", tag, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            key = (k, r["Dispatch_Id"])
+            if key not in seen:
+                seen.add(key)
+                cnt[k] += 1
+    return agg, cnt
+
+
+def main():
+    # kernel stats
+    st = glob.glob(os.path.join(R, "gpurun_out", "r02_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        rows = list(csv.DictReader(open(st[0])))
+        with open(os.path.join(OUT, "r02_a_kernel_stats_bench_cfg3.csv"), "w") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "ms_per_step(4 steps)"])
+            for r in rows[:30]:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            "%.3f" % (float(r["TotalDurationNs"]) / 4e6)])
+    fetch, nf = counters("r02_fetch")
+    write, nw = counters("r02_write")
+    sq, ns = counters("r02_sq")
+    with open(os.path.join(OUT, "r02_b_pmc_per_kernel.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "avg_FETCH_SIZE_KB_per_launch", "avg_WRITE_SIZE_KB_per_launch", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+                    "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"])
+        for k in sorted(fetch, key=lambda k: -fetch[k]["FETCH_SIZE"]):
+            n = max(nf[k], 1)
+            s = sq.get(k, {})
+            w.writerow([k, nf[k], "%.1f" % (fetch[k]["FETCH_SIZE"] / n), "%.1f" % (write.get(k, {}).get("WRITE_SIZE", 0.0) / max(nw[k], 1))] +
+                       ["%.4g" % s.get(c, 0.0) for c in ("SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU",
+                                                        "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")])
+    dom = [k for k in fetch if "k_conv3_f16x3" in k]
+    if dom:
+        k = dom[0]
+        fk, wk = fetch[k]["FETCH_SIZE"] / max(nf[k], 1), write[k]["WRITE_SIZE"] / max(nw[k], 1)
+        tj = {"kernel": k, "plc_mode": "f16x3", "launches": nf[k],
+              "avg_fetch_KB_per_launch": fk, "avg_write_KB_per_launch": wk,
+              "traffic_bytes_per_launch": (fk + wk) * 1024.0,
+              "correction": "none applied: the activation staging loads are 4 B/lane (calibrated 1:1 in round 1), only the "
+                            "weight-fragment stream (2.4 MB per plane, L2-resident) is 16 B/lane, where FETCH_SIZE reads half",
+              "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 "
+                        "--warmup 1 --train-steps 0 --no-cpu-baseline --no-hbm-kernels; profiles/r02_b_pmc_per_kernel.csv"}
+        json.dump(tj, open(os.path.join(OUT, "traffic_current.json"), "w"), indent=1)
+        json.dump(tj, open(os.path.join(OUT, "r02_traffic.json"), "w"), indent=1)
+        print(json.dumps(tj))
+    for k in list(sq)[:0]:
+        pass
+
+
+if __name__ == "__main__":
+    main()
