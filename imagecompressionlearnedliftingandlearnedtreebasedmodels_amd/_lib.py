@@ -79,6 +79,8 @@ SIGNATURES = {
     "lldwt_conv_pack_ex": (_i, [_p, _p, C.POINTER(ConvDesc), _i64, _i, _p]),
     "lldwt_conv2d": (_i, [_p, _p, _p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_absmax": (_i, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
+    "lldwt_conv2d_f16out": (_i, [_p, _p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
+    "lldwt_conv3x3_f16in": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_wgrad": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_wgrad_ex": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _f, _i, _p]),
     "lldwt_conv_f16x3_packed_bytes": (_i64, [_i, _i]),

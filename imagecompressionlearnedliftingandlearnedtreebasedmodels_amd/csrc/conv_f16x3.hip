@@ -23,6 +23,7 @@
 //      straight from L2 into registers (1 KB coalesced per instruction, no LDS), two k-steps ahead.
 #include "common.h"
 #include "split_f16.h"
+#include <type_traits>
 
 namespace lldwt {
 
@@ -131,10 +132,16 @@ struct F3Args {
     const uint8_t* packed;
     const float* bias;
     const float* slots;
+    const _Float16* x16;     // IN16: the input tensor stored as fp16 (already multiplied by xscale[plane]); x is unused
+    const float* xscale;     // IN16: (planes) power-of-two storage scale of x16
     int cin, cout, act, batch, h, w, tiles_x, nch;
     int64_t plane_bytes;
 };
 
+// IN16 = false: fp32 input, split on the way into LDS, three MFMA products per k-step (fp32-level accuracy).
+// IN16 = true : "fp16 storage" (BASELINE configs[4]): the input tensor lives in HBM as fp16 (half the bytes), it is the hi
+//               part and there is no lo: two products (w_hi x + w_lo x), 2^-11 relative on the activations.
+template <bool IN16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv3_f16x3(F3Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,10 +154,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int64_t hw = (int64_t)h * w;
 
     // ---- scales (exact powers of two)
-    float amax = a.slots[plane * 64 + lane];
+    float sx;
+    if constexpr (IN16) {
+        sx = a.xscale[plane];
+    } else {
+        float amax = a.slots[plane * 64 + lane];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    const float sx = pow2_scale_for(amax);
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        sx = pow2_scale_for(amax);
+    }
     const uint8_t* pp = a.packed + (int64_t)plane * a.plane_bytes;
     const float sw = *reinterpret_cast<const float*>(pp);
     const float out_scale = (1.f / sx) * (1.f / sw);
@@ -172,11 +184,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         inimg[r] = in;
         icg8[r] = icg * 8;
         woff[r] = p * F3_PITCH + icg * 16;
-        pix[r] = in ? 4u * (unsigned)(gy * w + gx) : 0u;
+        pix[r] = in ? (IN16 ? 2u : 4u) * (unsigned)(gy * w + gx) : 0u;
     }
-    const float* xg = a.x + z * (int64_t)a.cin * hw;
-    const unsigned hw4 = 4u * (unsigned)hw;
-    float xin[F3_R][8];
+    using in_t = typename std::conditional<IN16, _Float16, float>::type;
+    const in_t* xg = (IN16 ? reinterpret_cast<const in_t*>(a.x16) : reinterpret_cast<const in_t*>(a.x)) + z * (int64_t)a.cin * hw;
+    const unsigned hw4 = (IN16 ? 2u : 4u) * (unsigned)hw;
+    in_t xin[F3_R][8];
 
     // loads of staging task R of the chunk whose first channel is C1 (channels past cin-1 read plane cin-1, zeroed later)
 #define F3_TASK_LOAD(R, C1)                                                                                           \
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned rcmax_ = (unsigned)(a.cin - 1 - (C1));                                                         \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
             const unsigned rc_ = min((unsigned)(icg8[R] + j), rcmax_);                                                \
-            xin[R][j] = *reinterpret_cast<const float*>(cb_ + (rc_ * hw4 + pix[R]));                                  \
+            xin[R][j] = *reinterpret_cast<const in_t*>(cb_ + (rc_ * hw4 + pix[R]));                                   \
         }                                                                                                             \
     }
     // split + store of channels 4*HALF .. 4*HALF+3 of staging task R into the LDS buffer at DST
@@ -193,16 +206,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {                                                                                                                 \
         typedef _Float16 half4_ __attribute__((ext_vector_type(4)));                                                  \
         half4_ hi_, lo_;                                                                                              \
-        float v4_[4];                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
-            const bool ok_ = inimg[R] && ((C1) + icg8[R] + (HALF) * 4 + j) < a.cin;                                   \
-            v4_[j] = ok_ ? xin[R][(HALF) * 4 + j] * sx : 0.f;                                                         \
-        }                                                                                                             \
-        split4v(v4_, hi_, lo_);                                                                                       \
         const bool dead_ = (tid + (R) * 256) >= F3_NTASK;                                                             \
         uint8_t* d_ = dead_ ? lds + 2 * F3_BUF + (HALF) * 8 : (DST) + woff[R] + (HALF) * 8;                           \
-        *reinterpret_cast<half4_*>(d_) = hi_;                                                                         \
-        *reinterpret_cast<half4_*>(d_ + (dead_ ? 16 : F3_PART)) = lo_;                                                \
+        if constexpr (IN16) {                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+                const bool ok_ = inimg[R] && ((C1) + icg8[R] + (HALF) * 4 + j) < a.cin;                               \
+                hi_[j] = ok_ ? (_Float16)xin[R][(HALF) * 4 + j] : (_Float16)0.f;                                      \
+            }                                                                                                         \
+            *reinterpret_cast<half4_*>(d_) = hi_;                                                                     \
+        } else {                                                                                                      \
+            float v4_[4];                                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+                const bool ok_ = inimg[R] && ((C1) + icg8[R] + (HALF) * 4 + j) < a.cin;                               \
+                v4_[j] = ok_ ? (float)xin[R][(HALF) * 4 + j] * sx : 0.f;                                              \
+            }                                                                                                         \
+            split4v(v4_, hi_, lo_);                                                                                   \
+            *reinterpret_cast<half4_*>(d_) = hi_;                                                                     \
+            *reinterpret_cast<half4_*>(d_ + (dead_ ? 16 : F3_PART)) = lo_;                                            \
+        }                                                                                                             \
     }
 
     floatx16 acc[8];
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                            \
                 const int off = ((hf_ * 4 + n + dy_) * F3_IW + dx_) * F3_PITCH + ks_ * 32;             \
                 bh[SET][n] = *reinterpret_cast<const half8*>(bb + off);                                \
-                bl[SET][n] = *reinterpret_cast<const half8*>(bb + F3_PART + off);                      \
+                if constexpr (!IN16) bl[SET][n] = *reinterpret_cast<const half8*>(bb + F3_PART + off); \
             }                                                                                          \
         }
         F3_BLOAD(0, 0)
@@ -271,7 +292,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_l, bh[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
-                acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, bl[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
+                if constexpr (!IN16)
+                    acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, bl[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
                 acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, bh[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
             }
 #pragma unroll
@@ -353,6 +375,7 @@ extern "C" int lldwt_conv3x3_f16x3(const float* x, float* y, const void* packed,
     LLDWT_REQUIRE((int64_t)F3_CK * h * w_ * 4 < (int64_t)1 << 32, "conv3x3_f16x3: image too large for 32-bit chunk offsets");
     F3Args a;
     a.x = x; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed); a.bias = bias; a.slots = slots;
+    a.x16 = nullptr; a.xscale = nullptr;
     a.cin = cin; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
     a.tiles_x = (int)cdiv(w_, F3_TW);
     a.nch = f3_nch(cin);
@@ -360,13 +383,45 @@ extern "C" int lldwt_conv3x3_f16x3(const float* x, float* y, const void* packed,
     const int tiles_y = (int)cdiv(h, F3_TH);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv3_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv3_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess) {
             set_error("conv3x3_f16x3: cannot reserve %d bytes of LDS", F3_LDS);
             return LLDWT_EHIP;
         }
         attr_set = true;
     }
     dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)f3_nocb(cout), (unsigned)(planes * batch));
-    hipLaunchKernelGGL(k_conv3_f16x3, grid, dim3(256), F3_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_conv3_f16x3<false>, grid, dim3(256), F3_LDS, (hipStream_t)stream, a);
     return check_launch("conv3x3_f16x3");
+}
+
+// fp16-storage variant: x16 (planes,batch,cin,h,w) fp16 = fp32 activations x xscale[plane] (a power of two), as written by
+// lldwt_conv2d_f16out; two MFMA products per k-step.
+extern "C" int lldwt_conv3x3_f16in(const void* x16, float* y, const void* packed, const float* bias, const float* xscale,
+                                   int cin, int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_,
+                                   void* stream) {
+    LLDWT_REQUIRE(x16 && y && packed && xscale, "conv3x3_f16in: null pointer");
+    LLDWT_REQUIRE(cin > 0 && cout > 0 && planes > 0 && batch > 0 && h > 0 && w_ > 0 && planes * batch <= 65535,
+                  "conv3x3_f16in: bad dims");
+    LLDWT_REQUIRE(act == LLDWT_ACT_NONE || act == LLDWT_ACT_LRELU || act == LLDWT_ACT_TANH, "conv3x3_f16in: bad activation");
+    LLDWT_REQUIRE((int64_t)F3_CK * h * w_ * 2 < (int64_t)1 << 32, "conv3x3_f16in: image too large for 32-bit chunk offsets");
+    F3Args a;
+    a.x = nullptr; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed); a.bias = bias; a.slots = nullptr;
+    a.x16 = reinterpret_cast<const _Float16*>(x16); a.xscale = xscale;
+    a.cin = cin; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
+    a.tiles_x = (int)cdiv(w_, F3_TW);
+    a.nch = f3_nch(cin);
+    a.plane_bytes = f3_plane_bytes(cin, cout);
+    const int tiles_y = (int)cdiv(h, F3_TH);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv3_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess) {
+            set_error("conv3x3_f16in: cannot reserve %d bytes of LDS", F3_LDS);
+            return LLDWT_EHIP;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)f3_nocb(cout), (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_conv3_f16x3<true>, grid, dim3(256), F3_LDS, (hipStream_t)stream, a);
+    return check_launch("conv3x3_f16in");
 }

@@ -107,6 +107,8 @@ struct ConvArgs {
     const float* residual;   // same layout as y (ytot channels) or null
     const float* aux;        // same layout as y: forward output for the gradient epilogue, or null
     float* absmax;           // (planes,64) slots receiving max |y| of this launch (feeds the split-fp16 conv), or null
+    _Float16* y16;           // fp16 STORAGE of the output instead of y (values multiplied by oscale[plane]), or null
+    const float* oscale;     // (planes) power-of-two storage scale for y16
     lldwt_conv_desc d;
     ConvPlan p;
     int batch, h, w, tiles_x, tiles_y;
@@ -332,7 +334,9 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
             const int oc = g * cout_g + ocl;
             const int ocp = (oc / d.oc_block) * d.oc_stride + d.oc_off + oc % d.oc_block;
             const float bv = a.bias ? a.bias[plane * d.cout + oc] : 0.f;
-            float* yp = a.y + (z * d.ytot + ocp) * hw;
+            float* yp = a.y16 ? nullptr : a.y + (z * d.ytot + ocp) * hw;
+            _Float16* yp16 = a.y16 ? a.y16 + (z * d.ytot + ocp) * hw : nullptr;
+            const float osc = a.y16 ? a.oscale[plane] : 1.f;
             const float* rp = a.residual ? a.residual + (z * d.ytot + ocp) * hw : nullptr;
             const float* ap = (a.aux && d.epi) ? a.aux + (z * d.ytot + ocp) * hw : nullptr;
 #pragma unroll
@@ -347,7 +351,8 @@ __global__ __launch_bounds__(64 * WVM * WVN) void k_conv_mfma(ConvArgs a) {
                     }
                     if (rp) v += rp[(int64_t)gy * w + gx];
                     v = act_apply(v, d.act);
-                    yp[(int64_t)gy * w + gx] = v;
+                    if (yp16) yp16[(int64_t)gy * w + gx] = (_Float16)(v * osc);
+                    else yp[(int64_t)gy * w + gx] = v;
                     omax = fmaxf(omax, fabsf(v));
                 }
             }
@@ -412,6 +417,13 @@ static int conv_desc_ok(const char* who, const lldwt_conv_desc* d, int64_t plane
 }  // namespace lldwt
 using namespace lldwt;
 
+static int conv2d_launch_impl(ConvArgs& a, const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_,
+                              void* stream);
+static int conv2d_launch(ConvArgs& a, const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_,
+                         void* stream) {
+    return conv2d_launch_impl(a, d, planes, batch, h, w_, stream);
+}
+
 extern "C" int64_t lldwt_conv_packed_floats(const lldwt_conv_desc* d) {
     if (!d || d->groups <= 0 || d->cin % d->groups || d->cout % d->groups) return -1;
     return make_plan(*d).plane_floats;
@@ -452,6 +464,24 @@ extern "C" int lldwt_conv2d_absmax(const float* x, float* y, const float* packed
     }
     ConvArgs a;
     a.x = x; a.y = y; a.packed = packed; a.bias = bias; a.residual = residual; a.aux = aux; a.absmax = absmax_slots;
+    a.y16 = nullptr; a.oscale = nullptr;
+    return conv2d_launch(a, d, planes, batch, h, w_, stream);
+}
+
+extern "C" int lldwt_conv2d_f16out(const float* x, void* y16, const float* packed, const float* bias, const float* oscale,
+                                   const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_,
+                                   void* stream) {
+    int r = conv_desc_ok("conv2d_f16out", d, planes, batch, h, w_);
+    if (r) return r;
+    LLDWT_REQUIRE(x && y16 && packed && oscale, "conv2d_f16out: null pointer");
+    ConvArgs a;
+    a.x = x; a.y = nullptr; a.packed = packed; a.bias = bias; a.residual = nullptr; a.aux = nullptr; a.absmax = nullptr;
+    a.y16 = reinterpret_cast<_Float16*>(y16); a.oscale = oscale;
+    return conv2d_launch(a, d, planes, batch, h, w_, stream);
+}
+
+static int conv2d_launch_impl(ConvArgs& a, const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_,
+                              void* stream) {
     a.d = *d;
     a.d.tap_mask &= (1u << (d->K * d->K)) - 1u;
     a.p = make_plan(a.d);

@@ -73,6 +73,18 @@ def _plc_pair(first, second, parent, act2):
         t = _conv(first, parent, act=ops.ACT_LRELU, upsample2=True)
         return _conv(second, t, act=act2)
     m2 = second[0]
+    if ops.storage_dtype() == "fp16":
+        # fp16 STORAGE of the 243-channel tensor between the two convs (BASELINE configs[4]): power-of-two scale from a
+        # bound on |LeakyReLU(conv1(parent))| <= max|parent| * max row L1 norm + max|bias| (all on the device, no sync)
+        w1, b1, packed1, _ = _conv_params(first, "w")
+        l1, bm = cached(first[0], ("l1bound",), [p for m in first for p in (m.weight, m.bias)],
+                        lambda: (w1.abs().sum(dim=(2, 3, 4)).amax(dim=1), b1.abs().amax(dim=1)))
+        bound = ops.absmax_slots(parent).amax(dim=1) * l1 + bm
+        oscale = torch.exp2(14.0 - torch.ceil(torch.log2(bound.clamp_min(1e-30)))).contiguous()
+        t16 = ops.conv2d_f16out(parent, w1, b1, 3, oscale, act=ops.ACT_LRELU, upsample2=True, packed=packed1)
+        b2, packed16 = cached(m2, ("conv_f16x3",), [p for m in second for p in (m.weight, m.bias)],
+                              lambda: (_stack(second, lambda m: m.bias), ops.conv_f16x3_pack(_stack(second, lambda m: m.weight))))
+        return ops.conv3x3_f16in(t16, packed16, b2, m2.out_channels, oscale, act=act2)
     slots = torch.empty(parent.shape[0], 64, device=parent.device, dtype=torch.float32)
     t = _conv(first, parent, act=ops.ACT_LRELU, upsample2=True, absmax=slots)
 

@@ -277,6 +277,42 @@ def conv2d(x, w, bias, K, groups=1, act=ACT_NONE, upsample2=False, transposed=Fa
     return out
 
 
+def storage_dtype():
+    """Storage type of the tree-context tensor between the two tree convs: 'fp32' (default, the reference's) or 'fp16'
+    (BASELINE configs[4]: half the bytes, two MFMA products instead of three, 1e-2 tolerance class).  LLDWT_STORAGE."""
+    import os
+    m = os.environ.get("LLDWT_STORAGE", "fp32")
+    if m not in ("fp32", "fp16"):
+        raise _lib.LLDWTError("LLDWT_STORAGE must be 'fp32' or 'fp16' (got %r)" % m)
+    return m
+
+
+def conv2d_f16out(x, w, bias, K, oscale, act=ACT_NONE, upsample2=False, packed=None):
+    """conv2d whose output is STORED as fp16 x oscale[plane] (include/lldwt.h lldwt_conv2d_f16out) -> (P,B,cout,h,w) half."""
+    lib = _lib.load()
+    P, B, cin, hi, wi = x.shape
+    cout = w.shape[1]
+    h, wd = (hi * 2, wi * 2) if upsample2 else (hi, wi)
+    y = torch.empty(P, B, cout, h, wd, device=x.device, dtype=torch.float16)
+    d = conv_desc(cin, cout, K, 1, act, upsample2, False, None, None, 0, 0, cout, 0, 0, 0, 0, 0)
+    if packed is None:
+        packed = conv_pack(w, K)
+    check(lib.lldwt_conv2d_f16out(_chk(x, "x"), C.c_void_p(y.data_ptr()), _chk(packed, "packed"), _opt(bias, "bias"),
+                                  _chk(oscale, "oscale"), C.byref(d), P, B, h, wd, _stream()), "conv2d_f16out")
+    return y
+
+
+def conv3x3_f16in(x16, packed, bias, cout, xscale, act=ACT_NONE):
+    """Dense 3x3 conv reading an fp16-stored input (lldwt_conv3x3_f16in); packed = conv_f16x3_pack(w)."""
+    if not (x16.is_cuda and x16.dtype == torch.float16 and x16.is_contiguous()):
+        raise _lib.LLDWTError("conv3x3_f16in: x16 must be a contiguous fp16 device tensor")
+    P, B, cin, h, w = x16.shape
+    y = torch.empty(P, B, cout, h, w, device=x16.device, dtype=torch.float32)
+    check(_lib.load().lldwt_conv3x3_f16in(C.c_void_p(x16.data_ptr()), _chk(y), C.c_void_p(packed.data_ptr()), _opt(bias, "bias"),
+                                         _chk(xscale, "xscale"), cin, cout, act, P, B, h, w, _stream()), "conv3x3_f16in")
+    return y
+
+
 def cgp_mode():
     """Arithmetic of the fused cgp stack on the eval path: 'f16x3' (default; split-fp16 register chain, csrc/cgp_f16x3.hip)
     or 'f32' (fp32 MFMA kernel k_cgp_rate).  Environment variable LLDWT_CGP_MODE."""

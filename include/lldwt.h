@@ -263,6 +263,18 @@ int lldwt_absmax_slots(const float* x, int64_t planes, int64_t n_per_plane, floa
 int lldwt_conv3x3_f16x3(const float* x, float* y, const void* packed, const float* bias, const float* slots, int cin,
                         int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
 
+/* Reduced-precision STORAGE of the tree-context tensor (BASELINE.json configs[4] "fp16"): the first tree
+ * conv writes its output as fp16 (half the HBM bytes), multiplied by a power of two oscale[plane] chosen by the caller from
+ * a bound (max |parent| x max row L1 norm + max |bias|) so that it cannot overflow; the second conv consumes it as the hi
+ * half with no lo (two MFMA products instead of three): 2^-11 relative on the activations, fp32 accumulate.  Its own
+ * tolerance (1e-2) and bench config; never the headline.
+ *   lldwt_conv2d_f16out : lldwt_conv2d with y16 (planes,batch,ytot,h,w) fp16 = act(conv(x) + bias) * oscale[plane]
+ *   lldwt_conv3x3_f16in : lldwt_conv3x3_f16x3 reading such a tensor (xscale = the oscale it was written with)        */
+int lldwt_conv2d_f16out(const float* x, void* y16, const float* packed, const float* bias, const float* oscale,
+                        const lldwt_conv_desc* d, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+int lldwt_conv3x3_f16in(const void* x16, float* y, const void* packed, const float* bias, const float* xscale, int cin,
+                        int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+
 /* Same maths from the raw PyTorch-layout weights w, reference-order direct kernel (VALU); cross-checks the MFMA engine. */
 int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
                         int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);

@@ -269,3 +269,34 @@ def test_cgp_rate_ctx_large_vs_torch():
             fr = (resid[bad] - torch.floor(resid[bad]) - 0.5).abs()
             assert float(fr.max()) < 1e-3 and int(bad.sum()) < 20, (int(bad.sum()), float(fr.max()))
         assert abs(float(got[0].cpu()[~bad].double().sum()) - float(ref[~bad].double().sum())) < 1e-4 * float(ref.double().sum())
+
+
+def test_fp16_storage_of_the_tree_context_tensor(monkeypatch):
+    """BASELINE configs[4] "fp16": the 243-channel tensor between the two tree convs stored as fp16 (LLDWT_STORAGE=fp16,
+    two MFMA products per MAC).  Its own tolerance class (~1e-2 relative against the fp32 oracle): summed bits
+    within 1e-2 relative, 99 % of the coefficients within 1e-2 * (1 + bits); the fp32-storage path keeps the tight bars."""
+    cfg = _cfg(dwtlevels=4, entropy_layer="onlyEZWT")
+    x = natural_ish(1, 512, 512, 21)
+    net, sd = _net(cfg)
+    y = omodel.rgb2ycbcr(x) - omodel._YSHIFT
+    ora = _oracle(y, sd, cfg)
+    L = cfg.dwtlevels
+    oxe = torch.stack([ora[c][2] for c in range(3)], 0).to(DEV).contiguous()
+    oxo = [torch.stack([ora[c][3][i] for c in range(3)], 0).to(DEV).contiguous() for i in range(L)]
+    em = [n.entropymodel for n in net.nets()]
+    monkeypatch.setenv("LLDWT_STORAGE", "fp16")
+    with torch.no_grad():
+        si_xe, si_xo, _, _ = type(em[0]).forward_planes(em, oxe, oxo, False)
+    tot = ref = 0.0
+    close = n = 0
+    for c in range(3):
+        for i in range(L):
+            got, want = si_xo[i][c].cpu(), ora[c][5][i]
+            tot += float(got.double().sum())
+            ref += float(want.double().sum())
+            close += int(((got - want).abs() <= 1e-2 * (1.0 + want)).sum())
+            n += want.numel()
+    assert abs(tot - ref) < 1e-2 * ref, (tot, ref)
+    assert close >= 0.99 * n, (close, n)
+    print("\n[fp16 storage] sum bits %.1f vs oracle %.1f (rel %.2e); %d of %d coefficients within 1e-2*(1+bits)" % (
+        tot, ref, abs(tot - ref) / ref, close, n))
