@@ -15,8 +15,12 @@ constexpr int LF_H_C1 = 0;
 constexpr int LF_H_C2 = LF_H_C1 + LF_FRAG;
 constexpr int LF_H_C3 = LF_H_C2 + LF_KS * LF_FRAG;
 constexpr int LF_H_C4 = LF_H_C3 + LF_KS * LF_FRAG;
-constexpr int LF_H_END = LF_H_C4 + LF_KS4 * LF_FRAG;          // 30 * 1024 halves
-constexpr int LF_ORIENT_FLOATS = LF_H_END / 2 + 16;           // + scales (4 floats, padded to 16)
+constexpr int LF_KSC = 5;                 // conv4 o conv3 composed (9x9, 16 -> 1) as D[dx][px]: K = 9 dy x 16 ch = 144 -> 5 k-steps
+constexpr int LF_H_CC = LF_H_C4 + LF_KS4 * LF_FRAG;           // composite fragments
+constexpr int LF_H_END = LF_H_CC + LF_KSC * LF_FRAG;          // 35 * 1024 halves
+// floats after the fragments: [0..3] s_w1..s_w4, [4] s_wc, [16..31] sum over taps of w4[oc], [32..112] Wr[81] = w4 o w1
+constexpr int LF_TAIL_FLOATS = 128;
+constexpr int LF_ORIENT_FLOATS = LF_H_END / 2 + LF_TAIL_FLOATS;
 constexpr int LF_FLOATS = 2 * LF_ORIENT_FLOATS;               // both orientations
 
 static inline __host__ __device__ int lift_f16_floats(int C, int K) { return (C == LF_C && K == LF_K) ? LF_FLOATS : 0; }

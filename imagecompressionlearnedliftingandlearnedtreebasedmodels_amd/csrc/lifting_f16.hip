@@ -90,6 +90,41 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
     for (int q = 0; q < 4; ++q) sw[q] = pow2_scale(fmaxf(fmaxf(red[q][0], red[q][1]), fmaxf(red[q][2], red[q][3])));
     float* dst = packed + (int64_t)plane * plane_stride + f16_off + (int64_t)orient * LF_ORIENT_FLOATS;
     _Float16* hp = reinterpret_cast<_Float16*>(dst);
+    // ---- the composed kernels of this orientation (effective taps): P_block_v2.py:50-55 has no nonlinearity between
+    // conv3 and conv4, so away from the image border conv4(conv3(t2) + b3 + r) + b4 =
+    //   (w4 o w3) * t2  +  (w4 o w1) * skip  +  b4 + sum_oc (b3 + b1)[oc] * sum_p w4[oc][p]
+    // wc[ic][u][v] = sum_oc sum_{p + q = (u, v)} w4[oc][p] w3[oc][ic][q]  (9x9);  wr[u][v] the same with w1 (1 -> 16)
+    __shared__ float wc[LF_C * 81];
+    __shared__ float wr[81];
+    __shared__ float redc[4];
+    for (int i = tid; i < LF_C * 81 + 81; i += 256) {
+        const bool is_r = i >= LF_C * 81;
+        const int ic = is_r ? 0 : i / 81, s = is_r ? i - LF_C * 81 : i % 81;
+        const int u = s / 9, vv = s % 9;
+        double acc = 0.0;
+        for (int oc = 0; oc < LF_C; ++oc)
+            for (int py = 0; py < LF_K; ++py) {
+                const int qy = u - py;
+                if (qy < 0 || qy >= LF_K) continue;
+                for (int px = 0; px < LF_K; ++px) {
+                    const int qx = vv - px;
+                    if (qx < 0 || qx >= LF_K) continue;
+                    const float a4 = w4[oc * LF_KK + srctap(py * LF_K + px, orient)];
+                    const float b = is_r ? w1[oc * LF_KK + srctap(qy * LF_K + qx, orient)]
+                                         : w3[(oc * LF_C + ic) * LF_KK + srctap(qy * LF_K + qx, orient)];
+                    acc += (double)a4 * (double)b;
+                }
+            }
+        if (is_r) wr[s] = (float)acc; else wc[i] = (float)acc;
+    }
+    __syncthreads();
+    float mc = 0.f;
+    for (int i = tid; i < LF_C * 81; i += 256) mc = fmaxf(mc, fabsf(wc[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+    if ((tid & 63) == 0) redc[tid >> 6] = mc;
+    __syncthreads();
+    const float swc = pow2_scale(fmaxf(fmaxf(redc[0], redc[1]), fmaxf(redc[2], redc[3])));
     for (int i = tid; i < LF_H_END / 2; i += 256) {          // one (hi, lo) pair per iteration
         int rem = i;
         const int j = rem % 8; rem /= 8;
@@ -105,17 +140,29 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
             const int t = 2 * ks + (kg >> 1), ic = 8 * (kg & 1) + j;
             const float* w = which == 0 ? w2 : w3;
             if (t < LF_KK) v = w[(row * LF_C + ic) * LF_KK + srctap(t, orient)] * sw[1 + which];
-        } else {                                              // conv4: rows = dx, k = (dy, channel)
+        } else if (step < 1 + 2 * LF_KS + LF_KS4) {           // conv4: rows = dx, k = (dy, channel)
             const int ks = step - 1 - 2 * LF_KS;
             const int k = 32 * ks + 8 * kg + j, dy = k / LF_C, ic = k % LF_C;
             if (dy < LF_K && row < LF_K) v = w4[ic * LF_KK + srctap(dy * LF_K + row, orient)] * sw[3];
+        } else {                                              // conv4 o conv3: rows = dx (0..8), k = (dy 0..8, channel)
+            const int ks = step - 1 - 2 * LF_KS - LF_KS4;
+            const int k = 32 * ks + 8 * kg + j, dy = k / LF_C, ic = k % LF_C;
+            if (dy < 9 && row < 9) v = wc[ic * 81 + dy * 9 + row] * swc;
         }
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         hp[(step * 2 + 0) * 512 + lane * 8 + j] = hi;
         hp[(step * 2 + 1) * 512 + lane * 8 + j] = lo;
     }
-    if (tid < 4) dst[LF_H_END / 2 + tid] = sw[tid];
+    float* tail = dst + LF_H_END / 2;
+    if (tid < 4) tail[tid] = sw[tid];
+    if (tid == 4) tail[4] = swc;
+    if (tid < LF_C) {
+        float s4 = 0.f;
+        for (int t = 0; t < LF_KK; ++t) s4 += w4[tid * LF_KK + t];
+        tail[16 + tid] = s4;
+    }
+    if (tid < 81) tail[32 + tid] = wr[tid];
 }
 
 struct LfArgs {
@@ -370,6 +417,71 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     __syncthreads();
+
+    // ---------------- interior tiles: conv4(conv3(t2) + b3 + r) + b4 through the COMPOSED 9x9 kernels (packed by
+    // k_lift_f16_pack): exact algebra wherever the t3 region (20 x 36 around the tile) lies inside the image, because
+    // the only thing between conv3 and conv4 is the zero padding at the image border.  5 k-steps x 3 MFMAs per 16 pixels on
+    // 16 x 40 pixels instead of 13 x 3 on 20 x 36 plus conv4, no t3 image, no second pass over conv1.
+    const bool interior = y0 >= 2 && y0 + TH + 2 <= h && x0 >= 2 && x0 + TW + 2 <= w && !(a.dbg & 16);
+    if (interior) {
+        constexpr int NPC = TH * R2W, NTC = NPC / 16;           // 640 pixels (16 rows x 40 T2 columns), 40 tiles
+        constexpr int DP = 12;                                  // floats per pixel in the D image (9 used)
+        static_assert(NPC % 16 == 0 && NPC * DP * 4 <= 4 * N1 * 16, "D image fits the T1 region");
+        const float* tail = pk + a.f16 + LF_H_END / 2;
+        const float swc = tail[4];
+        float* D = reinterpret_cast<float*>(lds + LDS_T1);      // T1 is dead after P2
+        {
+            half8 ah[LF_KSC], al[LF_KSC];
+#pragma unroll
+            for (int ks = 0; ks < LF_KSC; ++ks) {
+                ah[ks] = *reinterpret_cast<const half8*>(frag + LF_H_CC + (ks * 2 + 0) * 512 + lane * 8);
+                al[ks] = *reinterpret_cast<const half8*>(frag + LF_H_CC + (ks * 2 + 1) * 512 + lane * 8);
+            }
+            const uint8_t* img = lds + LDS_T2;
+            for (int tile = wave; tile < NTC; tile += NWAVE) {
+                const int p = tile * 16 + pl;
+                const int r = p / R2W, c = p - r * R2W;         // D(r, c) <-> output row r, T2 column c; tap dy -> T2 row r + dy
+                const int basein = (r * R2W + c) * 16 + halfsel * (N2 * 16);
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < LF_KSC; ++ks) {
+                    const int dya = 2 * ks, dyb = 2 * ks + 1 < 9 ? 2 * ks + 1 : 8;            // dy 9 does not exist: weight 0
+                    const int off = basein + (hi_tap ? dyb : dya) * (R2W * 16);
+                    const half8 bh = *reinterpret_cast<const half8*>(img + off);
+                    const half8 bl = *reinterpret_cast<const half8*>(img + 2 * N2 * 16 + off);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc, 0, 0, 0);
+                }
+                // rows = dx: lanes kg 0 hold dx 0-3, kg 1 dx 4-7, kg 2 dx 8 (register 0)
+                if (kg < 2) *reinterpret_cast<floatx4*>(D + p * DP + 4 * kg) = acc;
+                if (kg == 2) D[p * DP + 8] = acc[0];
+            }
+        }
+        __syncthreads();
+        {
+            const int oy = tid / TW, ox = tid - oy * TW;
+            const int gy = y0 + oy, gx = x0 + ox;                // inside the image by the interior condition
+            const float invc = (1.f / ACT_SCALE) * (1.f / swc);
+            float net = 0.f;
+#pragma unroll
+            for (int dx = 0; dx < 9; ++dx) net += D[(oy * R2W + ox + dx) * DP + dx];
+            net *= invc;
+            float cst = bias[a.b4];
+#pragma unroll
+            for (int oc = 0; oc < LF_C; ++oc) cst += (bias[a.b3 + oc] + bias[a.b1 + oc]) * tail[16 + oc];
+            float rs = 0.f;                                       // (w4 o w1) * skip: 81 taps on the skip patch
+#pragma unroll
+            for (int u = 0; u < 9; ++u)
+#pragma unroll
+                for (int v = 0; v < 9; ++v) rs += tail[32 + u * 9 + v] * S[(oy + 4 + u) * SW + ox + 4 + v];
+            net += rs + cst;
+            const float skip = S[(oy + 8) * SW + ox + 8];
+            const float din = a.v.din[z * a.v.din_sz + (int64_t)gy * a.v.din_sy + (int64_t)gx * a.v.din_sx];
+            a.v.dout[z * a.v.dout_sz + (int64_t)gy * a.v.dout_sy + (int64_t)gx * a.v.dout_sx] = din + a.sign * (skip + a.rw * net);
+        }
+        return;
+    }
 
     // ---------------- P3: t3 = conv3(t2) + b3 + r,  r = conv1(skip) + b1 (recomputed), on 20 x 36; dynamic scale
     constexpr int IT3 = (NT3 + NWAVE - 1) / NWAVE;      // 6

@@ -45,7 +45,7 @@ def main():
     res["f32_three_launches_us"] = timeit()
     ref = out.clone()
     lib.lldwt_set_lift_mode(1)
-    for dbg in (0, 1, 2, 4, 8, 15, 6):
+    for dbg in (0, 16, 1, 2, 4, 8, 15):
         os.environ["LLDWT_LF_DBG"] = str(dbg)
         res["fused_dbg%d_us" % dbg] = timeit()
     os.environ["LLDWT_LF_DBG"] = "0"
