@@ -17,10 +17,23 @@ class ConvFn(torch.autograd.Function):
     """y = act(conv(x, w) + b [+ residual]); x (P,B,cin,h,w) [(P,B,cin,h/2,w/2) if upsample2], w (P,cout,cin/g,K,K)."""
 
     @staticmethod
+    def _f16x3(x, w, K, groups, upsample2, tap_mask, residual):
+        """Dense 3x3 convs with many channels (the 243 -> 243 tree conv) run on the fp16 matrix cores with split-fp16
+        operands in training too -- forward and backward-data (same kernel, transposed + flipped weights); fp32-level
+        accuracy (csrc/conv_f16x3.hip).  The weight gradient stays on the fp32 MFMA kernel."""
+        return (K == 3 and groups == 1 and not upsample2 and tap_mask is None and residual is None and w.shape[1] >= 64 and
+                w.shape[2] >= 64 and ops.plc_mode() == "f16x3")
+
+    @staticmethod
     def forward(ctx, x, w, b, residual, K, groups, act, upsample2, tap_mask):
-        y = ops.conv2d(x, w, b, K, groups=groups, act=act, upsample2=upsample2, tap_mask=tap_mask, residual=residual)
+        fast = ConvFn._f16x3(x, w, K, groups, upsample2, tap_mask, residual)
+        if fast:
+            y = ops.conv3x3_f16x3(x, ops.conv_f16x3_pack(w.detach().contiguous()), b, w.shape[1], act=act)
+        else:
+            y = ops.conv2d(x, w, b, K, groups=groups, act=act, upsample2=upsample2, tap_mask=tap_mask, residual=residual)
         ctx.save_for_backward(x, w, y if act != ops.ACT_NONE else None)
         ctx.cfg = (K, groups, act, upsample2, tap_mask, b is not None, residual is not None)
+        ctx.fast = fast
         return y
 
     @staticmethod
@@ -30,7 +43,10 @@ class ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dpre = ops.act_bwd(dy, y, act) if act != ops.ACT_NONE else dy
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.fast:
+            wt = w.detach().transpose(1, 2).flip(-1, -2).contiguous()          # (P, cin, cout, 3, 3): the adjoint conv's weight
+            dx = ops.conv3x3_f16x3(dpre, ops.conv_f16x3_pack(wt), None, w.shape[2])
+        elif ctx.needs_input_grad[0]:
             # backward-data: the forward weight read as a ConvTranspose2d weight (cin' = cout) with flipped taps
             dx = ops.conv2d(dpre, w, None, K, groups=groups, transposed=True, tap_mask=ops.flip_mask(tap_mask, K))
             if upsample2:
