@@ -330,6 +330,12 @@ def main():
         ops.conv2d = timed(ops.conv2d, plc_work)                  # mode f32: the fp32 MFMA engine
         ops.conv3x3_f16x3 = timed(ops.conv3x3_f16x3, plc16_work)  # mode f16x3: split-fp16 on the fp16 matrix cores
         ops.conv3x3_f16in = timed(ops.conv3x3_f16in, plc16_work)  # fp16 storage: two products per MAC
+
+        def fused_work(parent, packed1, packed2, bias2, cmid, cout, **kw):
+            # the pair in one launch (default): both convs' algorithmic MACs, the halo recomputation of the first NOT counted
+            P, B, _, hp, wp = parent.shape
+            return 2.0 * (cmid * cout * 9 + 3 * cmid * 9) * P * B * 4 * hp * wp if (cmid == 243 and cout == 243) else 0.0
+        ops.plc_fused = timed(ops.plc_fused, fused_work)
         roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS,
                 "kernel": "plc conv 243->243 3x3 (tree context model; the largest share of the step's FLOPs)"}
     elif lifting:
@@ -384,7 +390,8 @@ def main():
     if os.path.exists(tpath) and a.config == 2 and not c["overrides"]:
         with open(tpath) as f:
             tj = json.load(f)
-        if tj.get("plc_mode", "f32") == ops.plc_mode():
+        fused_now = ops.plc_mode() == "f16x3" and ops.plc_fuse() and ops.storage_dtype() != "fp16"
+        if tj.get("plc_mode", "f32") == ops.plc_mode() and bool(tj.get("fused", False)) == fused_now:
             traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source")
     dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom["events"])
     n_launch = max(len(dom["events"]), 1)
@@ -398,6 +405,9 @@ def main():
     if has_plc:
         mode = ops.plc_mode()
         roof["arithmetic"] = mode
+        if mode == "f16x3" and ops.plc_fuse() and ops.storage_dtype() != "fp16":
+            roof["kernel"] = ("tree-context pair conv 3->243 (on the fly) + conv 243->243 3x3 in one launch, k_conv3_f16x3<2> "
+                              "(lldwt_plc_fused; the largest share of the step's FLOPs)")
         nprod = 2.0 if ops.storage_dtype() == "fp16" else 3.0
         if ops.storage_dtype() == "fp16":
             roof["storage"] = "fp16 (tree-context tensor stored as fp16; 2 MFMA products per MAC; tolerance class 1e-2)"

@@ -10,7 +10,10 @@ pids=()
 for f in ops lifting lifting_f16 cdf97 conv_mfma conv_f16x3 cgp_fused cgp_f16x3 conv_bwd rans; do
   [ -f "$HERE/$f.hip" ] || continue
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/lifting_f16.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/split_f16.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/lldwt.h" -nt "$HERE/obj/$f.o" ]; then
-    ( $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" ) &
+    EXTRA=""
+    # the 36-unit chunk loop of the split-fp16 conv must unroll completely (register rings indexed by the unit number)
+    [ "$f" = conv_f16x3 ] && EXTRA="-mllvm -pragma-unroll-threshold=131072"
+    ( $HIPCC $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" ) &
     pids+=($!)
   fi
 done

@@ -44,6 +44,13 @@ constexpr int F3_HDR = 256;                     // per-plane header: [0] = s_w
 constexpr int F3_NTASK = F3_NPX * (F3_CK / 8);  // staging tasks (pixel, group of 8 channels) per chunk
 constexpr int F3_R = (F3_NTASK + 255) / 256;    // per thread: 6
 
+constexpr int F1_HDR = 2048;                    // conv1 pack: [0] s_w1, [1] max row L1 norm, [2] max |b|; floats [16 .. 16+256) bias
+constexpr int F1_CHUNK_BYTES = 2 * F3_STEP_BYTES;   // 2 k-steps (K = 27 -> 32) x (hi, lo)
+constexpr int F1_NBLK = (F3_NPX + 31) / 32;     // 11 pixel blocks of 32 cover the 340-pixel patch (12 slots: 3 per wave)
+constexpr int F1_COL = 12 * 4 * 1024;           // the split im2col of the parent patch, [block][k-step][hi|lo][lane][8 x fp16]
+constexpr int F1_LDS = F3_LDS + F1_COL;         // 158,016 B
+static inline int64_t f1_plane_bytes(int cmid) { return F1_HDR + (int64_t)cdiv(cmid, F3_CK) * F1_CHUNK_BYTES; }
+
 static inline int f3_nch(int cin) { return (int)cdiv(cin, F3_CK); }
 static inline int f3_nocb(int cout) { return (int)cdiv(cout, F3_OCB); }
 static inline int64_t f3_plane_bytes(int cin, int cout) {
@@ -126,6 +133,56 @@ __global__ void k_f3_pack(const float* __restrict__ w, uint8_t* __restrict__ pac
     if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = sw;
 }
 
+// ---- FUSED mode: first tree conv (cmid, 3, 3, 3) -> per plane [hdr | chunk][ks][hi|lo][lane][8 x fp16]
+// A[row = channel of the chunk][k = ci*9 + tap], k < 27
+__global__ void k_f1_pack(const float* __restrict__ w1, const float* __restrict__ b1, uint8_t* __restrict__ packed, int cmid,
+                          int64_t plane_bytes) {
+    const int plane = blockIdx.x, tid = threadIdx.x;
+    const float* wp = w1 + (int64_t)plane * cmid * 27;
+    const float* bp = b1 + (int64_t)plane * cmid;
+    uint8_t* pp = packed + (int64_t)plane * plane_bytes;
+    float* hdr = reinterpret_cast<float*>(pp);
+    __shared__ float red[3][4];
+    float mw = 0.f, ml1 = 0.f, mb = 0.f;
+    for (int r = tid; r < cmid; r += 256) {
+        float s1 = 0.f;
+        for (int k = 0; k < 27; ++k) {
+            const float v = fabsf(wp[r * 27 + k]);
+            s1 += v;
+            mw = fmaxf(mw, v);
+        }
+        ml1 = fmaxf(ml1, s1);
+        mb = fmaxf(mb, fabsf(bp[r]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+        ml1 = fmaxf(ml1, __shfl_xor(ml1, o, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = mw; red[1][tid >> 6] = ml1; red[2][tid >> 6] = mb; }
+    __syncthreads();
+    const float amw = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    const float sw1 = pow2_scale_for(amw);
+    if (tid == 0) {
+        hdr[0] = sw1;
+        hdr[1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        hdr[2] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    }
+    const int nch = (cmid + F3_CK - 1) / F3_CK;
+    for (int i = tid; i < nch * F3_CK; i += 256) hdr[16 + i] = i < cmid ? bp[i] : 0.f;
+    _Float16* fr = reinterpret_cast<_Float16*>(pp + F1_HDR);
+    for (int i = tid; i < nch * 2 * 512; i += 256) {
+        const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) & 1, chunk = i >> 10;
+        const int c = chunk * F3_CK + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+        float v = 0.f;
+        if (c < cmid && k < 27) v = wp[c * 27 + k] * sw1;
+        const _Float16 hi = (_Float16)v;
+        fr[(chunk * 2 + ks) * 1024 + lane * 8 + j] = hi;
+        fr[(chunk * 2 + ks) * 1024 + 512 + lane * 8 + j] = (_Float16)(v - (float)hi);
+    }
+}
+
 struct F3Args {
     const float* x;
     float* y;
@@ -134,6 +191,9 @@ struct F3Args {
     const float* slots;
     const _Float16* x16;     // IN16: the input tensor stored as fp16 (already multiplied by xscale[plane]); x is unused
     const float* xscale;     // IN16: (planes) power-of-two storage scale of x16
+    const float* parent;     // FUSED: (planes*batch, 3, h/2, w/2) fp32, the tensor the FIRST tree conv reads (2x-upsampled)
+    const uint8_t* packed1;  // FUSED: first conv's split-fp16 fragments + bias + bounds (lldwt_plc_fused_pack1)
+    int64_t plane_bytes1;
     int cin, cout, act, batch, h, w, tiles_x, nch;
     int64_t plane_bytes;
 };
@@ -141,8 +201,15 @@ struct F3Args {
 // IN16 = false: fp32 input, split on the way into LDS, three MFMA products per k-step (fp32-level accuracy).
 // IN16 = true : "fp16 storage" (BASELINE configs[4]): the input tensor lives in HBM as fp16 (half the bytes), it is the hi
 //               part and there is no lo: two products (w_hi x + w_lo x), 2^-11 relative on the activations.
-template <bool IN16>
+// MODE 2 (FUSED): the input tensor does not exist.  It is LeakyReLU(conv3x3(3 -> cin) of the 2x-upsampled parent), and
+//               each chunk of 32 of its channels is computed ON THE FLY for the 10 x 34 patch by the matrix cores
+//               (M = 32 channels, N = pixels, K = 27 -> 32; B = the im2col of the parent patch, gathered and split ONCE per
+//               tile and kept in registers) and written straight into the LDS image that the second conv reads: no first
+//               conv launch, no 243-channel tensor in HBM (1.5 GB written + 2 GB read per level-0 launch), no global
+//               staging loads, no |x|-max pass (the activation scale comes from a per-workgroup bound).
+template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv3_f16x3(F3Args a) {
+    constexpr bool IN16 = MODE == 1, FUSED = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t z = blockIdx.z;
@@ -154,9 +221,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int64_t hw = (int64_t)h * w;
 
     // ---- scales (exact powers of two)
-    float sx;
+    float sx = 1.f;
     if constexpr (IN16) {
         sx = a.xscale[plane];
+    } else if constexpr (FUSED) {
+        // set after the parent patch has been gathered (below)
     } else {
         float amax = a.slots[plane * 64 + lane];
 #pragma unroll
@@ -165,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     const uint8_t* pp = a.packed + (int64_t)plane * a.plane_bytes;
     const float sw = *reinterpret_cast<const float*>(pp);
-    const float out_scale = (1.f / sx) * (1.f / sw);
+    float out_scale = (1.f / sx) * (1.f / sw);
 
     // ---- staging tasks of this thread: (pixel p of the 10x34 patch, group of 8 channels icg).  Branch-free: padding
     // pixels and dead tasks load pixel 0 of a real plane and are zeroed at the split; dead tasks store to a dump slot.
@@ -235,13 +304,128 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint8_t* wbase = pp + F3_HDR + ((int64_t)(ocb * 4 + wave) * a.nch) * F3_CHUNK_BYTES + lane * 16;
     const int boff = (lane & 31) * F3_PITCH + (lane >> 5) * 16;     // B fragment: pixel column lane&31, k half lane>>5
 
+    // ---- FUSED: the im2col of the parent patch for this wave's pixel blocks (wave, wave + 4, wave + 8), once per tile
+    uint8_t* col1 = lds + F3_LDS + lane * 16;     // each lane writes and reads only its own 16-byte slots: no barrier needed
+    int p1[3];
+    bool pin1[3];
+    float inv1 = 1.f;
+    const uint8_t* pk1 = nullptr;
+    const float* bias1 = nullptr;
+    if constexpr (FUSED) {
+        pk1 = a.packed1 + (int64_t)plane * a.plane_bytes1;
+        const float* h1 = reinterpret_cast<const float*>(pk1);
+        bias1 = h1 + 16;
+        const int hp = h >> 1, wp_ = w >> 1;
+        const float* par = a.parent + z * 3 * (int64_t)hp * wp_;
+        const int hh = lane >> 5;
+        float g1[3][2][8];
+        float amax = 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int p = (wave + 4 * b) * 32 + (lane & 31);
+            const bool live = p < F3_NPX;
+            const int pc = live ? p : 0;
+            const int ly = pc / F3_IW, lx = pc - ly * F3_IW;
+            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+            p1[b] = live ? p : -1;
+            pin1[b] = live && gy >= 0 && gy < h && gx >= 0 && gx < w;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * ks + 8 * hh + j;                  // (input channel, tap) = divmod(k, 9), k < 27
+                    const int ci = k >= 18 ? 2 : (k >= 9 ? 1 : 0), tap = k - 9 * ci;
+                    const int dy = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), dx = tap - 3 * dy;
+                    const int Y = gy + dy - 1, X = gx + dx - 1;          // position in the UPSAMPLED image (zero padded)
+                    const bool ok = live && k < 27 && Y >= 0 && Y < h && X >= 0 && X < w;
+                    const float v = ok ? par[(int64_t)ci * hp * wp_ + (Y >> 1) * wp_ + (X >> 1)] : 0.f;
+                    g1[b][ks][j] = v;
+                    amax = fmaxf(amax, fabsf(v));
+                }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        float* red = reinterpret_cast<float*>(lds + 2 * F3_BUF + 32);      // second half of the 64-byte dump slot
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float s_p = pow2_scale_for(amax);
+        sx = pow2_scale_for(amax * h1[1] + h1[2]);                           // bound on |LeakyReLU(conv1)|: max|parent| * L1max + |b|max
+        out_scale = (1.f / sx) * (1.f / sw);
+        inv1 = (1.f / s_p) * (1.f / h1[0]);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v8[j] = g1[b][ks][j] * s_p;
+                half8 ch_, cl_;
+                split8v(v8, ch_, cl_);
+                *reinterpret_cast<half8*>(col1 + (((wave + 4 * b) * 2 + ks) * 2 + 0) * 1024) = ch_;
+                *reinterpret_cast<half8*>(col1 + (((wave + 4 * b) * 2 + ks) * 2 + 1) * 1024) = cl_;
+            }
+    }
+    // conv1 operands of the chunk being staged: weight fragments (2 k-steps x hi, lo) and the 16 bias values of this lane's
+    // rows -- the same for the wave's three pixel blocks, loaded once per chunk a few units ahead of their first use
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    half8 w1h[2], w1l[2];
+    floatx4 b1v[4];
+#define F3_FUSED_LOAD(C1)                                                                                             \
+    {                                                                                                                 \
+        const uint8_t* w1_ = pk1 + F1_HDR + (int64_t)((C1) / F3_CK) * F1_CHUNK_BYTES + lane * 16;                     \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
+            w1h[ks] = *reinterpret_cast<const half8*>(w1_ + ks * F3_STEP_BYTES);                                      \
+            w1l[ks] = *reinterpret_cast<const half8*>(w1_ + ks * F3_STEP_BYTES + 1024);                               \
+        }                                                                                                             \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                              \
+            b1v[gq] = *reinterpret_cast<const floatx4*>(bias1 + (C1) + 8 * gq + 4 * (lane >> 5));                     \
+    }
+    // channels C1 .. C1+31 of the first conv for pixel block B of this wave -> split -> the LDS image at DST
+#define F3_FUSED_BLOCK(B, DST)                                                                                        \
+    {                                                                                                                 \
+        floatx16 t_;                                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) t_[q] = 0.f;                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
+            const half8 ch_ = *reinterpret_cast<const half8*>(col1 + (((wave + 4 * (B)) * 2 + ks) * 2 + 0) * 1024);  \
+            const half8 cl_ = *reinterpret_cast<const half8*>(col1 + (((wave + 4 * (B)) * 2 + ks) * 2 + 1) * 1024);  \
+            t_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[ks], ch_, t_, 0, 0, 0);                                   \
+            t_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ks], cl_, t_, 0, 0, 0);                                   \
+            t_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ks], ch_, t_, 0, 0, 0);                                   \
+        }                                                                                                             \
+        typedef _Float16 half4_ __attribute__((ext_vector_type(4)));                                                  \
+        const bool livep_ = p1[B] >= 0;                                                                               \
+        uint8_t* d0_ = livep_ ? (DST) + p1[B] * F3_PITCH + (lane >> 5) * 8 : lds + 2 * F3_BUF;                        \
+        const int lo_off_ = livep_ ? F3_PART : 16;                                                                    \
+        const int gstep_ = livep_ ? 16 : 0;                                                                           \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                            \
+            float v4_[4];                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+                float v_ = t_[4 * gq + i] * inv1 + b1v[gq][i];                                                        \
+                v_ = v_ >= 0.f ? v_ : 0.01f * v_;                                                                     \
+                v4_[i] = pin1[B] ? v_ * sx : 0.f;                                                                     \
+            }                                                                                                         \
+            half4_ hi_, lo_;                                                                                          \
+            split4v(v4_, hi_, lo_);                                                                                   \
+            *reinterpret_cast<half4_*>(d0_ + gq * gstep_) = hi_;                                                      \
+            *reinterpret_cast<half4_*>(d0_ + gq * gstep_ + lo_off_) = lo_;                                            \
+        }                                                                                                             \
+    }
+
     // ---- prologue: chunk 0 into buffer 0
+    if constexpr (FUSED) {
+        F3_FUSED_LOAD(0)
+        F3_FUSED_BLOCK(0, lds)
+        F3_FUSED_BLOCK(1, lds)
+        F3_FUSED_BLOCK(2, lds)
+    } else {
 #pragma unroll
-    for (int r = 0; r < F3_R; ++r) F3_TASK_LOAD(r, 0)
+        for (int r = 0; r < F3_R; ++r) F3_TASK_LOAD(r, 0)
 #pragma unroll
-    for (int r = 0; r < F3_R; ++r) {
-        F3_TASK_STORE(r, 0, 0, lds)
-        F3_TASK_STORE(r, 1, 0, lds)
+        for (int r = 0; r < F3_R; ++r) {
+            F3_TASK_STORE(r, 0, 0, lds)
+            F3_TASK_STORE(r, 1, 0, lds)
+        }
     }
     __syncthreads();
 
@@ -286,8 +470,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 al[(st + 5) % 6] = *reinterpret_cast<const half8*>(wp + (st + 5) * F3_STEP_BYTES + 1024);
             }
             if (u + 1 < 36) F3_BLOAD(u + 1, (u + 1) & 1)
-            if (u < F3_R) F3_TASK_LOAD(u, c1)
-            if (u >= 24) F3_TASK_STORE((u - 24) >> 1, (u - 24) & 1, c1, sdst)
+            if constexpr (FUSED) {
+                if (u == 14) F3_FUSED_LOAD(c1)
+                if (u == 22) F3_FUSED_BLOCK(0, sdst)
+                if (u == 26) F3_FUSED_BLOCK(1, sdst)
+                if (u == 30) F3_FUSED_BLOCK(2, sdst)
+            } else {
+                if (u < F3_R) F3_TASK_LOAD(u, c1)
+                if (u >= 24) F3_TASK_STORE((u - 24) >> 1, (u - 24) & 1, c1, sdst)
+            }
             const half8 A_h = ah[st % 6], A_l = al[st % 6];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -311,6 +502,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 #undef F3_TASK_LOAD
 #undef F3_TASK_STORE
+#undef F3_FUSED_BLOCK
+#undef F3_FUSED_LOAD
 
     // ---- epilogue: D col = lane&31 (pixel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (channel of the wave's 32)
     const int gx = x0 + (lane & 31);
@@ -375,7 +568,7 @@ extern "C" int lldwt_conv3x3_f16x3(const float* x, float* y, const void* packed,
     LLDWT_REQUIRE((int64_t)F3_CK * h * w_ * 4 < (int64_t)1 << 32, "conv3x3_f16x3: image too large for 32-bit chunk offsets");
     F3Args a;
     a.x = x; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed); a.bias = bias; a.slots = slots;
-    a.x16 = nullptr; a.xscale = nullptr;
+    a.x16 = nullptr; a.xscale = nullptr; a.parent = nullptr; a.packed1 = nullptr; a.plane_bytes1 = 0;
     a.cin = cin; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
     a.tiles_x = (int)cdiv(w_, F3_TW);
     a.nch = f3_nch(cin);
@@ -383,15 +576,15 @@ extern "C" int lldwt_conv3x3_f16x3(const float* x, float* y, const void* packed,
     const int tiles_y = (int)cdiv(h, F3_TH);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv3_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_conv3_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv3_f16x3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv3_f16x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess) {
             set_error("conv3x3_f16x3: cannot reserve %d bytes of LDS", F3_LDS);
             return LLDWT_EHIP;
         }
         attr_set = true;
     }
     dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)f3_nocb(cout), (unsigned)(planes * batch));
-    hipLaunchKernelGGL(k_conv3_f16x3<false>, grid, dim3(256), F3_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_conv3_f16x3<0>, grid, dim3(256), F3_LDS, (hipStream_t)stream, a);
     return check_launch("conv3x3_f16x3");
 }
 
@@ -408,6 +601,7 @@ extern "C" int lldwt_conv3x3_f16in(const void* x16, float* y, const void* packed
     F3Args a;
     a.x = nullptr; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed); a.bias = bias; a.slots = nullptr;
     a.x16 = reinterpret_cast<const _Float16*>(x16); a.xscale = xscale;
+    a.parent = nullptr; a.packed1 = nullptr; a.plane_bytes1 = 0;
     a.cin = cin; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
     a.tiles_x = (int)cdiv(w_, F3_TW);
     a.nch = f3_nch(cin);
@@ -415,13 +609,53 @@ extern "C" int lldwt_conv3x3_f16in(const void* x16, float* y, const void* packed
     const int tiles_y = (int)cdiv(h, F3_TH);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv3_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv3_f16x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) != hipSuccess) {
             set_error("conv3x3_f16in: cannot reserve %d bytes of LDS", F3_LDS);
             return LLDWT_EHIP;
         }
         attr_set = true;
     }
     dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)f3_nocb(cout), (unsigned)(planes * batch));
-    hipLaunchKernelGGL(k_conv3_f16x3<true>, grid, dim3(256), F3_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_conv3_f16x3<1>, grid, dim3(256), F3_LDS, (hipStream_t)stream, a);
     return check_launch("conv3x3_f16in");
+}
+
+
+// ---- the tree-context PAIR in one launch: y = act2(conv3x3(LeakyReLU(conv3x3(up2(parent)) + b1)) + b2)
+extern "C" int64_t lldwt_plc_fused_pack1_bytes(int cmid) { return cmid > 0 && cmid <= 256 ? f1_plane_bytes(cmid) : -1; }
+
+extern "C" int lldwt_plc_fused_pack1(const float* w1, const float* b1, void* packed1, int cmid, int64_t planes, void* stream) {
+    LLDWT_REQUIRE(w1 && b1 && packed1 && cmid > 0 && cmid <= 256 && planes > 0 && planes <= 65535, "plc_fused_pack1: bad arguments");
+    hipLaunchKernelGGL(k_f1_pack, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, w1, b1,
+                       reinterpret_cast<uint8_t*>(packed1), cmid, f1_plane_bytes(cmid));
+    return check_launch("plc_fused_pack1");
+}
+
+extern "C" int lldwt_plc_fused(const float* parent, float* y, const void* packed1, const void* packed2, const float* bias2,
+                               int cmid, int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream) {
+    LLDWT_REQUIRE(parent && y && packed1 && packed2, "plc_fused: null pointer");
+    LLDWT_REQUIRE(cmid > 0 && cmid <= 256 && cout > 0 && planes > 0 && batch > 0 && h > 0 && w_ > 0 && planes * batch <= 65535,
+                  "plc_fused: bad dims");
+    LLDWT_REQUIRE(h % 2 == 0 && w_ % 2 == 0, "plc_fused: the output is the 2x-upsampled parent's size: even h, w");
+    LLDWT_REQUIRE(act == LLDWT_ACT_NONE || act == LLDWT_ACT_LRELU || act == LLDWT_ACT_TANH, "plc_fused: bad activation");
+    F3Args a;
+    a.x = nullptr; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed2); a.bias = bias2; a.slots = nullptr;
+    a.x16 = nullptr; a.xscale = nullptr;
+    a.parent = parent; a.packed1 = reinterpret_cast<const uint8_t*>(packed1); a.plane_bytes1 = f1_plane_bytes(cmid);
+    a.cin = cmid; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
+    a.tiles_x = (int)cdiv(w_, F3_TW);
+    a.nch = f3_nch(cmid);
+    a.plane_bytes = f3_plane_bytes(cmid, cout);
+    const int tiles_y = (int)cdiv(h, F3_TH);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv3_f16x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS) != hipSuccess) {
+            set_error("plc_fused: cannot reserve %d bytes of LDS", F1_LDS);
+            return LLDWT_EHIP;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)f3_nocb(cout), (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_conv3_f16x3<2>, grid, dim3(256), F1_LDS, (hipStream_t)stream, a);
+    return check_launch("plc_fused");
 }

@@ -85,12 +85,17 @@ def _plc_pair(first, second, parent, act2):
         b2, packed16 = cached(m2, ("conv_f16x3",), [p for m in second for p in (m.weight, m.bias)],
                               lambda: (_stack(second, lambda m: m.bias), ops.conv_f16x3_pack(_stack(second, lambda m: m.weight))))
         return ops.conv3x3_f16in(t16, packed16, b2, m2.out_channels, oscale, act=act2)
-    slots = torch.empty(parent.shape[0], 64, device=parent.device, dtype=torch.float32)
-    t = _conv(first, parent, act=ops.ACT_LRELU, upsample2=True, absmax=slots)
-
     def build():
         return _stack(second, lambda m: m.bias), ops.conv_f16x3_pack(_stack(second, lambda m: m.weight))
     b2, packed16 = cached(m2, ("conv_f16x3",), [p for m in second for p in (m.weight, m.bias)], build)
+    m1 = first[0]
+    if ops.plc_fuse() and m1.in_channels == 3 and m1.kernel_size[0] == 3 and m1.out_channels <= 256 and m1.groups == 1:
+        # one launch: the first conv is computed per halo patch inside the second's staging (no 243-channel tensor in HBM)
+        packed1f = cached(m1, ("plc_fused1",), [p for m in first for p in (m.weight, m.bias)],
+                          lambda: ops.plc_fused_pack1(_stack(first, lambda m: m.weight), _stack(first, lambda m: m.bias)))
+        return ops.plc_fused(parent, packed1f, packed16, b2, m1.out_channels, m2.out_channels, act=act2)
+    slots = torch.empty(parent.shape[0], 64, device=parent.device, dtype=torch.float32)
+    t = _conv(first, parent, act=ops.ACT_LRELU, upsample2=True, absmax=slots)
     return ops.conv3x3_f16x3(t, packed16, b2, m2.out_channels, act=act2, slots=slots)
 
 

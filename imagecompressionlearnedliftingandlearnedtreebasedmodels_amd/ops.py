@@ -313,6 +313,44 @@ def conv3x3_f16in(x16, packed, bias, cout, xscale, act=ACT_NONE):
     return y
 
 
+def plc_fuse():
+    """Whether the eval path computes the tree-context PAIR in one launch (lldwt_plc_fused: the first conv on the fly
+    inside the second's staging, no 243-channel tensor in HBM).  Only with plc_mode() == 'f16x3' and fp32 storage.
+    Environment variable LLDWT_PLC_FUSE (default 1)."""
+    import os
+    v = os.environ.get("LLDWT_PLC_FUSE", "1")
+    if v not in ("0", "1"):
+        raise _lib.LLDWTError("LLDWT_PLC_FUSE must be 0 or 1 (got %r)" % v)
+    return v == "1"
+
+
+def plc_fused_pack1(w1, b1):
+    """(P,cmid,3,3,3), (P,cmid) fp32 -> packed split-fp16 first tree conv for plc_fused (uint8 (P, bytes))."""
+    lib = _lib.load()
+    P, cmid, cin, K, K2 = w1.shape
+    if cin != 3 or K != 3 or K2 != 3:
+        raise _lib.LLDWTError("plc_fused_pack1: a (P,cmid,3,3,3) weight")
+    nb = int(lib.lldwt_plc_fused_pack1_bytes(cmid))
+    if nb <= 0:
+        raise _lib.LLDWTError("plc_fused_pack1: cmid must be in 1..256")
+    packed = torch.empty(P, nb, device=w1.device, dtype=torch.uint8)
+    check(lib.lldwt_plc_fused_pack1(_chk(w1, "w1"), _chk(b1, "b1"), C.c_void_p(packed.data_ptr()), cmid, P, _stream()),
+          "plc_fused_pack1")
+    return packed
+
+
+def plc_fused(parent, packed1, packed2, bias2, cmid, cout, act=ACT_NONE):
+    """y = act(conv3x3(LeakyReLU(conv3x3(up2(parent)) + b1)) + b2) in one launch (include/lldwt.h lldwt_plc_fused)."""
+    P, B, cin, hp, wp = parent.shape
+    if cin != 3:
+        raise _lib.LLDWTError("plc_fused: the parent has 3 channels")
+    y = torch.empty(P, B, cout, 2 * hp, 2 * wp, device=parent.device, dtype=torch.float32)
+    check(_lib.load().lldwt_plc_fused(_chk(parent, "parent"), _chk(y), C.c_void_p(packed1.data_ptr()),
+                                     C.c_void_p(packed2.data_ptr()), _opt(bias2, "bias2"), cmid, cout, act, P, B,
+                                     2 * hp, 2 * wp, _stream()), "plc_fused")
+    return y
+
+
 def cgp_mode():
     """Arithmetic of the fused cgp stack on the eval path: 'f16x3' (default; split-fp16 register chain, csrc/cgp_f16x3.hip)
     or 'f32' (fp32 MFMA kernel k_cgp_rate).  Environment variable LLDWT_CGP_MODE."""

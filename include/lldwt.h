@@ -275,6 +275,20 @@ int lldwt_conv2d_f16out(const float* x, void* y16, const float* packed, const fl
 int lldwt_conv3x3_f16in(const void* x16, float* y, const void* packed, const float* bias, const float* xscale, int cin,
                         int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
 
+/* The tree-context PAIR in ONE launch (LiftingBasedDWT_net.py:271-272 / :793-795):
+ *   y = act(conv3x3_{cmid->cout}(LeakyReLU(conv3x3_{3->cmid}(up2(parent)) + b1)) + b2)
+ * parent (planes,batch,3,h/2,w/2) fp32, y (planes,batch,cout,h,w) fp32.  The first conv is evaluated on the fly by the
+ * matrix cores for each workgroup's 10x34 halo patch (K = 27, split-fp16 like the second) and written straight into the
+ * LDS image the second conv consumes: the cmid-channel tensor never exists in HBM.  Scales are per workgroup: the parent
+ * patch by its own |max|, the intermediate by the bound max|patch| * max row L1 norm(w1) + max|b1| (a power of two either
+ * way, so the choice does not change the result beyond the 2^-21 split error).
+ *   packed1 = lldwt_plc_fused_pack1(w1 (planes,cmid,3,3,3), b1 (planes,cmid)), cmid <= 256
+ *   packed2 = lldwt_conv_f16x3_pack(w2 (planes,cout,cmid,3,3));  bias2 (planes,cout) or NULL                              */
+int64_t lldwt_plc_fused_pack1_bytes(int cmid);
+int lldwt_plc_fused_pack1(const float* w1, const float* b1, void* packed1, int cmid, int64_t planes, void* stream);
+int lldwt_plc_fused(const float* parent, float* y, const void* packed1, const void* packed2, const float* bias2, int cmid,
+                    int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);
+
 /* Same maths from the raw PyTorch-layout weights w, reference-order direct kernel (VALU); cross-checks the MFMA engine. */
 int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,
                         int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);

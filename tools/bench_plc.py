@@ -47,6 +47,22 @@ def main():
     out["f16x3"] = {"ms": t * 1e3, "TFLOP/s (algorithmic fp32-equivalent)": flop / t / 1e12, "issued TFLOP/s": 3 * flop * (256 / 243) ** 2 / t / 1e12}
     t = timeit(lambda: ops.absmax_slots(x), a.iters)
     out["absmax_slots"] = {"ms": t * 1e3, "GB/s": x.numel() * 4 / t / 1e9}
+    # the PAIR (first tree conv 3 -> 243 on the 2x-upsampled parent + the dense conv): two launches vs one fused launch
+    parent = torch.randn(P, B, 3, S // 2, S // 2, device=dev).round_()
+    w1 = (torch.rand(P, C, 3, 3, 3, device=dev) - 0.5) * 0.4
+    b1 = torch.rand(P, C, device=dev) - 0.5
+    pk1 = ops.conv_pack(w1, 3)
+    pk1f = ops.plc_fused_pack1(w1, b1)
+
+    def two():
+        sl = torch.empty(P, 64, device=dev)
+        t1 = ops.conv2d(parent, w1, b1, 3, act=ops.ACT_LRELU, upsample2=True, packed=pk1, absmax=sl)
+        return ops.conv3x3_f16x3(t1, pk16, b, C, slots=sl)
+    t = timeit(two, a.iters)
+    out["pair_two_launches"] = {"ms": t * 1e3}
+    t = timeit(lambda: ops.plc_fused(parent, pk1f, pk16, b, C, C), a.iters)
+    out["pair_fused"] = {"ms": t * 1e3, "TFLOP/s (algorithmic fp32-equivalent, second conv only)": flop / t / 1e12}
+    out["pair_max_abs_diff"] = float((two() - ops.plc_fused(parent, pk1f, pk16, b, C, C)).abs().max())
     y32 = ops.conv2d(x, w, b, 3, packed=pk32)
     y16 = ops.conv3x3_f16x3(x, pk16, b, C, slots=slots)
     out["max_abs_diff_f16x3_vs_f32"] = float((y32 - y16).abs().max())
