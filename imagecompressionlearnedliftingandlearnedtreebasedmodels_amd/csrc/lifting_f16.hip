@@ -20,7 +20,12 @@
 // wrap rows -- addressing is per lane anyway).  conv1 (1 -> 16) gathers its 25 taps from the fp32 skip patch straight
 // into a B fragment; conv4 (16 -> 1) is computed as D[dx][pixel] = sum over (dy, channel) and finished by a 5-term
 // shifted sum, 9 MFMAs per 16 pixels instead of 39.
-// LDS: skip 6 KB + T1 77 KB + T2 60 KB (+ T3 aliasing T1, D aliasing T2) = 143 KB: one 512-thread workgroup per CU.
+// LDS: skip 6 KB + T1 77 KB + T2 60 KB (+ T3 aliasing T1, D aliasing T2) + 12 KB fp16 skip images = 155.5 KB: one
+// 512-thread workgroup per CU.
+// conv1's B operand: the skip patch is also kept as SCALED SPLIT fp16 (hi and lo images, plus a copy of each shifted by
+// one element), and conv1's k order is (row dy = lane group, three dx PAIRS (0,1) (2,3) (4,5*)) + one pair of row 4 per
+// lane group (* = a real neighbour value against a zero weight): a lane's 8 k values are four aligned 4-byte LDS reads
+// that land as packed fp16 pairs -- no per-tap gather, no scaling, no split in the loop.
 #include "lifting_f16.h"
 #include "split_f16.h"
 
@@ -44,7 +49,10 @@ constexpr int LDS_S = 0;
 constexpr int LDS_RED = NS * 4;                                       // 64 floats of scratch
 constexpr int LDS_T1 = LDS_RED + 256;
 constexpr int LDS_T2 = LDS_T1 + 4 * N1 * 16;
-constexpr int LDS_TOTAL = LDS_T2 + 4 * N2 * 16;                       // 146,688 B
+constexpr int LDS_S16 = LDS_T2 + 4 * N2 * 16;                         // skip patch as scaled fp16: [copy 0|1][hi|lo][NS16]
+constexpr int NS16 = NS + 48;                                         // copy 1 is copy 0 shifted by one element (aligned pair reads
+constexpr int LDS_TOTAL = LDS_S16 + 4 * NS16 * 2;                     // at odd columns); tails zeroed; copy 1 starts 16 banks after
+static_assert((2 * NS16 * 2) % 128 == 64, "even- and odd-column lanes read different banks");   // copy 0.  159,360 B
 constexpr int LDS_T3 = LDS_T1, LDS_D = LDS_T2;
 static_assert(4 * N3 * 16 <= 4 * N1 * 16 && ND * 8 * 4 <= 4 * N2 * 16, "aliases fit");
 constexpr float ACT_SCALE = 16384.f;                                  // tanh outputs: |t| <= 1 -> |t * 2^14| < fp16 max
@@ -132,9 +140,10 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
         const int step = rem;                                 // global k-step index over conv1 | conv2 | conv3 | conv4
         const int row = lane & 15, kg = lane >> 4;
         float v = 0.f;
-        if (step == 0) {                                      // conv1: k = tap
-            const int t = 8 * kg + j;
-            if (t < LF_KK) v = w1[row * LF_KK + srctap(t, orient)] * sw[0];
+        if (step == 0) {                                      // conv1: k = 8 kg + j; pairs i = j / 2: i < 3 -> (dy = kg, dx = 2 i + j % 2);
+            const int i = j >> 1, e = j & 1;                  // i == 3 -> (dy = 4, dx = 2 kg + j % 2), nothing for kg == 3; dx == 5: zero
+            const int dy = i < 3 ? kg : 4, dx = i < 3 ? 2 * i + e : 2 * kg + e;
+            if (dx < LF_K && dy < LF_K && !(i == 3 && kg == 3)) v = w1[row * LF_KK + srctap(dy * LF_K + dx, orient)] * sw[0];
         } else if (step < 1 + 2 * LF_KS) {                    // conv2 / conv3: k = (tap pair, channel)
             const int which = (step - 1) / LF_KS, ks = (step - 1) % LF_KS;
             const int t = 2 * ks + (kg >> 1), ic = 8 * (kg & 1) + j;
@@ -176,7 +185,15 @@ struct LfArgs {
     int batch, h, w, vertical;
     float sign, rw;
     int dbg;              // diagnostics only (LLDWT_LF_DBG): bit i set = skip the tile loop of phase P(i+1); results are then wrong
+    unsigned long long* stamps;   // diagnostics only (LLDWT_LF_STAMPS = device address): [tile][wave][16] s_memtime stamps
+    int tiles_x, tiles_y;
+    int64_t ntiles;               // tiles_x * tiles_y * Z
 };
+// in-kernel clock stamps of a diagnostic run (tools/lift_stamps.py); a null pointer (always, outside that tool) skips them
+#define LF_STAMP(i)                                                                                                     \
+    if (a.stamps && lane == 0)                                                                                          \
+        a.stamps[(stamp_tile * NWAVE + wave) * 16 + (i)] =                                                              \
+            (i) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
 
 // 13 k-steps of one 16-pixel tile: B fragments from a T-image (input region width WIN, NIN pixels), A fragments in registers
 template <int WIN, int NIN>
@@ -203,20 +220,27 @@ __device__ __forceinline__ floatx4 conv16_tile(const uint8_t* __restrict__ img, 
 // read from LDS into a second register set BEFORE the 6 MFMAs of k-step ks (the sched_group_barrier sequence pins that
 // order and leaves room for 2 vector instructions of a neighbouring epilogue after every MFMA), so the matrix pipe never
 // waits for an LDS round trip.
-template <int WIN, int NIN>
+template <int WIN, int NIN, class Piece>
 __device__ __forceinline__ void conv16_tile2(const uint8_t* __restrict__ img, int base0, int base1, bool hi_tap,
-                                             const half8 (&ah)[LF_KS], const half8 (&al)[LF_KS], floatx4& acc0, floatx4& acc1) {
+                                             const half8 (&ah)[LF_KS], const half8 (&al)[LF_KS], floatx4& acc0, floatx4& acc1,
+                                             Piece&& piece) {
     acc0 = floatx4{0.f, 0.f, 0.f, 0.f};
     acc1 = floatx4{0.f, 0.f, 0.f, 0.f};
     half8 bh0[2], bl0[2], bh1[2], bl1[2];
+    // lanes kg >= 2 take the second tap of the pair: the next pixel (+16 B), the first pixel of the next row where the
+    // first tap ends a row (k-steps 2 and 7), the same tap again in the last k-step (tap 25 does not exist: weight 0).
+    // Three per-lane bases per tile, every k-step offset an immediate.
+    const int dA = hi_tap ? 16 : 0, dW = hi_tap ? (WIN - 4) * 16 : 0;
+    const uint8_t* q0[3] = {img + base0 + dA, img + base0 + dW, img + base0};
+    const uint8_t* q1[3] = {img + base1 + dA, img + base1 + dW, img + base1};
     auto load = [&](int ks, int set) {
-        const int ta = 2 * ks, tb = (2 * ks + 1) < LF_KK ? 2 * ks + 1 : LF_KK - 1;
-        const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16, offb = ((tb / LF_K) * WIN + tb % LF_K) * 16;
-        const int off = hi_tap ? offb : offa;
-        bh0[set] = *reinterpret_cast<const half8*>(img + base0 + off);
-        bl0[set] = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + base0 + off);
-        bh1[set] = *reinterpret_cast<const half8*>(img + base1 + off);
-        bl1[set] = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + base1 + off);
+        const int ta = 2 * ks;
+        const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16;
+        const int sel = ks == LF_KS - 1 ? 2 : (ta % LF_K == LF_K - 1 ? 1 : 0);
+        bh0[set] = *reinterpret_cast<const half8*>(q0[sel] + offa);
+        bl0[set] = *reinterpret_cast<const half8*>(q0[sel] + 2 * NIN * 16 + offa);
+        bh1[set] = *reinterpret_cast<const half8*>(q1[sel] + offa);
+        bl1[set] = *reinterpret_cast<const half8*>(q1[sel] + 2 * NIN * 16 + offa);
     };
     load(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -230,12 +254,16 @@ __device__ __forceinline__ void conv16_tile2(const uint8_t* __restrict__ img, in
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl1[c], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh0[c], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh1[c], acc1, 0, 0, 0);
+        piece(ks);       // a slice of the PREVIOUS pair's epilogue (vector ALU, LDS stores): runs in the shadow of the MFMAs
         // this k-step is a scheduling region of its own (fenced): its 4 LDS reads can only be the NEXT step's, one after
-        // each of the first four MFMAs
+        // each of the first four MFMAs; the epilogue slice is spread between the MFMAs (two waves of a SIMD otherwise fall
+        // into lockstep -- both in their MFMA stretch, then both in their vector stretch -- and the matrix pipe idles)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -253,14 +281,25 @@ __device__ __forceinline__ void interleave_hint() {
     }
 }
 
-// conv1 of one 16-pixel tile: gather this lane's 8 taps from the fp32 skip patch, split, 3 MFMAs
-__device__ __forceinline__ floatx4 conv1_tile(const float* __restrict__ S, int sbase, const int (&soff)[8], float s_skip,
+// conv1 of one 16-pixel tile: this lane's 8 k values = 4 aligned fp16 pairs of the scaled skip patch (see the header), 3 MFMAs.
+// sbase = element index of the tile pixel's top-left tap in the patch; kgoff = {kg * SW, 4 * SW + 2 * min(kg, 2)} (elements)
+__device__ __forceinline__ floatx4 conv1_tile(const uint8_t* __restrict__ s16, int sbase, int kgoff0, int kgoff1,
                                               const half8& a1h, const half8& a1l) {
-    half8 bh, bl;
-    float g[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = S[sbase + soff[j]] * s_skip;
-    split8v(g, bh, bl);
+    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+    const int par = sbase & 1;                                        // odd column: the copy shifted by one element
+    const uint8_t* c = s16 + par * (2 * NS16 * 2) + (sbase - par) * 2;
+    const uint8_t* r0 = c + kgoff0 * 2;
+    const uint8_t* r1 = c + kgoff1 * 2;
+    uintx4 uh, ul;
+    uh[0] = *reinterpret_cast<const unsigned*>(r0);
+    uh[1] = *reinterpret_cast<const unsigned*>(r0 + 4);
+    uh[2] = *reinterpret_cast<const unsigned*>(r0 + 8);
+    uh[3] = *reinterpret_cast<const unsigned*>(r1);
+    ul[0] = *reinterpret_cast<const unsigned*>(r0 + NS16 * 2);
+    ul[1] = *reinterpret_cast<const unsigned*>(r0 + NS16 * 2 + 4);
+    ul[2] = *reinterpret_cast<const unsigned*>(r0 + NS16 * 2 + 8);
+    ul[3] = *reinterpret_cast<const unsigned*>(r1 + NS16 * 2);
+    const half8 bh = __builtin_bit_cast(half8, uh), bl = __builtin_bit_cast(half8, ul);
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bl, acc, 0, 0, 0);
@@ -278,55 +317,106 @@ __device__ __forceinline__ void timg_store(uint8_t* __restrict__ img, int p, int
     *reinterpret_cast<half4*>(d + 2 * N * 16) = lo;
 }
 
+// raw operands of one tile's skip patch (this thread's three patch elements: centre and the two filter neighbours) and its
+// dst_in value: fetched for tile n+1 while tile n is still computing
+struct LfPre {
+    float c[NS / NTH], m[NS / NTH], p[NS / NTH];
+    float din;
+};
+
+// PERSISTENT: one workgroup per CU (155 KB of LDS) walks over tiles t = blockIdx.x, + gridDim.x, ...  The position of a
+// tile inside its image is rotated by the image index, so that a workgroup does not meet the (slower) border tiles of
+// every image.
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lift_fused_f16(LfArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* S = reinterpret_cast<float*>(lds + LDS_S);
     float* RED = reinterpret_cast<float*>(lds + LDS_RED);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
+    const int h = a.h, w = a.w;
+    const int tpi = a.tiles_x * a.tiles_y;                     // tiles per image
+
+    auto decode = [&](int64_t t, int64_t& z, int& y0, int& x0) {
+        z = t / tpi;
+        const int pos = (int)((t - z * tpi + z * 37) % tpi);
+        const int ty = pos / a.tiles_x;
+        y0 = ty * TH;
+        x0 = (pos - ty * a.tiles_x) * TW;
+    };
+    // branch-free: every load goes to a clamped (valid) address; P0 applies the zero padding when it consumes the values
+    const int ssy = (int)a.v.src_sy, ssx = (int)a.v.src_sx;   // per-image offsets fit 32 bits (checked on the host)
+    auto fetch = [&](int64_t t, int tid, LfPre& pr) {
+        const int oy_ = tid / TW, ox_ = tid - oy_ * TW;        // this thread's output pixel inside a tile
+        int64_t z;
+        int y0, x0;
+        decode(t, z, y0, x0);
+        const float* sp = a.v.src + z * a.v.src_sz;
+        const int dyv = a.vertical ? 1 : 0, dxv = 1 - dyv;
+#pragma unroll
+        for (int k = 0; k < NS / NTH; ++k) {
+            const int i = tid + k * NTH;
+            const int sy = i / SW, sx = i - sy * SW;
+            const int gy = min(max(y0 - 8 + sy, 0), h - 1), gx = min(max(x0 - 8 + sx, 0), w - 1);
+            pr.c[k] = sp[gy * ssy + gx * ssx];
+            pr.m[k] = sp[max(gy - dyv, 0) * ssy + max(gx - dxv, 0) * ssx];
+            pr.p[k] = sp[min(gy + dyv, h - 1) * ssy + min(gx + dxv, w - 1) * ssx];
+        }
+        const int gy = min(y0 + oy_, h - 1), gx = min(x0 + ox_, w - 1);
+        pr.din = a.v.din[z * a.v.din_sz + gy * (int)a.v.din_sy + gx * (int)a.v.din_sx];
+    };
+
+    LfPre pre;
+    if ((int64_t)blockIdx.x < a.ntiles) fetch(blockIdx.x, tid0, pre);
+    for (int64_t tile_i = blockIdx.x; tile_i < a.ntiles; tile_i += gridDim.x) {
+    // every per-lane index below derives from an OPAQUE copy of the thread id: otherwise the compiler hoists all the
+    // tile-invariant per-lane address arithmetic of all phases out of the tile loop and spills it
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 4, pl = lane & 15, oc0 = 4 * kg;
     const bool hi_tap = kg >= 2;
     const int halfsel = kg & 1;
-    const int64_t z = blockIdx.z;
+    int64_t z;
+    int y0, x0;
+    decode(tile_i, z, y0, x0);
+    const int64_t stamp_tile = (z * a.tiles_y + y0 / TH) * a.tiles_x + x0 / TW;
     const int plane = (int)(z / a.batch);
-    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-    const int h = a.h, w = a.w;
     const float* pk = a.packed + (int64_t)plane * a.pstride;
     const float* bias = pk + a.orient_fp32;
     const _Float16* frag = reinterpret_cast<const _Float16*>(pk + a.f16);
     const float* scales = pk + a.f16 + LF_H_END / 2;
     const float sw1 = scales[0], sw2 = scales[1], sw3 = scales[2], sw4 = scales[3];
-
-    // ---------------- P0: skip patch (32 x 48) and its |max|
+    const float din_pre = pre.din;
+    LF_STAMP(0)
+    LF_STAMP(14)
+    if (a.stamps && lane == 0)          // slot 13: which CU (XCC_ID << 32 | HW_ID)
+        a.stamps[(stamp_tile * NWAVE + wave) * 16 + 13] =
+            ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
+    // ---------------- P0: skip patch (32 x 48) from the prefetched operands, and its |max|
+    float sv[NS / NTH];
     {
         const float t0 = a.taps[plane * 3 + 0], t1 = a.taps[plane * 3 + 1], t2 = a.taps[plane * 3 + 2];
-        const float* sp = a.v.src + z * a.v.src_sz;
         float amax = 0.f;
+        const int dyv = a.vertical ? 1 : 0, dxv = 1 - dyv;
 #pragma unroll
         for (int k = 0; k < NS / NTH; ++k) {
             const int i = tid + k * NTH;
             const int sy = i / SW, sx = i - sy * SW;
             const int gy = y0 - 8 + sy, gx = x0 - 8 + sx;
-            float v = 0.f;
-            if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
-                const float c = sp[(int64_t)gy * a.v.src_sy + (int64_t)gx * a.v.src_sx];
-                float m = 0.f, p = 0.f;
-                if (a.vertical) {
-                    if (gy > 0) m = sp[(int64_t)(gy - 1) * a.v.src_sy + (int64_t)gx * a.v.src_sx];
-                    if (gy + 1 < h) p = sp[(int64_t)(gy + 1) * a.v.src_sy + (int64_t)gx * a.v.src_sx];
-                } else {
-                    if (gx > 0) m = sp[(int64_t)gy * a.v.src_sy + (int64_t)(gx - 1) * a.v.src_sx];
-                    if (gx + 1 < w) p = sp[(int64_t)gy * a.v.src_sy + (int64_t)(gx + 1) * a.v.src_sx];
-                }
-                v = t0 * m + t1 * c + t2 * p;
-            }
+            const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+            const float m = (gy - dyv >= 0 && gx - dxv >= 0) ? pre.m[k] : 0.f;          // zero padding of the 3-tap filter
+            const float p = (gy + dyv < h && gx + dxv < w) ? pre.p[k] : 0.f;
+            const float v = in ? t0 * m + t1 * pre.c[k] + t2 * p : 0.f;
             S[i] = v;
+            sv[k] = v;
             amax = fmaxf(amax, fabsf(v));
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) RED[wave] = amax;
     }
+    LF_STAMP(1)
     __syncthreads();
+    LF_STAMP(2)
     float s_skip;
     {
         float m = RED[0];
@@ -335,33 +425,69 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         s_skip = pow2_scale(m);
     }
     const float inv1 = (1.f / s_skip) * (1.f / sw1);
-
-    // conv1 operands: this lane's 8 taps (k = 8*kg + j) as offsets into the skip patch
-    int soff[8];
+    {   // the scaled split-fp16 images of the patch (this thread's own three values, still in registers)
+        _Float16* h0 = reinterpret_cast<_Float16*>(lds + LDS_S16);             // copy 0: hi, lo; copy 1: hi, lo
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int t = 8 * kg + j;
-        soff[j] = t < LF_KK ? (t / LF_K) * SW + t % LF_K : 0;
+        for (int k = 0; k < NS / NTH; ++k) {
+            const int i = tid + k * NTH;
+            const float v = sv[k] * s_skip;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            h0[i] = hi;
+            h0[NS16 + i] = lo;
+            if (i > 0) {
+                h0[2 * NS16 + i - 1] = hi;
+                h0[3 * NS16 + i - 1] = lo;
+            }
+        }
+        if (tid < 4 * 49) {                                                   // tails: finite values against zero weights
+            const int arr = tid / 49, j = tid - arr * 49;
+            if (arr >= 2 || j > 0) h0[arr * NS16 + NS - 1 + j] = (_Float16)0.f;
+        }
     }
+    __syncthreads();
+
+    // conv1 operands: element offsets of this lane group's pairs inside the patch (conv1_tile)
+    const uint8_t* s16 = lds + LDS_S16;
+    const int kgoff0 = kg * SW, kgoff1 = 4 * SW + 2 * (kg < 2 ? kg : 2);
     const half8 a1h = *reinterpret_cast<const half8*>(frag + LF_H_C1 + lane * 8);
     const half8 a1l = *reinterpret_cast<const half8*>(frag + LF_H_C1 + 512 + lane * 8);
     float b1v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) b1v[q] = bias[a.b1 + oc0 + q];
 
-    // ---------------- P1: t1 = tanh(conv1(skip) + b1) on 28 x 44
-    for (int tile = wave; tile < ((a.dbg & 1) ? 0 : NT1); tile += NWAVE) {
-        const int p = tile * 16 + pl;
-        const int r = p / R1W, c = p - r * R1W;
-        const floatx4 acc = conv1_tile(S, r * SW + c, soff, s_skip, a1h, a1l);
-        const int gy = y0 - 6 + r, gx = x0 - 6 + c;
-        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-        float v[4];
+    // ---------------- P1: t1 = tanh(conv1(skip) + b1) on 28 x 44.  Two tiles per iteration (independent chains for the
+    // scheduler: one tile alone is a latency chain LDS -> MFMA x3 -> tanh -> split -> store); tiles past the end repeat the
+    // last one (same bytes stored again)
+    if (!(a.dbg & 1)) {
+        constexpr int NIT1 = (NT1 + 2 * NWAVE - 1) / (2 * NWAVE);      // 5
+#pragma unroll 1
+        for (int it = 0; it < NIT1; ++it) {
+            floatx4 acc[2];
+            int pq[2];
+            float msk[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = in ? fast_tanh(acc[q] * inv1 + b1v[q]) * ACT_SCALE : 0.f;
-        timg_store<N1>(lds + LDS_T1, p, oc0, v);
+            for (int t = 0; t < 2; ++t) {
+                const int tile = wave + (2 * it + t) * NWAVE;
+                const int p = (tile < NT1 ? tile : NT1 - 1) * 16 + pl;
+                const int r = p / R1W, c = p - r * R1W;
+                acc[t] = conv1_tile(s16, r * SW + c, kgoff0, kgoff1, a1h, a1l);
+                const int gy = y0 - 6 + r, gx = x0 - 6 + c;
+                msk[t] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? ACT_SCALE : 0.f;
+                pq[t] = p;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fast_tanh(__builtin_fmaf(acc[t][q], inv1, b1v[q])) * msk[t];
+                timg_store<N1>(lds + LDS_T1, pq[t], oc0, v);
+            }
+        }
     }
+    LF_STAMP(3)
     __syncthreads();
+    LF_STAMP(4)
 
     // ---------------- P2: t2 = tanh(conv2(t1) + b2) on 24 x 40
     {
@@ -385,38 +511,51 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             p_out = p;
             return (r * R1W + c) * 16 + halfsel * (N1 * 16);
         };
-        auto epilogue2 = [&](const floatx4& acc, int p) {              // branch-free: one basic block per pipeline stage
+        // the epilogue of a pair (tiles at pixels pp[0], pp[1], accumulators pc[0], pc[1]) in 10 slices: one value per slice
+        // (scale + bias, tanh, mask), then split + store of each tile
+        floatx4 pc[2];
+        int pp[2];
+        float pin[2];                          // ACT_SCALE inside the image, 0 outside (a factor, not a branch)
+        float ev[8];
+        auto in_image = [&](int p) {
             const int r = p / R2W, c = p - r * R2W;
             const int gy = y0 - 4 + r, gx = x0 - 4 + c;
-            const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = in ? fast_tanh(acc[q] * inv2 + bv[q]) * ACT_SCALE : 0.f;
-            timg_store<N2>(lds + LDS_T2, p, oc0, v);
+            return (gy >= 0 && gy < h && gx >= 0 && gx < w) ? ACT_SCALE : 0.f;
+        };
+        auto slice = [&](int ks) {
+            if (ks < 8) {
+                const int t = ks >> 2, q = ks & 3;
+                ev[ks] = fast_tanh(__builtin_fmaf(pc[t][q], inv2, bv[q])) * pin[t];
+            } else if (ks < 10) {
+                const int t = ks - 8;
+                const float v[4] = {ev[4 * t], ev[4 * t + 1], ev[4 * t + 2], ev[4 * t + 3]};
+                timg_store<N2>(lds + LDS_T2, pp[t], oc0, v);
+            }
         };
         if (!(a.dbg & 2)) {
-            floatx4 c0, c1;
-            int p0, p1;
             {
-                const int b0 = tile_base(wave, p0), b1 = tile_base(wave + NWAVE, p1);
-                conv16_tile2<R1W, N1>(lds + LDS_T1, b0, b1, hi_tap, ah, al, c0, c1);
+                const int b0 = tile_base(wave, pp[0]), b1 = tile_base(wave + NWAVE, pp[1]);
+                conv16_tile2<R1W, N1>(lds + LDS_T1, b0, b1, hi_tap, ah, al, pc[0], pc[1], [](int) {});
+                pin[0] = in_image(pp[0]);
+                pin[1] = in_image(pp[1]);
             }
 #pragma unroll
-            for (int it = 0; it < NIT2; ++it) {
-                floatx4 n0 = c0, n1 = c1;
-                int q0 = p0, q1 = p1;
-                if (it + 1 < NIT2) {
-                    const int b0 = tile_base(wave + 16 * (it + 1), q0), b1 = tile_base(wave + 16 * (it + 1) + NWAVE, q1);
-                    conv16_tile2<R1W, N1>(lds + LDS_T1, b0, b1, hi_tap, ah, al, n0, n1);
-                }
-                epilogue2(c0, p0);
-                epilogue2(c1, p1);
-                __builtin_amdgcn_sched_barrier(0);
-                c0 = n0; c1 = n1; p0 = q0; p1 = q1;
+            for (int it = 1; it < NIT2; ++it) {
+                floatx4 n0, n1;
+                int q0, q1;
+                const int b0 = tile_base(wave + 16 * it, q0), b1 = tile_base(wave + 16 * it + NWAVE, q1);
+                conv16_tile2<R1W, N1>(lds + LDS_T1, b0, b1, hi_tap, ah, al, n0, n1, slice);
+                pc[0] = n0; pc[1] = n1; pp[0] = q0; pp[1] = q1;
+                pin[0] = in_image(q0);
+                pin[1] = in_image(q1);
             }
+#pragma unroll
+            for (int ks = 0; ks < 10; ++ks) slice(ks);
         }
     }
+    LF_STAMP(5)
     __syncthreads();
+    LF_STAMP(6)
 
     // ---------------- interior tiles: conv4(conv3(t2) + b3 + r) + b4 through the COMPOSED 9x9 kernels (packed by
     // k_lift_f16_pack): exact algebra wherever the t3 region (20 x 36 around the tile) lies inside the image, because
@@ -430,6 +569,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float* tail = pk + a.f16 + LF_H_END / 2;
         const float swc = tail[4];
         float* D = reinterpret_cast<float*>(lds + LDS_T1);      // T1 is dead after P2
+        float rs = 0.f;
         {
             half8 ah[LF_KSC], al[LF_KSC];
 #pragma unroll
@@ -438,7 +578,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 al[ks] = *reinterpret_cast<const half8*>(frag + LF_H_CC + (ks * 2 + 1) * 512 + lane * 8);
             }
             const uint8_t* img = lds + LDS_T2;
-            for (int tile = wave; tile < NTC; tile += NWAVE) {
+            static_assert(NTC == 5 * NWAVE, "five composite tiles per wave");
+            // (w4 o w1) * skip, 81 fp32 taps on the skip patch for this thread's output pixel: vector work with no MFMA of
+            // its own -- a fifth of it rides in the shadow of each composite tile's 15 MFMAs
+            const int oyc = tid / TW, oxc = tid - oyc * TW;
+            const float* Sc = S + (oyc + 4) * SW + oxc + 4;
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int tile = wave + it * NWAVE;
                 const int p = tile * 16 + pl;
                 const int r = p / R2W, c = p - r * R2W;         // D(r, c) <-> output row r, T2 column c; tap dy -> T2 row r + dy
                 const int basein = (r * R2W + c) * 16 + halfsel * (N2 * 16);
@@ -456,9 +603,21 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // rows = dx: lanes kg 0 hold dx 0-3, kg 1 dx 4-7, kg 2 dx 8 (register 0)
                 if (kg < 2) *reinterpret_cast<floatx4*>(D + p * DP + 4 * kg) = acc;
                 if (kg == 2) D[p * DP + 8] = acc[0];
+#pragma unroll
+                for (int j = 17 * it; j < 17 * it + 17 && j < 81; ++j) rs += tail[32 + j] * Sc[(j / 9) * SW + j % 9];
+#pragma unroll
+                for (int i = 0; i < 15; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
             }
         }
+        LF_STAMP(7)
         __syncthreads();
+        LF_STAMP(8)
+        // operands of the NEXT tile of this workgroup: in flight during the rest of this one (few live registers from here on)
+        if (tile_i + gridDim.x < a.ntiles) fetch(tile_i + gridDim.x, tid, pre);
         {
             const int oy = tid / TW, ox = tid - oy * TW;
             const int gy = y0 + oy, gx = x0 + ox;                // inside the image by the interior condition
@@ -470,18 +629,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float cst = bias[a.b4];
 #pragma unroll
             for (int oc = 0; oc < LF_C; ++oc) cst += (bias[a.b3 + oc] + bias[a.b1 + oc]) * tail[16 + oc];
-            float rs = 0.f;                                       // (w4 o w1) * skip: 81 taps on the skip patch
-#pragma unroll
-            for (int u = 0; u < 9; ++u)
-#pragma unroll
-                for (int v = 0; v < 9; ++v) rs += tail[32 + u * 9 + v] * S[(oy + 4 + u) * SW + ox + 4 + v];
             net += rs + cst;
             const float skip = S[(oy + 8) * SW + ox + 8];
-            const float din = a.v.din[z * a.v.din_sz + (int64_t)gy * a.v.din_sy + (int64_t)gx * a.v.din_sx];
+            const float din = din_pre;
             a.v.dout[z * a.v.dout_sz + (int64_t)gy * a.v.dout_sy + (int64_t)gx * a.v.dout_sx] = din + a.sign * (skip + a.rw * net);
         }
-        return;
-    }
+        LF_STAMP(9)
+        LF_STAMP(15)
+    } else {
 
     // ---------------- P3: t3 = conv3(t2) + b3 + r,  r = conv1(skip) + b1 (recomputed), on 20 x 36; dynamic scale
     constexpr int IT3 = (NT3 + NWAVE - 1) / NWAVE;      // 6
@@ -508,7 +663,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int p = tile * 16 + pl;
                 const int r = p / R3W, c = p - r * R3W;
                 const floatx4 acc = conv16_tile<R2W, N2>(lds + LDS_T2, (r * R2W + c) * 16 + halfsel * (N2 * 16), hi_tap, ah, al);
-                const floatx4 accr = conv1_tile(S, (r + 4) * SW + c + 4, soff, s_skip, a1h, a1l);
+                const floatx4 accr = conv1_tile(s16, (r + 4) * SW + c + 4, kgoff0, kgoff1, a1h, a1l);
                 const int gy = y0 - 2 + r, gx = x0 - 2 + c;
                 const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
 #pragma unroll
@@ -523,6 +678,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) RED[8 + wave] = amax;
     }
+    LF_STAMP(7)
     __syncthreads();            // also: every wave is done reading T1 (P2) -- T3 may now overwrite it
     {
         float m = RED[8];
@@ -541,6 +697,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     __syncthreads();            // T3 complete; every wave is done reading T2 -- D may now overwrite it
+    LF_STAMP(8)
+    if (tile_i + gridDim.x < a.ntiles) fetch(tile_i + gridDim.x, tid, pre);        // the NEXT tile's operands (see the interior path)
 
     // ---------------- P4: D[dx][pixel] = sum over (dy, channel) of t3 * w4 on 16 x 36
     {
@@ -572,7 +730,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (kg == 1) D[p * 8 + 4] = acc[0];
         }
     }
+    LF_STAMP(10)
     __syncthreads();
+    LF_STAMP(11)
 
     // ---------------- P5: net = b4 + sum_dx D[dx][x + dx];  dst_out = dst_in + sign * (skip + rw * net)
     {
@@ -586,11 +746,17 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int dx = 0; dx < LF_K; ++dx) net += D[(oy * RDW + ox + dx) * 8 + dx];
             net = net * inv4 + bias[a.b4];
             const float skip = S[(oy + 8) * SW + ox + 8];
-            const float din = a.v.din[z * a.v.din_sz + (int64_t)gy * a.v.din_sy + (int64_t)gx * a.v.din_sx];
+            const float din = din_pre;
             a.v.dout[z * a.v.dout_sz + (int64_t)gy * a.v.dout_sy + (int64_t)gx * a.v.dout_sx] = din + a.sign * (skip + a.rw * net);
         }
     }
+    LF_STAMP(12)
+    LF_STAMP(15)
+    }                           // border path
+    __syncthreads();            // S, the T / D images and the fp16 skip images are rewritten by the next tile
+    }                           // tile loop
 }
+#undef LF_STAMP
 
 }  // namespace
 
@@ -628,8 +794,28 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
     a.sign = sign; a.rw = rw;
     const char* dbg = getenv("LLDWT_LF_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
-    dim3 grid((unsigned)cdiv(w, TW), (unsigned)cdiv(h, TH), (unsigned)Z);
-    hipLaunchKernelGGL(k_lift_fused_f16, grid, dim3(NTH), LDS_TOTAL, st, a);
+    const char* stp = getenv("LLDWT_LF_STAMPS");
+    a.stamps = stp ? reinterpret_cast<unsigned long long*>(strtoull(stp, nullptr, 0)) : nullptr;
+    auto fits = [&](int64_t sy, int64_t sx) { return llabs(sy) * h + llabs(sx) * w < (int64_t)1 << 31; };
+    if (!fits(v.src_sy, v.src_sx) || !fits(v.din_sy, v.din_sx) || !fits(v.dout_sy, v.dout_sx)) {
+        set_error("lift_f16_step: per-image strides beyond 32-bit offsets");
+        return LLDWT_EINVAL;
+    }
+    a.tiles_x = (int)cdiv(w, TW);
+    a.tiles_y = (int)cdiv(h, TH);
+    a.ntiles = (int64_t)a.tiles_x * a.tiles_y * Z;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) {
+            set_error("lift_f16_step: cannot read the device's CU count");
+            return LLDWT_EHIP;
+        }
+        ncu = prop.multiProcessorCount;
+    }
+    const unsigned grid = (unsigned)(a.ntiles < ncu ? a.ntiles : ncu);      // one resident workgroup per CU
+    hipLaunchKernelGGL(k_lift_fused_f16, dim3(grid), dim3(NTH), LDS_TOTAL, st, a);
     return check_launch("lift_f16_step");
 }
 
