@@ -54,6 +54,8 @@ constexpr int NS16 = NS + 48;                                         // copy 1 
 constexpr int LDS_TOTAL = LDS_S16 + 4 * NS16 * 2;                     // at odd columns); tails zeroed; copy 1 starts 16 banks after
 static_assert((2 * NS16 * 2) % 128 == 64, "even- and odd-column lanes read different banks");   // copy 0.  159,360 B
 constexpr int LDS_T3 = LDS_T1, LDS_D = LDS_T2;
+constexpr int LDS_STG = LDS_T2 + 20480;                               // next tile's operands, 10 floats per thread, inside T2
+static_assert(ND * 8 * 4 <= 20480 && 20480 + 10 * NTH * 4 <= 4 * N2 * 16, "staging fits T2 behind the sequential path's D image");
 static_assert(4 * N3 * 16 <= 4 * N1 * 16 && ND * 8 * 4 <= 4 * N2 * 16, "aliases fit");
 constexpr float ACT_SCALE = 16384.f;                                  // tanh outputs: |t| <= 1 -> |t * 2^14| < fp16 max
 
@@ -181,6 +183,7 @@ struct LfArgs {
     int64_t pstride;
     int orient_fp32;      // float offset of this orientation's fp32 section (biases)
     int b1, b2, b3, b4;   // float offsets of the biases inside an fp32 orientation section
+    int w4;               // float offset of the fp32 conv4 weights [channel][tap] inside an fp32 orientation section
     int f16;              // float offset of this orientation's f16 section
     int batch, h, w, vertical;
     float sign, rw;
@@ -212,6 +215,33 @@ __device__ __forceinline__ floatx4 conv16_tile(const uint8_t* __restrict__ img, 
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// the same with the A fragments streamed from memory (L2) k-step by k-step: for the few strip tiles of a border tile, where
+// holding all 26 fragments in registers is not worth their 104 VGPRs
+template <int WIN, int NIN>
+__device__ __forceinline__ floatx4 conv16_tile_stream(const uint8_t* __restrict__ img, int basein, bool hi_tap,
+                                                      const _Float16* __restrict__ afrag /* + lane * 8 */) {
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    half8 ah[2], al[2];
+    ah[0] = *reinterpret_cast<const half8*>(afrag);
+    al[0] = *reinterpret_cast<const half8*>(afrag + 512);
+#pragma unroll
+    for (int ks = 0; ks < LF_KS; ++ks) {
+        if (ks + 1 < LF_KS) {
+            ah[(ks + 1) & 1] = *reinterpret_cast<const half8*>(afrag + ((ks + 1) * 2 + 0) * 512);
+            al[(ks + 1) & 1] = *reinterpret_cast<const half8*>(afrag + ((ks + 1) * 2 + 1) * 512);
+        }
+        const int ta = 2 * ks, tb = (2 * ks + 1) < LF_KK ? 2 * ks + 1 : LF_KK - 1;
+        const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16, offb = ((tb / LF_K) * WIN + tb % LF_K) * 16;
+        const int off = basein + (hi_tap ? offb : offa);
+        const half8 bh = *reinterpret_cast<const half8*>(img + off);
+        const half8 bl = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + off);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks & 1], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks & 1], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks & 1], bh, acc, 0, 0, 0);
     }
     return acc;
 }
@@ -327,6 +357,7 @@ struct LfPre {
 // PERSISTENT: one workgroup per CU (155 KB of LDS) walks over tiles t = blockIdx.x, + gridDim.x, ...  The position of a
 // tile inside its image is rotated by the image index, so that a workgroup does not meet the (slower) border tiles of
 // every image.
+template <bool SEQ>      // SEQ: the sequential evaluation of conv3 / conv4 for every tile (LLDWT_LF_DBG bit 16), the check of the composed path
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lift_fused_f16(LfArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* S = reinterpret_cast<float*>(lds + LDS_S);
@@ -363,9 +394,24 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int gy = min(y0 + oy_, h - 1), gx = min(x0 + ox_, w - 1);
         pr.din = a.v.din[z * a.v.din_sz + gy * (int)a.v.din_sy + gx * (int)a.v.din_sx];
     };
+    // the fetched operands wait for their tile in LDS (each thread's own ten floats, written and read back by that thread
+    // only: no barrier), not in registers carried around the tile loop (the register file is full in P2)
+    float* STG = reinterpret_cast<float*>(lds + LDS_STG);
+    auto stage = [&](int tid, const LfPre& pr) {
+#pragma unroll
+        for (int k = 0; k < NS / NTH; ++k) {
+            STG[(3 * k + 0) * NTH + tid] = pr.c[k];
+            STG[(3 * k + 1) * NTH + tid] = pr.m[k];
+            STG[(3 * k + 2) * NTH + tid] = pr.p[k];
+        }
+        STG[9 * NTH + tid] = pr.din;
+    };
 
-    LfPre pre;
-    if ((int64_t)blockIdx.x < a.ntiles) fetch(blockIdx.x, tid0, pre);
+    if ((int64_t)blockIdx.x < a.ntiles) {
+        LfPre pr0;
+        fetch(blockIdx.x, tid0, pr0);
+        stage(tid0, pr0);
+    }
     for (int64_t tile_i = blockIdx.x; tile_i < a.ntiles; tile_i += gridDim.x) {
     // every per-lane index below derives from an OPAQUE copy of the thread id: otherwise the compiler hoists all the
     // tile-invariant per-lane address arithmetic of all phases out of the tile loop and spills it
@@ -385,7 +431,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const _Float16* frag = reinterpret_cast<const _Float16*>(pk + a.f16);
     const float* scales = pk + a.f16 + LF_H_END / 2;
     const float sw1 = scales[0], sw2 = scales[1], sw3 = scales[2], sw4 = scales[3];
-    const float din_pre = pre.din;
+    LfPre pre;
+#pragma unroll
+    for (int k = 0; k < NS / NTH; ++k) {
+        pre.c[k] = STG[(3 * k + 0) * NTH + tid];
+        pre.m[k] = STG[(3 * k + 1) * NTH + tid];
+        pre.p[k] = STG[(3 * k + 2) * NTH + tid];
+    }
+    const float din_pre = STG[9 * NTH + tid];
     LF_STAMP(0)
     LF_STAMP(14)
     if (a.stamps && lane == 0)          // slot 13: which CU (XCC_ID << 32 | HW_ID)
@@ -561,14 +614,66 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // k_lift_f16_pack): exact algebra wherever the t3 region (20 x 36 around the tile) lies inside the image, because
     // the only thing between conv3 and conv4 is the zero padding at the image border.  5 k-steps x 3 MFMAs per 16 pixels on
     // 16 x 40 pixels instead of 13 x 3 on 20 x 36 plus conv4, no t3 image, no second pass over conv1.
-    const bool interior = y0 >= 2 && y0 + TH + 2 <= h && x0 >= 2 && x0 + TW + 2 <= w && !(a.dbg & 16);
-    if (interior) {
+    // BORDER tiles take the same path plus a correction: the composed kernel also sums conv4 taps that fall OUTSIDE the
+    // image, where the true t3 is conv4's zero padding but the composition sees t3v = conv3(t2) + b3 + r evaluated there
+    // (t2 and the skip patch are zero outside the image, so t3v is well defined).  Those positions are at most two rows /
+    // columns beyond each image edge: t3v is evaluated on these strips only (<= 14 MFMA tiles instead of the 45 of a full
+    // t3 region), kept in fp32, and  sum_{taps outside} w4 . t3v  is subtracted per output pixel.  LLDWT_LF_DBG bit 16
+    // selects the sequential evaluation (t3 on 20 x 36, conv4, below) for every tile instead: the check of this algebra.
+    const bool interior = y0 >= 2 && y0 + TH + 2 <= h && x0 >= 2 && x0 + TW + 2 <= w;
+    // strips in t3-region coordinates (20 x 36, origin (y0 - 2, x0 - 2)): rows / columns whose image coordinate is
+    // -2, -1 or h, h + 1 (w, w + 1)
+    int nR = 0, nC = 0, Rl[4] = {0, 0, 0, 0}, Cl[4] = {0, 0, 0, 0};
+    if (!SEQ && !interior) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gy = k < 2 ? k - 2 : h + k - 2, gx = k < 2 ? k - 2 : w + k - 2;
+            const int r = gy - (y0 - 2), c = gx - (x0 - 2);
+            if (r >= 0 && r < TH + 4) { Rl[nR == 0 ? 0 : nR == 1 ? 1 : nR == 2 ? 2 : 3] = r; ++nR; }
+            if (c >= 0 && c < TW + 4) { Cl[nC == 0 ? 0 : nC == 1 ? 1 : nC == 2 ? 2 : 3] = c; ++nC; }
+        }
+    }
+    const int nF = nR * R3W + nC * (TH + 4);
+    if constexpr (!SEQ) {
         constexpr int NPC = TH * R2W, NTC = NPC / 16;           // 640 pixels (16 rows x 40 T2 columns), 40 tiles
         constexpr int DP = 12;                                  // floats per pixel in the D image (9 used)
         static_assert(NPC % 16 == 0 && NPC * DP * 4 <= 4 * N1 * 16, "D image fits the T1 region");
         const float* tail = pk + a.f16 + LF_H_END / 2;
         const float swc = tail[4];
         float* D = reinterpret_cast<float*>(lds + LDS_T1);      // T1 is dead after P2
+        float* T3V = D + NPC * DP;                              // [strip position][16 channels] fp32, after the D image
+        float* U = T3V + (4 * R3W + 4 * (TH + 4)) * LF_C;        // [strip position][25 taps]: sum over channels of w4 * t3v
+        float* W4L = U + (4 * R3W + 4 * (TH + 4)) * LF_KK;       // conv4's fp32 weights as [tap][channel]
+        static_assert((NPC * DP + (4 * R3W + 4 * (TH + 4)) * (LF_C + LF_KK) + LF_KK * LF_C) * 4 <= 4 * N1 * 16, "D, t3v, U, w4 fit T1");
+        if (!interior) {                                        // before the composite loop: what it needs from P1 dies here
+            if (tid < LF_C * LF_KK) W4L[(tid % LF_KK) * LF_C + tid / LF_KK] = bias[a.w4 + tid];
+            const half8 c1h = *reinterpret_cast<const half8*>(frag + LF_H_C1 + lane * 8);
+            const half8 c1l = *reinterpret_cast<const half8*>(frag + LF_H_C1 + 512 + lane * 8);
+            float bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = bias[a.b3 + oc0 + q] + bias[a.b1 + oc0 + q];
+            const float inv3 = (1.f / ACT_SCALE) * (1.f / sw3);
+            for (int tile = wave; tile * 16 < nF; tile += NWAVE) {
+                const int j = tile * 16 + pl, jc = j < nF ? j : nF - 1;
+                int r, c;
+                if (jc < nR * R3W) {
+                    const int ir = jc / R3W;
+                    c = jc - ir * R3W;
+                    r = ir == 0 ? Rl[0] : ir == 1 ? Rl[1] : ir == 2 ? Rl[2] : Rl[3];
+                } else {
+                    const int q = jc - nR * R3W, ic = q / (TH + 4);
+                    r = q - ic * (TH + 4);
+                    c = ic == 0 ? Cl[0] : ic == 1 ? Cl[1] : ic == 2 ? Cl[2] : Cl[3];
+                }
+                const floatx4 acc = conv16_tile_stream<R2W, N2>(lds + LDS_T2, (r * R2W + c) * 16 + halfsel * (N2 * 16), hi_tap,
+                                                                frag + LF_H_C3 + lane * 8);
+                const floatx4 accr = conv1_tile(s16, (r + 4) * SW + c + 4, kgoff0, kgoff1, c1h, c1l);
+                floatx4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = acc[q] * inv3 + accr[q] * inv1 + bv[q];
+                if (j < nF) *reinterpret_cast<floatx4*>(T3V + j * LF_C + oc0) = v;
+            }
+        }
         float rs = 0.f;
         {
             half8 ah[LF_KSC], al[LF_KSC];
@@ -616,11 +721,29 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         LF_STAMP(7)
         __syncthreads();
         LF_STAMP(8)
-        // operands of the NEXT tile of this workgroup: in flight during the rest of this one (few live registers from here on)
-        if (tile_i + gridDim.x < a.ntiles) fetch(tile_i + gridDim.x, tid, pre);
+        // operands of the NEXT tile of this workgroup: in flight during the rest of this one, staged in LDS at its end (T2 is
+        // dead from here on)
+        const bool more = tile_i + gridDim.x < a.ntiles;
+        LfPre nxt;
+        if (more) fetch(tile_i + gridDim.x, tid, nxt);
+        if (!interior) {           // U[position][tap] = sum_oc w4[oc][tap] * t3v[position][oc]: dense over (position, tap) items
+            for (int i = tid; i < nF * LF_KK; i += NTH) {
+                const int pos = i / LF_KK, tap = i - pos * LF_KK;
+                const floatx4* tv = reinterpret_cast<const floatx4*>(T3V + pos * LF_C);
+                const floatx4* wv = reinterpret_cast<const floatx4*>(W4L + tap * LF_C);
+                float u = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const floatx4 t = tv[q], ww = wv[q];
+                    u += t[0] * ww[0] + t[1] * ww[1] + t[2] * ww[2] + t[3] * ww[3];
+                }
+                U[i] = u;
+            }
+            __syncthreads();
+        }
         {
             const int oy = tid / TW, ox = tid - oy * TW;
-            const int gy = y0 + oy, gx = x0 + ox;                // inside the image by the interior condition
+            const int gy = y0 + oy, gx = x0 + ox;
             const float invc = (1.f / ACT_SCALE) * (1.f / swc);
             float net = 0.f;
 #pragma unroll
@@ -630,10 +753,36 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int oc = 0; oc < LF_C; ++oc) cst += (bias[a.b3 + oc] + bias[a.b1 + oc]) * tail[16 + oc];
             net += rs + cst;
+            const bool valid = gy < h && gx < w;
+            if (!interior && valid) {          // the conv4 taps of this pixel that land outside the image
+                float corr = 0.f;
+                for (int dy = 0; dy < LF_K; ++dy) {
+                    const int r = oy + dy, gyy = gy - 2 + dy;
+                    if (gyy < 0 || gyy >= h) {
+                        const int ir = r == Rl[0] ? 0 : r == Rl[1] ? 1 : r == Rl[2] ? 2 : 3;
+                        const float* up = U + (ir * R3W + ox) * LF_KK + dy * LF_K;
+#pragma unroll
+                        for (int dx = 0; dx < LF_K; ++dx) corr += up[dx * (LF_KK + 1)];
+                    } else {
+#pragma unroll
+                        for (int dx = 0; dx < LF_K; ++dx) {
+                            const int c = ox + dx, gxx = gx - 2 + dx;
+                            if (gxx < 0 || gxx >= w) {
+                                const int ic = c == Cl[0] ? 0 : c == Cl[1] ? 1 : c == Cl[2] ? 2 : 3;
+                                corr += U[(nR * R3W + ic * (TH + 4) + r) * LF_KK + dy * LF_K + dx];
+                            }
+                        }
+                    }
+                }
+                net -= corr;
+            }
             const float skip = S[(oy + 8) * SW + ox + 8];
             const float din = din_pre;
-            a.v.dout[z * a.v.dout_sz + (int64_t)gy * a.v.dout_sy + (int64_t)gx * a.v.dout_sx] = din + a.sign * (skip + a.rw * net);
+            if (valid)
+                a.v.dout[z * a.v.dout_sz + (int64_t)gy * a.v.dout_sy + (int64_t)gx * a.v.dout_sx] = din + a.sign * (skip + a.rw * net);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage(tid, nxt);
         LF_STAMP(9)
         LF_STAMP(15)
     } else {
@@ -698,7 +847,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();            // T3 complete; every wave is done reading T2 -- D may now overwrite it
     LF_STAMP(8)
-    if (tile_i + gridDim.x < a.ntiles) fetch(tile_i + gridDim.x, tid, pre);        // the NEXT tile's operands (see the interior path)
+    const bool more = tile_i + gridDim.x < a.ntiles;                         // the NEXT tile's operands (see the composed path)
+    LfPre nxt;
+    if (more) fetch(tile_i + gridDim.x, tid, nxt);
 
     // ---------------- P4: D[dx][pixel] = sum over (dy, channel) of t3 * w4 on 16 x 36
     {
@@ -750,9 +901,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             a.v.dout[z * a.v.dout_sz + (int64_t)gy * a.v.dout_sy + (int64_t)gx * a.v.dout_sx] = din + a.sign * (skip + a.rw * net);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stage(tid, nxt);
     LF_STAMP(12)
     LF_STAMP(15)
-    }                           // border path
+    }                           // sequential path
     __syncthreads();            // S, the T / D images and the fp16 skip images are rewritten by the next tile
     }                           // tile loop
 }
@@ -771,7 +924,8 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
                   hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_lift_fused_f16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_lift_fused_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_lift_fused_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) {
             set_error("lift_f16_step: cannot reserve %d bytes of LDS", LDS_TOTAL);
             return LLDWT_EHIP;
         }
@@ -788,7 +942,7 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
     auto pad16 = [](int n) { return (n + 15) & ~15; };
     const int w1o = 0, b1o = w1o + pad16(LF_KK * LF_C), w2o = b1o + pad16(LF_C), b2o = w2o + pad16(LF_C * LF_KK * LF_C);
     const int w3o = b2o + pad16(LF_C), b3o = w3o + pad16(LF_C * LF_KK * LF_C), w4o = b3o + pad16(LF_C), b4o = w4o + pad16(LF_C * LF_KK);
-    a.b1 = b1o; a.b2 = b2o; a.b3 = b3o; a.b4 = b4o;
+    a.b1 = b1o; a.b2 = b2o; a.b3 = b3o; a.b4 = b4o; a.w4 = w4o;
     a.f16 = f16_off + orient * LF_ORIENT_FLOATS;
     a.batch = (int)batch; a.h = (int)h; a.w = (int)w; a.vertical = vertical;
     a.sign = sign; a.rw = rw;
@@ -815,7 +969,8 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
         ncu = prop.multiProcessorCount;
     }
     const unsigned grid = (unsigned)(a.ntiles < ncu ? a.ntiles : ncu);      // one resident workgroup per CU
-    hipLaunchKernelGGL(k_lift_fused_f16, dim3(grid), dim3(NTH), LDS_TOTAL, st, a);
+    if (a.dbg & 16) hipLaunchKernelGGL(k_lift_fused_f16<true>, dim3(grid), dim3(NTH), LDS_TOTAL, st, a);
+    else hipLaunchKernelGGL(k_lift_fused_f16<false>, dim3(grid), dim3(NTH), LDS_TOTAL, st, a);
     return check_launch("lift_f16_step");
 }
 

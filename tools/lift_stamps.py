@@ -63,12 +63,23 @@ def main():
     res["in_kernel_clock_GHz"] = float(np.median(tot[ok] / real[ok]) * 0.1)
     res["wg_duration_us_median"] = float(np.median(real[ok]) / 100.0)
     sb = s[:, ~interior]
-    names_b = ["P0", "P0 barrier", "P1", "P1 barrier", "P2", "P2 barrier", "P3 conv3+conv1", "P3 barrier+store+barrier",
-               None, "P4", "P4 barrier", "P5"]
-    res["border_total_cycles_mean"] = float((sb[..., 12] - sb[..., 0]).mean())
-    db = {"P3 conv3+conv1": sb[..., 7] - sb[..., 6], "t3 scale+store (2 barriers)": sb[..., 8] - sb[..., 7],
-          "P4 conv4": sb[..., 10] - sb[..., 8], "P4 barrier": sb[..., 11] - sb[..., 10], "P5": sb[..., 12] - sb[..., 11]}
-    res["border_mean_cycles_per_wave"] = {k: float(v.mean()) for k, v in db.items()}
+    if os.environ.get("LLDWT_LF_DBG", "0") == "16":          # sequential path for every tile
+        res["border_total_cycles_mean"] = float((sb[..., 12] - sb[..., 0]).mean())
+    else:                                                     # composed path + strip correction: same stamps as interior tiles
+        db = np.diff(sb[..., :10], axis=-1)
+        res["border_mean_cycles_per_wave"] = {n: float(db[..., i].mean()) for i, n in enumerate(names)}
+        res["border_total_cycles_mean"] = float((sb[..., 9] - sb[..., 0]).mean())
+        edge = np.zeros((gy, gx), bool)
+        edge[0, 1:-1] = True
+        se = s[:, edge]
+        res["top_edge_total_cycles_mean"] = float((se[..., 9] - se[..., 0]).mean())
+        res["top_edge_finish"] = float((se[..., 9] - se[..., 8]).mean())
+        edge[:] = False
+        edge[1:-1, 0] = True
+        se = s[:, edge]
+        res["left_edge_total_cycles_mean"] = float((se[..., 9] - se[..., 0]).mean())
+        res["left_edge_finish"] = float((se[..., 9] - se[..., 8]).mean())
+        res["left_edge_PC+strips"] = float((se[..., 7] - se[..., 6]).mean())
     # the span of the launch in real time and the number of workgroups resident at once
     t0, t1 = s[..., 14].min(), s[..., 15].max()
     res["launch_span_us"] = float((t1 - t0) / 100.0)
