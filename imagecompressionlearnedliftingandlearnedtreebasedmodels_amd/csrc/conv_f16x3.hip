@@ -48,7 +48,8 @@ constexpr int F1_HDR = 2048;                    // conv1 pack: [0] s_w1, [1] max
 constexpr int F1_CHUNK_BYTES = 2 * F3_STEP_BYTES;   // 2 k-steps (K = 27 -> 32) x (hi, lo)
 constexpr int F1_NBLK = (F3_NPX + 31) / 32;     // 11 pixel blocks of 32 cover the 340-pixel patch (12 slots: 3 per wave)
 constexpr int F1_COL = 12 * 4 * 1024;           // the split im2col of the parent patch, [block][k-step][hi|lo][lane][8 x fp16]
-constexpr int F1_LDS = F3_LDS + F1_COL;         // 158,016 B
+constexpr int F1_PP = 3 * 6 * 18;               // parent values under a tile (see the kernel)
+constexpr int F1_LDS = F3_LDS + F1_COL + 1536;  // + the parent patch: 159,552 B
 static inline int64_t f1_plane_bytes(int cmid) { return F1_HDR + (int64_t)cdiv(cmid, F3_CK) * F1_CHUNK_BYTES; }
 
 static inline int f3_nch(int cin) { return (int)cdiv(cin, F3_CK); }
@@ -196,7 +197,13 @@ struct F3Args {
     int64_t plane_bytes1;
     int cin, cout, act, batch, h, w, tiles_x, nch;
     int64_t plane_bytes;
+    unsigned long long* stamps;   // diagnostics only (LLDWT_F3_STAMPS = device address): [workgroup][wave][16] s_memtime stamps
 };
+// in-kernel clock stamps of a diagnostic run (tools/plc_stamps.py); a null pointer (always, outside that tool) skips them
+#define F3_STAMP(i)                                                                                                     \
+    if (a.stamps && lane == 0)                                                                                          \
+        a.stamps[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 16 + (i)] =   \
+            (i) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
 
 // IN16 = false: fp32 input, split on the way into LDS, three MFMA products per k-step (fp32-level accuracy).
 // IN16 = true : "fp16 storage" (BASELINE configs[4]): the input tensor lives in HBM as fp16 (half the bytes), it is the hi
@@ -220,6 +227,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int h = a.h, w = a.w;
     const int64_t hw = (int64_t)h * w;
 
+    F3_STAMP(0)
+    F3_STAMP(14)
     // ---- scales (exact powers of two)
     float sx = 1.f;
     if constexpr (IN16) {
@@ -318,30 +327,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int hp = h >> 1, wp_ = w >> 1;
         const float* par = a.parent + z * 3 * (int64_t)hp * wp_;
         const int hh = lane >> 5;
-        float g1[3][2][8];
+        // the parent values under the tile: 3 channels x 6 rows x 18 columns (the 10 x 34 patch and conv1's one-pixel rim,
+        // halved), zero outside the parent image = the zero padding of the upsampled image.  Into LDS once, then every
+        // lane gathers its 48 im2col values from there.
+        float* PP = reinterpret_cast<float*>(lds + F3_LDS + F1_COL);
         float amax = 0.f;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int p = (wave + 4 * b) * 32 + (lane & 31);
-            const bool live = p < F3_NPX;
-            const int pc = live ? p : 0;
-            const int ly = pc / F3_IW, lx = pc - ly * F3_IW;
-            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-            p1[b] = live ? p : -1;
-            pin1[b] = live && gy >= 0 && gy < h && gx >= 0 && gx < w;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * ks + 8 * hh + j;                  // (input channel, tap) = divmod(k, 9), k < 27
-                    const int ci = k >= 18 ? 2 : (k >= 9 ? 1 : 0), tap = k - 9 * ci;
-                    const int dy = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), dx = tap - 3 * dy;
-                    const int Y = gy + dy - 1, X = gx + dx - 1;          // position in the UPSAMPLED image (zero padded)
-                    const bool ok = live && k < 27 && Y >= 0 && Y < h && X >= 0 && X < w;
-                    const float v = ok ? par[(int64_t)ci * hp * wp_ + (Y >> 1) * wp_ + (X >> 1)] : 0.f;
-                    g1[b][ks][j] = v;
-                    amax = fmaxf(amax, fabsf(v));
-                }
+        for (int i = tid; i < F1_PP; i += 256) {
+            const int ci = i / 108, rem = i - ci * 108, r = rem / 18, c = rem - r * 18;
+            const int Yp = (y0 >> 1) - 1 + r, Xp = (x0 >> 1) - 1 + c;
+            const bool in = Yp >= 0 && Yp < hp && Xp >= 0 && Xp < wp_;
+            const float v = par[(int64_t)ci * hp * wp_ + min(max(Yp, 0), hp - 1) * wp_ + min(max(Xp, 0), wp_ - 1)];
+            const float vz = in ? v : 0.f;
+            PP[i] = vz;
+            amax = fmaxf(amax, fabsf(vz));
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
@@ -354,17 +353,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         out_scale = (1.f / sx) * (1.f / sw);
         inv1 = (1.f / s_p) * (1.f / h1[0]);
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+        for (int b = 0; b < 3; ++b) {
+            const int p = (wave + 4 * b) * 32 + (lane & 31);
+            const bool live = p < F3_NPX;
+            const int pc = live ? p : 0;
+            const int ly = pc / F3_IW, lx = pc - ly * F3_IW;
+            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+            p1[b] = live ? p : -1;
+            pin1[b] = live && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            // PP index of tap (dy, dx) of channel ci for this pixel: ci * 108 + ((ly + dy) >> 1) * 18 + ((lx + dx) >> 1)
+            int ro[3], co[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                ro[d] = ((ly + d) >> 1) * 18;
+                co[d] = (lx + d) >> 1;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 float v8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v8[j] = g1[b][ks][j] * s_p;
+                for (int j = 0; j < 8; ++j) {
+                    // k = 16 ks + 8 hh + j -> (channel, dy, dx) = (k / 9, (k % 9) / 3, k % 3); k >= 27 meets zero weights
+                    const int k0 = 16 * ks + j, k1 = k0 + 8;
+                    const int q0 = k0 < 27 ? k0 : 26, q1 = k1 < 27 ? k1 : 26;
+                    const int i0 = (q0 / 9) * 108 + ro[(q0 % 9) / 3] + co[q0 % 3];
+                    const int i1 = (q1 / 9) * 108 + ro[(q1 % 9) / 3] + co[q1 % 3];
+                    v8[j] = PP[hh ? i1 : i0] * s_p;
+                }
                 half8 ch_, cl_;
                 split8v(v8, ch_, cl_);
                 *reinterpret_cast<half8*>(col1 + (((wave + 4 * b) * 2 + ks) * 2 + 0) * 1024) = ch_;
                 *reinterpret_cast<half8*>(col1 + (((wave + 4 * b) * 2 + ks) * 2 + 1) * 1024) = cl_;
             }
+        }
     }
     // conv1 operands of the chunk being staged: weight fragments (2 k-steps x hi, lo) and the 16 bias values of this lane's
     // rows -- the same for the wave's three pixel blocks, loaded once per chunk a few units ahead of their first use
@@ -443,7 +464,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ah[i] = *reinterpret_cast<const half8*>(wbase + i * F3_STEP_BYTES);
         al[i] = *reinterpret_cast<const half8*>(wbase + i * F3_STEP_BYTES + 1024);
     }
+    F3_STAMP(1)
     for (int chunk = 0; chunk < a.nch; ++chunk) {
+        if (chunk < 8) F3_STAMP(2 + chunk)
         const int buf = chunk & 1;
         const uint8_t* wp = wbase + (int64_t)chunk * F3_CHUNK_BYTES;
         const uint8_t* bb = lds + buf * F3_BUF + boff;
@@ -505,21 +528,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef F3_FUSED_BLOCK
 #undef F3_FUSED_LOAD
 
-    // ---- epilogue: D col = lane&31 (pixel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (channel of the wave's 32)
-    const int gx = x0 + (lane & 31);
+    F3_STAMP(10)
+    // ---- epilogue: D col = lane&31 (pixel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (channel of the wave's 32).
+    // 128 stores per lane: a wave-uniform base (scalar registers) + one per-lane offset, the activation resolved outside
+    // the loops, no per-element address arithmetic (the first version of this epilogue took a fifth of the kernel's time)
+    {
+        const int gx = x0 + (lane & 31);
+        const int ocw = ocb * F3_OCB + __builtin_amdgcn_readfirstlane(wave) * 32;       // first channel of this wave
+        const int och = 4 * (lane >> 5);
+        float* ybase = a.y + (z * a.cout + ocw) * hw + (int64_t)y0 * w;                  // wave-uniform
+        const unsigned loff = (unsigned)och * (unsigned)hw + (unsigned)gx;              // this lane's element offset
+        float bq[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int oc = ocb * F3_OCB + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (oc >= a.cout) continue;
-        const float bv = a.bias ? a.bias[plane * a.cout + oc] : 0.f;
-        float* yp = a.y + (z * a.cout + oc) * hw;
+        for (int q = 0; q < 16; ++q) {
+            const int oc = ocw + (q & 3) + 8 * (q >> 2) + och;
+            bq[q] = a.bias ? a.bias[plane * a.cout + (oc < a.cout ? oc : a.cout - 1)] : 0.f;
+        }
+        const bool full = y0 + F3_TH <= h && x0 + F3_TW <= w;                            // uniform
+        if (full && a.act != LLDWT_ACT_TANH) {
+            const float slope = a.act == LLDWT_ACT_LRELU ? 0.01f : 1.f;                  // none: max(v, v)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int gy = y0 + n;
-            if (gy < h && gx < w) yp[(int64_t)gy * w + gx] = act_apply(acc[n][q] * out_scale + bv, a.act);
+            for (int q = 0; q < 16; ++q) {
+                if (ocw + (q & 3) + 8 * (q >> 2) + och < a.cout) {
+                    float* yq = ybase + (int64_t)((q & 3) + 8 * (q >> 2)) * hw;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        const float v = acc[n][q] * out_scale + bq[q];
+                        yq[n * w + loff] = fmaxf(v, v * slope);
+                    }
+                }
+            }
+        } else if (full) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (ocw + (q & 3) + 8 * (q >> 2) + och < a.cout) {
+                    float* yq = ybase + (int64_t)((q & 3) + 8 * (q >> 2)) * hw;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) yq[n * w + loff] = fast_tanh(acc[n][q] * out_scale + bq[q]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (ocw + (q & 3) + 8 * (q >> 2) + och < a.cout) {
+                    float* yq = ybase + (int64_t)((q & 3) + 8 * (q >> 2)) * hw;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+                        if (y0 + n < h && gx < w) yq[n * w + loff] = act_apply(acc[n][q] * out_scale + bq[q], a.act);
+                }
+            }
         }
     }
+    F3_STAMP(11)
+    F3_STAMP(15)
 }
+#undef F3_STAMP
 
 }  // namespace lldwt
 using namespace lldwt;
@@ -568,7 +631,7 @@ extern "C" int lldwt_conv3x3_f16x3(const float* x, float* y, const void* packed,
     LLDWT_REQUIRE((int64_t)F3_CK * h * w_ * 4 < (int64_t)1 << 32, "conv3x3_f16x3: image too large for 32-bit chunk offsets");
     F3Args a;
     a.x = x; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed); a.bias = bias; a.slots = slots;
-    a.x16 = nullptr; a.xscale = nullptr; a.parent = nullptr; a.packed1 = nullptr; a.plane_bytes1 = 0;
+    a.x16 = nullptr; a.xscale = nullptr; a.parent = nullptr; a.packed1 = nullptr; a.plane_bytes1 = 0; a.stamps = nullptr;
     a.cin = cin; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
     a.tiles_x = (int)cdiv(w_, F3_TW);
     a.nch = f3_nch(cin);
@@ -601,7 +664,7 @@ extern "C" int lldwt_conv3x3_f16in(const void* x16, float* y, const void* packed
     F3Args a;
     a.x = nullptr; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed); a.bias = bias; a.slots = nullptr;
     a.x16 = reinterpret_cast<const _Float16*>(x16); a.xscale = xscale;
-    a.parent = nullptr; a.packed1 = nullptr; a.plane_bytes1 = 0;
+    a.parent = nullptr; a.packed1 = nullptr; a.plane_bytes1 = 0; a.stamps = nullptr;
     a.cin = cin; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
     a.tiles_x = (int)cdiv(w_, F3_TW);
     a.nch = f3_nch(cin);
@@ -644,6 +707,10 @@ extern "C" int lldwt_plc_fused(const float* parent, float* y, const void* packed
     a.parent = parent; a.packed1 = reinterpret_cast<const uint8_t*>(packed1); a.plane_bytes1 = f1_plane_bytes(cmid);
     a.cin = cmid; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
     a.tiles_x = (int)cdiv(w_, F3_TW);
+    {
+        const char* stp = getenv("LLDWT_F3_STAMPS");
+        a.stamps = stp ? reinterpret_cast<unsigned long long*>(strtoull(stp, nullptr, 0)) : nullptr;
+    }
     a.nch = f3_nch(cmid);
     a.plane_bytes = f3_plane_bytes(cmid, cout);
     const int tiles_y = (int)cdiv(h, F3_TH);
