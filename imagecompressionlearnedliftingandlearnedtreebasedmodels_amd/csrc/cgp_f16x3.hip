@@ -145,17 +145,22 @@ struct Cgp16Args {
     int cols;              // 64-pixel columns per image
 };
 
-// bias + LeakyReLU + rescale + split of one D tile into the two B fragments (k-steps 0 and 1) of the next layer
-__device__ __forceinline__ void next_frags(const floatx16& acc, float inv, const float* __restrict__ bias, int h, float snext,
-                                           half8 (&bh)[2], half8 (&bl)[2]) {
+// bias + LeakyReLU + rescale + split of one D tile into the two B fragments (k-steps 0 and 1) of the next layer.
+// The next layer's power-of-two scale commutes with LeakyReLU, so it is folded into the dequantisation factor and into the
+// bias (bsc = bias * snext, prepared once per tile for both pixel blocks): per value one FMA, LeakyReLU as max(t, 0.01 t),
+// then the split.
+__device__ __forceinline__ void load_bias_scaled(const float* __restrict__ bias, int h, float snext, float (&bsc)[16]) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bsc[q] = bias[drow(q, h)] * snext;
+}
+__device__ __forceinline__ void next_frags(const floatx16& acc, float k, const float (&bsc)[16], half8 (&bh)[2], half8 (&bl)[2]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float t = acc[8 * s + j] * inv + bias[drow(8 * s + j, h)];
-            t = t >= 0.f ? t : 0.01f * t;
-            v[j] = t * snext;
+            const float t = __builtin_fmaf(acc[8 * s + j], k, bsc[8 * s + j]);
+            v[j] = fmaxf(t, 0.01f * t);
         }
         split8v(v, bh[s], bl[s]);
     }
@@ -283,8 +288,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             ++step;
         }
         half8 b1h[NB][2], b1l[NB][2];
+        {
+            float bsc[16];
+            load_bias_scaled(bias0 + 32 * m0, h5, s1, bsc);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) next_frags(acc0[nb], inv0, bias0 + 32 * m0, h5, s1, b1h[nb], b1l[nb]);
+            for (int nb = 0; nb < NB; ++nb) next_frags(acc0[nb], inv0 * s1, bsc, b1h[nb], b1l[nb]);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -304,8 +313,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int m1 = 0; m1 < NM1; ++m1) {
         half8 b2h[NB][2], b2l[NB][2];
+        {
+            float bsc[16];
+            load_bias_scaled(bias1 + 32 * m1, h5, s2, bsc);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) next_frags(acc1[nb][m1], inv1, bias1 + 32 * m1, h5, s2, b2h[nb], b2l[nb]);
+            for (int nb = 0; nb < NB; ++nb) next_frags(acc1[nb][m1], inv1 * s2, bsc, b2h[nb], b2l[nb]);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             CGP16_NEXT()
@@ -322,8 +335,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         for (int q = 0; q < 16; ++q) acc3[nb][q] = 0.f;
     {
         half8 b3h[NB][2], b3l[NB][2];
+        {
+            float bsc[16];
+            load_bias_scaled(bias2, h5, s3, bsc);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) next_frags(acc2[nb], inv2, bias2, h5, s3, b3h[nb], b3l[nb]);
+            for (int nb = 0; nb < NB; ++nb) next_frags(acc2[nb], inv2 * s3, bsc, b3h[nb], b3l[nb]);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             CGP16_NEXT()

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     uint8_t* col1 = lds + F3_LDS + lane * 16;     // each lane writes and reads only its own 16-byte slots: no barrier needed
     int p1[3];
     bool pin1[3];
-    float inv1 = 1.f;
+    float inv1 = 1.f, inv1sx = 1.f;
     const uint8_t* pk1 = nullptr;
     const float* bias1 = nullptr;
     if constexpr (FUSED) {
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         sx = pow2_scale_for(amax * h1[1] + h1[2]);                           // bound on |LeakyReLU(conv1)|: max|parent| * L1max + |b|max
         out_scale = (1.f / sx) * (1.f / sw);
         inv1 = (1.f / s_p) * (1.f / h1[0]);
+        inv1sx = inv1 * sx;
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             const int p = (wave + 4 * b) * 32 + (lane & 31);
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             w1l[ks] = *reinterpret_cast<const half8*>(w1_ + ks * F3_STEP_BYTES + 1024);                               \
         }                                                                                                             \
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                              \
-            b1v[gq] = *reinterpret_cast<const floatx4*>(bias1 + (C1) + 8 * gq + 4 * (lane >> 5));                     \
+            b1v[gq] = *reinterpret_cast<const floatx4*>(bias1 + (C1) + 8 * gq + 4 * (lane >> 5)) * sx;                \
     }
     // channels C1 .. C1+31 of the first conv for pixel block B of this wave -> split -> the LDS image at DST
 #define F3_FUSED_BLOCK(B, DST)                                                                                        \
@@ -422,9 +423,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                            \
             float v4_[4];                                                                                             \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
-                float v_ = t_[4 * gq + i] * inv1 + b1v[gq][i];                                                        \
-                v_ = v_ >= 0.f ? v_ : 0.01f * v_;                                                                     \
-                v4_[i] = pin1[B] ? v_ * sx : 0.f;                                                                     \
+                const float v_ = __builtin_fmaf(t_[4 * gq + i], inv1sx, b1v[gq][i]);   /* sx (2^k) folded in */       \
+                v4_[i] = pin1[B] ? fmaxf(v_, 0.01f * v_) : 0.f;                                                       \
             }                                                                                                         \
             half4_ hi_, lo_;                                                                                          \
             split4v(v4_, hi_, lo_);                                                                                   \

@@ -1,6 +1,6 @@
 // split_f16.h -- fp32 -> (hi, lo) fp16 pairs for the split-fp16 MFMA kernels: hi = fp16(v), lo = fp16(v - hi), both
-// round-to-nearest, |v - hi - lo| <= 2^-22 |v| while lo stays normal.  Written on 2-element vectors so that hipcc emits
-// v_cvt_pk_f16_f32 (one instruction per pair, gfx950): 2.5 vector instructions per element instead of ~5.
+// round-to-nearest, |v - hi - lo| <= 2^-22 |v| while lo stays normal.  hi on 2-element vectors so that hipcc emits
+// v_cvt_pk_f16_f32 (one instruction per pair, gfx950).
 #pragma once
 #include "common.h"
 
@@ -11,11 +11,19 @@ typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
+// lo through v_fma_mixlo_f16 / v_fma_mixhi_f16: D.f16 = round(v * 1.0 - hi) with v read as fp32 and hi as the fp16 half it
+// already is (op_sel_hi / op_sel), one instruction per element and no fp16 -> fp32 conversion: 1.5 vector instructions per
+// element.  v - hi is exact in fp32 (|v - hi| <= ulp_f16(v) / 2, a multiple of ulp_f32(v)), so the single rounding to fp16
+// gives the same bits as (half)(v - (float)hi); tools/check_split.hip compares the two on 2^21 values.  The compiler does not
+// select these instructions from C (it folds the fused form back into a subtraction), hence the inline assembly.
 __device__ __forceinline__ void split2(float a, float b, h2_t& hi, h2_t& lo) {
     const f2_t v = {a, b};
     hi = __builtin_convertvector(v, h2_t);
-    const f2_t r = v - __builtin_convertvector(hi, f2_t);
-    lo = __builtin_convertvector(r, h2_t);
+    const unsigned hu = __builtin_bit_cast(unsigned, hi);
+    unsigned lu;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lu) : "v"(a), "v"(hu));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lu) : "v"(b), "v"(hu));
+    lo = __builtin_bit_cast(h2_t, lu);
 }
 
 __device__ __forceinline__ void split4v(const float (&v)[4], h4_t& hi, h4_t& lo) {
