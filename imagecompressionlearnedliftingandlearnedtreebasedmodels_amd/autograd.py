@@ -287,7 +287,8 @@ def _pack_forward(W, nblocks):
     """W: dict of 8 stacked tensors (nblocks,2,P,...) -> packed (P,nblocks,2,total) for the lifting step kernels."""
     blocks = []
     for b in range(nblocks):
-        pu = [ops.pack_pblock(*[W[k][b, u] for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")]) for u in range(2)]
+        pu = [ops.pack_pblock(*[W[k][b, u] for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")], train=True)
+              for u in range(2)]     # training kernels only: no split-fp16 section (re-packed every step)
         blocks.append(torch.stack(pu, 1))
     return torch.stack(blocks, 1).contiguous()
 

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         const bool full = y0 + F3_TH <= h && x0 + F3_TW <= w;                            // uniform
         if (full && a.act != LLDWT_ACT_TANH) {
-            const float slope = a.act == LLDWT_ACT_LRELU ? 0.01f : 1.f;                  // none: max(v, v)
+            const float slope = a.act == LLDWT_ACT_LRELU ? 0.01f : (a.act == LLDWT_ACT_RELU ? 0.f : 1.f);   // none: max(v, v)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 if (ocw + (q & 3) + 8 * (q >> 2) + och < a.cout) {
@@ -627,7 +627,7 @@ extern "C" int lldwt_conv3x3_f16x3(const float* x, float* y, const void* packed,
     LLDWT_REQUIRE(x && y && packed && slots, "conv3x3_f16x3: null pointer");
     LLDWT_REQUIRE(cin > 0 && cout > 0 && planes > 0 && batch > 0 && h > 0 && w_ > 0 && planes * batch <= 65535,
                   "conv3x3_f16x3: bad dims");
-    LLDWT_REQUIRE(act == LLDWT_ACT_NONE || act == LLDWT_ACT_LRELU || act == LLDWT_ACT_TANH, "conv3x3_f16x3: bad activation");
+    LLDWT_REQUIRE(act == LLDWT_ACT_NONE || act == LLDWT_ACT_LRELU || act == LLDWT_ACT_TANH || act == LLDWT_ACT_RELU, "conv3x3_f16x3: bad activation");
     LLDWT_REQUIRE((int64_t)F3_CK * h * w_ * 4 < (int64_t)1 << 32, "conv3x3_f16x3: image too large for 32-bit chunk offsets");
     F3Args a;
     a.x = x; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed); a.bias = bias; a.slots = slots;
@@ -659,7 +659,7 @@ extern "C" int lldwt_conv3x3_f16in(const void* x16, float* y, const void* packed
     LLDWT_REQUIRE(x16 && y && packed && xscale, "conv3x3_f16in: null pointer");
     LLDWT_REQUIRE(cin > 0 && cout > 0 && planes > 0 && batch > 0 && h > 0 && w_ > 0 && planes * batch <= 65535,
                   "conv3x3_f16in: bad dims");
-    LLDWT_REQUIRE(act == LLDWT_ACT_NONE || act == LLDWT_ACT_LRELU || act == LLDWT_ACT_TANH, "conv3x3_f16in: bad activation");
+    LLDWT_REQUIRE(act == LLDWT_ACT_NONE || act == LLDWT_ACT_LRELU || act == LLDWT_ACT_TANH || act == LLDWT_ACT_RELU, "conv3x3_f16in: bad activation");
     LLDWT_REQUIRE((int64_t)F3_CK * h * w_ * 2 < (int64_t)1 << 32, "conv3x3_f16in: image too large for 32-bit chunk offsets");
     F3Args a;
     a.x = nullptr; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed); a.bias = bias; a.slots = nullptr;
@@ -700,7 +700,7 @@ extern "C" int lldwt_plc_fused(const float* parent, float* y, const void* packed
     LLDWT_REQUIRE(cmid > 0 && cmid <= 256 && cout > 0 && planes > 0 && batch > 0 && h > 0 && w_ > 0 && planes * batch <= 65535,
                   "plc_fused: bad dims");
     LLDWT_REQUIRE(h % 2 == 0 && w_ % 2 == 0, "plc_fused: the output is the 2x-upsampled parent's size: even h, w");
-    LLDWT_REQUIRE(act == LLDWT_ACT_NONE || act == LLDWT_ACT_LRELU || act == LLDWT_ACT_TANH, "plc_fused: bad activation");
+    LLDWT_REQUIRE(act == LLDWT_ACT_NONE || act == LLDWT_ACT_LRELU || act == LLDWT_ACT_TANH || act == LLDWT_ACT_RELU, "plc_fused: bad activation");
     F3Args a;
     a.x = nullptr; a.y = y; a.packed = reinterpret_cast<const uint8_t*>(packed2); a.bias = bias2; a.slots = nullptr;
     a.x16 = nullptr; a.xscale = nullptr;

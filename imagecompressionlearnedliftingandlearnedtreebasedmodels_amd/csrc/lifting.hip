@@ -1430,16 +1430,32 @@ extern "C" int lldwt_set_lift_mode(int mode) {
 }
 extern "C" int lldwt_get_lift_mode(void) { return g_lift_mode; }
 
+static int pack_pblock_impl(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                            const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
+                            bool with_f16, void* stream);
+
 extern "C" int lldwt_pack_pblock(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                  const float* b3, const float* w4, const float* b4, float* packed, int planes, int C,
                                  int K, void* stream) {
+    return pack_pblock_impl(w1, b1, w2, b2, w3, b3, w4, b4, packed, planes, C, K, true, stream);
+}
+
+extern "C" int lldwt_pack_pblock_train(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                       const float* b3, const float* w4, const float* b4, float* packed, int planes, int C,
+                                       int K, void* stream) {
+    return pack_pblock_impl(w1, b1, w2, b2, w3, b3, w4, b4, packed, planes, C, K, false, stream);
+}
+
+static int pack_pblock_impl(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                            const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
+                            bool with_f16, void* stream) {
     LLDWT_REQUIRE(planes > 0 && C > 0 && (K == 3 || K == 5), "pack_pblock: bad planes/C/K (%d,%d,%d)", planes, C, K);
     LLDWT_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && w4 && b4 && packed, "pack_pblock: null pointer");
     const PackOff o = pack_off(C, K);
     dim3 grid((unsigned)cdiv(o.total, 256), (unsigned)planes);
     hipLaunchKernelGGL(k_pack_pblock, grid, dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3, w4, b4, packed, C,
                        K);
-    if (lift_f16_floats(C, K) > 0) {
+    if (with_f16 && lift_f16_floats(C, K) > 0) {
         int r = lift_f16_pack(w1, w2, w3, w4, packed, o.total, o.f16, planes, (hipStream_t)stream);
         if (r) return r;
     }

@@ -83,6 +83,12 @@ int lldwt_get_lift_mode(void);
 int lldwt_pack_pblock(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                       const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
                       void* stream);
+/* The same buffer WITHOUT its split-fp16 section (left unwritten): for the training step, which re-packs the changed
+ * weights every iteration and only runs the fp32 kernels that save their intermediates.  A buffer packed this way must
+ * not be handed to the eval path (lldwt_lift_step with lift mode 1 reads the split-fp16 section).                     */
+int lldwt_pack_pblock_train(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                            const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
+                            void* stream);
 
 /* One lifting step (wavelet_forward_v2.py:60-62 and the three like it; inverse wavelet_inverse_v2.py:76-90):
  *     skip = conv3x1(src, taps)            zero padded, along rows if vertical else along columns

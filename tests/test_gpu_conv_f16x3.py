@@ -16,6 +16,8 @@ def _ref64(x, w, b, act):
     y = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     if act == 2:
         y = F.leaky_relu(y, 0.01)
+    if act == 3:
+        y = F.relu(y)
     return y
 
 
@@ -36,7 +38,7 @@ def test_operand_maps_exact_on_integers():
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 243, 243, 64, 96, 0), (2, 1, 243, 243, 40, 33, 2), (1, 1, 96, 192, 24, 70, 0),
-                                   (1, 1, 64, 64, 8, 32, 2)])
+                                   (1, 1, 64, 64, 8, 32, 2), (1, 2, 64, 64, 12, 40, 3)])
 def test_accuracy_is_fp32_level(shape):
     """Relative error vs a float64 reference is at the fp32 engine's level (~1e-6 of the output scale): the split keeps
     22 bits per operand.  Also: the result does not depend on the input's overall scale (power-of-two scaling)."""
