@@ -307,7 +307,11 @@ def main():
     import imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net as M
     import imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.layers.lifting_dwt_nets as LN
 
-    def timed(fn, work_of):
+    dom2 = {"events": [], "work": 0.0}                       # the second kernel family of the step (lifting, when plc leads)
+
+    def timed(fn, work_of, acc=None):
+        acc = dom if acc is None else acc
+
         def wrapper(*args, **kw):
             w = work_of(*args, **kw) if dom["on"] else None
             if not w:
@@ -316,8 +320,8 @@ def main():
             e0.record()
             out = fn(*args, **kw)
             e1.record()
-            dom["events"].append((e0, e1))
-            dom["work"] += w
+            acc["events"].append((e0, e1))
+            acc["work"] += w
             return out
         return wrapper
     if has_plc:
@@ -341,6 +345,15 @@ def main():
         ops.plc_fused = timed(ops.plc_fused, fused_work)
         roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS,
                 "kernel": "plc conv 243->243 3x3 (tree context model; the largest share of the step's FLOPs)"}
+        if lifting:                                          # the other large kernel family: reported beside the dominant one
+            mac2 = {3: 71416, 4: 72266}.get(c["levels"], 72266)
+
+            def lift_work2(x_, *args, **kw):
+                P, B, _, H, W = x_.shape
+                return 2.0 * mac2 * P * B * H * W
+            wrapped2 = timed(ops.lifting_forward, lift_work2, dom2)
+            ops.lifting_forward = wrapped2
+            LN.ops.lifting_forward = wrapped2
     elif lifting:
         # whole learned-lifting forward (all levels, the k_lift_* launches): SURVEY 8d MAC / plane-pixel x 2
         mac = {3: 71416, 4: 72266}.get(c["levels"], 72266)
@@ -456,6 +469,20 @@ def main():
                    "backend": parallel.backend_name(), "world_size_seen": world_seen},
         "roofline": roof,
     }
+    if dom2["events"]:
+        ms2 = sum(e0.elapsed_time(e1) for e0, e1 in dom2["events"])
+        tf2 = dom2["work"] / (ms2 * 1e-3) / 1e12
+        from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import _lib as _L2
+        f16l = _L2.load().lldwt_get_lift_mode() == 1
+        out["roofline_lifting"] = {
+            "bound": "mfma", "unit": "TFLOP/s",
+            "kernel": "learned lifting forward, %d levels (one lldwt_lifting_forward call per step: %s)" % (
+                c["levels"], "48 persistent k_lift_fused_f16 launches, split-fp16" if f16l else "fp32 MFMA launches"),
+            "ms_per_step": ms2 / len(dom2["events"]), "calls": len(dom2["events"]),
+            "fp32_equivalent_tflops": tf2, "frac_of_fp32_mfma_peak": tf2 / F32_MFMA_PEAK_TFLOPS,
+            "achieved": (3.0 if f16l else 1.0) * tf2, "peak": F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS,
+            "frac": (3.0 if f16l else 1.0) * tf2 / (F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS),
+            "note": "algorithmic MACs of the transform (SURVEY 8d), halo recomputation not counted; 3 fp16 products per MAC"}
     if a.train_steps > 0:
         try:
             out["train"] = train_leg(a, c, dev, rank, world_seen, x)
