@@ -134,3 +134,32 @@ def test_bad_arguments_fail_loudly():
         ops.lifting_forward(x, taps, packed, 3, 16, 5, 0.1)      # 20 not divisible by 8
     with pytest.raises(LLDWTError):
         ops.lifting_forward(x.cpu(), taps, packed, 2, 16, 5, 0.1)  # host tensor
+
+
+@pytest.mark.parametrize("hw", [(16, 32), (33, 70), (8, 12), (100, 200)])
+@pytest.mark.parametrize("vertical", [1, 0])
+def test_composed_path_with_strip_correction_equals_sequential(hw, vertical, monkeypatch):
+    """The fused lifting step evaluates conv4(conv3(.)) through the composed 9x9 kernel for EVERY tile; border tiles
+    subtract the conv4 taps that fall outside the image (t3v on the <= 2-pixel frame).  LLDWT_LF_DBG=16 runs the
+    sequential evaluation (t3 on the halo region, then conv4) for every tile instead: both must agree to fp32 rounding on
+    single-tile images (all four edges in one tile), ragged multi-tile images, and images smaller than a tile."""
+    ops, gu = _ops()
+    cfg = dict(model.DEFAULT_CFG, filtersize=5, dwtlevels=1)
+    sds = [filled(weights.autoencoder_template(cfg), "m%d." % p) for p in range(2)]
+    g = torch.Generator().manual_seed(11)
+    P, B, (h, w) = 2, 3, hw
+    src = torch.rand(P, B, 1, h, w, generator=g) - 0.5
+    dst = torch.rand(P, B, 1, h, w, generator=g) - 0.5
+    taps, packed = gu.lifting_params(sds)
+    src_d, dst_d = gu.dev(src), gu.dev(dst)
+    Z = P * B
+    v = lambda t: ops.view_of(t, Z, h, w)
+    outs = []
+    for dbg in ("0", "16"):
+        monkeypatch.setenv("LLDWT_LF_DBG", dbg)
+        out_d = torch.empty_like(dst_d)
+        ops.lift_step(v(src_d), v(dst_d), v(out_d), Z, B, h, w, taps[0].contiguous(), packed[:, 0, 0].contiguous(), 16, 5,
+                      vertical, -1.0, 0.1)
+        outs.append(out_d.cpu())
+    monkeypatch.setenv("LLDWT_LF_DBG", "0")
+    assert maxdiff(outs[0], outs[1]) < 2e-6, (hw, vertical)
