@@ -20,7 +20,7 @@ class ConvFn(torch.autograd.Function):
     def _f16x3(x, w, K, groups, upsample2, tap_mask, residual):
         """Dense 3x3 convs with many channels (the 243 -> 243 tree conv) run on the fp16 matrix cores with split-fp16
         operands in training too -- forward and backward-data (same kernel, transposed + flipped weights); fp32-level
-        accuracy (csrc/conv_f16x3.hip).  The weight gradient stays on the fp32 MFMA kernel."""
+        accuracy (csrc/conv_f16x3.hip); the weight gradient likewise (csrc/conv_wgrad_f16x3.hip, rows that are multiples of 4)."""
         return (K == 3 and groups == 1 and not upsample2 and tap_mask is None and residual is None and w.shape[1] >= 64 and
                 w.shape[2] >= 64 and ops.plc_mode() == "f16x3")
 
@@ -52,8 +52,11 @@ class ConvFn(torch.autograd.Function):
             if upsample2:
                 dx = ops.downsum2(dx)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
-            dw, db = ops.conv2d_wgrad(x, dpre, tuple(w.shape), K, groups=groups, upsample2=upsample2, tap_mask=tap_mask,
-                                      want_bias=has_b)
+            if ctx.fast and x.shape[-1] % 4 == 0:
+                dw, db = ops.conv3x3_wgrad_f16x3(x, dpre, tuple(w.shape), want_bias=has_b)     # split-fp16 matrix cores
+            else:
+                dw, db = ops.conv2d_wgrad(x, dpre, tuple(w.shape), K, groups=groups, upsample2=upsample2, tap_mask=tap_mask,
+                                          want_bias=has_b)
         return dx, dw, db, (dpre if has_res else None), None, None, None, None, None
 
 

@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable"
 mkdir -p "$HERE/obj"
 pids=()
-for f in ops lifting lifting_f16 cdf97 conv_mfma conv_f16x3 cgp_fused cgp_f16x3 conv_bwd rans; do
+for f in ops lifting lifting_f16 cdf97 conv_mfma conv_f16x3 conv_wgrad_f16x3 cgp_fused cgp_f16x3 conv_bwd rans; do
   [ -f "$HERE/$f.hip" ] || continue
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/lifting_f16.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/split_f16.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/lldwt.h" -nt "$HERE/obj/$f.o" ]; then
     EXTRA=""

@@ -1,0 +1,303 @@
+// conv_wgrad_f16x3.hip -- backward-weights of the dense 3x3 tree-context conv (243 -> 243, LiftingBasedDWT_net.py:271-272)
+// on the fp16 matrix cores with split-fp16 operands (hi + lo fp16 per fp32 value, power-of-two scaled, hi*hi + hi*lo + lo*hi,
+// fp32 accumulate: fp32-level accuracy, see conv_f16x3.hip).  Replaces k_conv_wgrad<3,4,16> (fp32 MFMA, 26 ms of the
+// training step at 89 TFLOP/s) for this layer; the generic kernel stays for every other shape.
+//
+//   dW[oc][ic][ty][tx] += sum over images and pixels of dY[oc][y][x] * X[ic][y + ty - 1][x + tx - 1]       (zero padded)
+//   db[oc]             += sum dY[oc]
+//
+// GEMM view: M = oc, N = (tap, ic), K = pixels.  v_mfma_f32_32x32x16_f16: A = dY (32 oc x 16 pixels), B = X shifted by the
+// tap (16 pixels x 32 ic), so an N tile is ONE tap for 32 input channels and its B fragment is "8 consecutive pixels of
+// one channel at a fixed shift".  Both operands are indexed by pixel along K, so they live in LDS channel-major:
+//   A image [128 oc][2 rows x 32 px] fp16, pitch 144 B          (9 16-byte slots: odd -> conflict-free ds_read_b128)
+//   B image [3 tx][32 ic][4 rows][32 px] fp16, row pitch 80 B, channel pitch 336 B (21 slots: odd)
+// -- one copy of the input rows per horizontal tap, pre-shifted by tx, because a 16-byte fragment read must be aligned and
+// tx moves the start by 2 bytes; the vertical tap is a row offset.
+// Workgroup = 4 waves (one per SIMD), tile 128 oc x 32 ic x 9 taps = 36 accumulator tiles, wave w owns oc 32w .. 32w+31 for
+// all 9 taps (144 accumulator registers): one A fragment serves 27 MFMAs.  K is cut into chunks of 2 x 32 pixels; the
+// next chunk's global loads are in flight during the current chunk's 108 MFMAs per wave; split + LDS store between two
+// barriers.  K is also split over workgroups (slices of the chunk sequence), partial tiles are added with float atomics.
+// Scales: one power of two per plane for dY and for X (max |.| from lldwt_absmax_slots), so every chunk accumulates at
+// the same scale.
+#include "common.h"
+#include "split_f16.h"
+
+namespace lldwt {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int WM = 128, WIC = 32;                 // oc and ic per workgroup
+constexpr int CR = 2, CW = 32, CPX = CR * CW;     // K chunk: 2 rows x 32 pixels
+constexpr int A_PITCH = CPX * 2 + 16;             // 144 B per oc
+constexpr int A_PART = WM * A_PITCH;              // 18,432 B (hi or lo)
+constexpr int B_ROW = CW * 2 + 16;                // 80 B per row
+constexpr int B_IC = (CR + 2) * B_ROW + 16;       // 336 B per channel
+constexpr int B_TX = WIC * B_IC;                  // 10,752 B per horizontal tap
+constexpr int B_PART = 3 * B_TX;                  // 32,256 B (hi or lo)
+constexpr int LDS_A = 0, LDS_B = 2 * A_PART;
+constexpr int LDS_TOTAL = LDS_B + 2 * B_PART;     // 101,376 B
+constexpr int NA4 = WM * CPX / 4 / 256;           // dY float4s per thread and chunk: 8
+constexpr int XSEG = (CW + 8) / 4;                // input float4 segments per row: columns x0-4 .. x0+35 -> 10
+constexpr int NX4 = WIC * (CR + 2) * XSEG / 256;  // 5
+static_assert(WM * CPX / 4 % 256 == 0 && WIC * (CR + 2) * XSEG % 256 == 0, "whole staging rounds");
+
+__device__ __forceinline__ float pow2_scale_for(float amax) {         // s = 2^k with amax * s in [2^13, 2^14)
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(amax, &e);
+    int k = 14 - e;
+    k = k > 120 ? 120 : (k < -120 ? -120 : k);
+    return ldexpf(1.f, k);
+}
+
+struct WgArgs {
+    const float* x;       // (planes, batch, cin, h, w)
+    const float* dy;      // (planes, batch, cout, h, w)
+    float* dw;            // (planes, cout, cin, 3, 3)
+    float* db;            // (planes, cout) or null
+    const float* sx;      // (planes, 64) max-|x| slots
+    const float* sy;      // (planes, 64) max-|dy| slots
+    int cin, cout, batch, h, w, nicb, nocb, slices, chunks_x, chunks_y;
+    float alpha;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_wgrad3_f16x3(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int plane = blockIdx.z;
+    // blockIdx.x = (slice_hi * ncol + column) * 8 + slice_lo: the columns of one K slice sit on one XCD (id % 8), next to
+    // each other in its queue, so the chunk of dY / x they all stage is read from HBM once and from that XCD's L2 after
+    const int ncol = a.nicb * a.nocb;
+    const int s_lo = blockIdx.x & 7, t_ = blockIdx.x >> 3;
+    const int column = t_ % ncol, slice = (t_ / ncol) * 8 + s_lo;
+    const int icb = column % a.nicb, ocb = column / a.nicb;
+    const int ic0 = icb * WIC, oc0 = ocb * WM;
+    const int h = a.h, w = a.w;
+    const int64_t hw = (int64_t)h * w;
+    const int nchunk_img = a.chunks_x * a.chunks_y;
+    const int nchunk = a.batch * nchunk_img;
+
+    // ---- scales (powers of two, per plane)
+    float ax = a.sx[plane * 64 + lane], ay = a.sy[plane * 64 + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ax = fmaxf(ax, __shfl_xor(ax, o, 64));
+        ay = fmaxf(ay, __shfl_xor(ay, o, 64));
+    }
+    const float sX = pow2_scale_for(ax), sY = pow2_scale_for(ay);
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    // ---- staging roles of this thread (fixed over the chunks)
+    // dY: float4 f = tid + 256 j -> oc = f / 16, row = (f % 16) / 8, x4 = 4 (f % 8)
+    // x : float4 f = tid + 256 j -> ic = f / 40, row = (f % 40) / 10 (image row y0 - 1 + row), segment s = f % 10 (cols x0-4+4s ..)
+    const float* xp = a.x + ((int64_t)plane * a.batch * a.cin + ic0) * hw;
+    const float* yp = a.dy + ((int64_t)plane * a.batch * a.cout + oc0) * hw;
+    floatx4 ra[NA4], rx[NX4];
+    float dbs[NA4];
+#pragma unroll
+    for (int j = 0; j < NA4; ++j) dbs[j] = 0.f;
+
+    auto issue = [&](int chunk) {                     // global loads of one chunk (clamped addresses, masked at the store)
+        const int img = chunk / nchunk_img, rem = chunk - img * nchunk_img;
+        const int cy = rem / a.chunks_x, cx = rem - cy * a.chunks_x;
+        const int y0 = cy * CR, x0 = cx * CW;
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) {
+            const int f = tid + 256 * j;
+            const int oc = f >> 4, row = (f >> 3) & 1, x4 = (f & 7) * 4;
+            const int gy = min(y0 + row, h - 1), gx = min(x0 + x4, w - 4), occ = min(oc0 + oc, a.cout - 1) - oc0;
+            ra[j] = *reinterpret_cast<const floatx4*>(yp + ((int64_t)img * a.cout + occ) * hw + (int64_t)gy * w + gx);
+        }
+#pragma unroll
+        for (int j = 0; j < NX4; ++j) {
+            const int f = tid + 256 * j;
+            const int ic = f / ((CR + 2) * XSEG), r2 = f - ic * ((CR + 2) * XSEG), row = r2 / XSEG, s = r2 - row * XSEG;
+            const int gy = min(max(y0 - 1 + row, 0), h - 1), gx = min(max(x0 - 4 + 4 * s, 0), w - 4);
+            const int icc = min(ic0 + ic, a.cin - 1) - ic0;
+            rx[j] = *reinterpret_cast<const floatx4*>(xp + ((int64_t)img * a.cin + icc) * hw + (int64_t)gy * w + gx);
+        }
+    };
+    auto stage = [&](int chunk) {                     // scale, zero what lies outside, split, LDS store
+        const int img = chunk / nchunk_img, rem = chunk - img * nchunk_img;
+        const int cy = rem / a.chunks_x, cx = rem - cy * a.chunks_x;
+        const int y0 = cy * CR, x0 = cx * CW;
+        (void)img;
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) {
+            const int f = tid + 256 * j;
+            const int oc = f >> 4, row = (f >> 3) & 1, x4 = (f & 7) * 4;
+            const bool ok = oc0 + oc < a.cout && y0 + row < h && x0 + x4 < w;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ok ? ra[j][i] : 0.f;
+            dbs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= sY;
+            half4 hi, lo;
+            split4v(v, hi, lo);
+            uint8_t* d = lds + LDS_A + oc * A_PITCH + (row * CW + x4) * 2;
+            *reinterpret_cast<half4*>(d) = hi;
+            *reinterpret_cast<half4*>(d + A_PART) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < NX4; ++j) {
+            const int f = tid + 256 * j;
+            const int ic = f / ((CR + 2) * XSEG), r2 = f - ic * ((CR + 2) * XSEG), row = r2 / XSEG, s = r2 - row * XSEG;
+            const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * s;
+            const bool ok = ic0 + ic < a.cin && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ok ? rx[j][i] * sX : 0.f;
+            half4 hi, lo;
+            split4v(v, hi, lo);
+            // copy tx holds element e = (column - x0 + 1 - tx) of the row, e in [0, 32); this segment's columns are x0-4+4s+i
+            uint8_t* rowp = lds + LDS_B + ic * B_IC + row * B_ROW;
+            const int e1 = 4 * s - 4;                 // tx = 1: an aligned group of four
+            if (e1 >= 0 && e1 < CW) {
+                *reinterpret_cast<half4*>(rowp + B_TX + e1 * 2) = hi;
+                *reinterpret_cast<half4*>(rowp + B_TX + e1 * 2 + B_PART) = lo;
+            }
+#pragma unroll
+            for (int tx = 0; tx < 3; tx += 2) {       // tx = 0: e = 4s-3+i;  tx = 2: e = 4s-5+i  (odd start: 1 + 2 + 1)
+                const int e0 = 4 * s - 3 - tx;
+                uint8_t* cp = rowp + tx * B_TX;
+                if (e0 >= 0 && e0 < CW) {
+                    *reinterpret_cast<_Float16*>(cp + e0 * 2) = hi[0];
+                    *reinterpret_cast<_Float16*>(cp + e0 * 2 + B_PART) = lo[0];
+                }
+                if (e0 + 1 >= 0 && e0 + 1 < CW) {
+                    *reinterpret_cast<half2*>(cp + (e0 + 1) * 2) = half2{hi[1], hi[2]};
+                    *reinterpret_cast<half2*>(cp + (e0 + 1) * 2 + B_PART) = half2{lo[1], lo[2]};
+                }
+                if (e0 + 3 >= 0 && e0 + 3 < CW) {
+                    *reinterpret_cast<_Float16*>(cp + (e0 + 3) * 2) = hi[3];
+                    *reinterpret_cast<_Float16*>(cp + (e0 + 3) * 2 + B_PART) = lo[3];
+                }
+            }
+        }
+    };
+
+    // ---- main loop over this slice's chunks: slice, slice + slices, ...
+    const int kg = lane >> 5, l31 = lane & 31;
+    const uint8_t* abase = lds + LDS_A + (wave * 32 + l31) * A_PITCH + kg * 16;
+    const uint8_t* bbase = lds + LDS_B + l31 * B_IC + kg * 16;
+    int chunk = slice;
+    if (chunk < nchunk) {
+        issue(chunk);
+        stage(chunk);
+    }
+    __syncthreads();
+    while (chunk < nchunk) {
+        const int next = chunk + a.slices;
+        if (next < nchunk) issue(next);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int r = ks >> 1, xh = ks & 1;
+            const half8 ah = *reinterpret_cast<const half8*>(abase + (r * CW + 16 * xh) * 2);
+            const half8 al = *reinterpret_cast<const half8*>(abase + (r * CW + 16 * xh) * 2 + A_PART);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ty = t / 3, tx = t - 3 * ty;
+                const uint8_t* bp = bbase + tx * B_TX + (r + ty) * B_ROW + 16 * xh * 2;
+                const half8 bh = *reinterpret_cast<const half8*>(bp);
+                const half8 bl = *reinterpret_cast<const half8*>(bp + B_PART);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();                              // every wave is done reading this chunk's images
+        if (next < nchunk) stage(next);
+        __syncthreads();
+        chunk = next;
+    }
+
+    if (slice >= nchunk) return;                      // nothing staged, nothing to add (uniform: after the last barrier)
+    // ---- epilogue: dW[oc][ic][tap] += alpha * acc / (sY sX);  D row = (q&3) + 8 (q>>2) + 4 (lane>>5) (oc), col = lane&31 (ic)
+    const float inv = a.alpha * (1.f / sX) * (1.f / sY);
+    const int ic = ic0 + l31;
+    float* dwp = a.dw + (int64_t)plane * a.cout * a.cin * 9;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int oc = oc0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+        if (oc < a.cout && ic < a.cin) {
+            float* p = dwp + ((int64_t)oc * a.cin + ic) * 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) atomicAdd(p + t, acc[t][q] * inv);
+        }
+    }
+    // bias gradient: the input-channel block 0 of every oc block adds the dY sums it staged
+    if (a.db && icb == 0) {
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) {
+            float s = dbs[j];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);       // the 16 threads that stage one oc row
+            const int oc = oc0 + ((tid + 256 * j) >> 4);
+            if ((tid & 15) == 0 && oc < a.cout) atomicAdd(a.db + (int64_t)plane * a.cout + oc, s * a.alpha);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace lldwt
+using namespace lldwt;
+
+extern "C" int lldwt_absmax_slots(const float* x, int64_t planes, int64_t n_per_plane, float* slots, void* stream);
+
+extern "C" int lldwt_conv3x3_wgrad_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int cin,
+                                         int cout, int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha,
+                                         void* stream) {
+    LLDWT_REQUIRE(x && dy && dw && slots_ws, "conv3x3_wgrad_f16x3: null pointer");
+    LLDWT_REQUIRE(cin > 0 && cout > 0 && planes > 0 && planes <= 65535 && batch > 0 && h > 0 && w_ >= 4, "conv3x3_wgrad_f16x3: bad dims");
+    LLDWT_REQUIRE(w_ % 4 == 0, "conv3x3_wgrad_f16x3: the row length must be a multiple of 4 (16-byte row segments)");
+    LLDWT_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dy) & 15) == 0, "conv3x3_wgrad_f16x3: x and dy must be 16-byte aligned");
+    LLDWT_REQUIRE((int64_t)batch * (cin > cout ? cin : cout) * h * w_ < ((int64_t)1 << 40), "conv3x3_wgrad_f16x3: tensor too large");
+    hipStream_t st = (hipStream_t)stream;
+    // per-plane max |x| and max |dy| (two passes at HBM speed; 64 slots each)
+    float* sx = slots_ws;
+    float* sy = slots_ws + planes * 64;
+    int r = lldwt_absmax_slots(x, planes, batch * cin * h * w_, sx, stream);
+    if (r) return r;
+    r = lldwt_absmax_slots(dy, planes, batch * cout * h * w_, sy, stream);
+    if (r) return r;
+    WgArgs a;
+    a.x = x; a.dy = dy; a.dw = dw; a.db = dbias; a.sx = sx; a.sy = sy;
+    a.cin = cin; a.cout = cout; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
+    a.nicb = (int)cdiv(cin, WIC);
+    a.nocb = (int)cdiv(cout, WM);
+    a.chunks_x = (int)cdiv(w_, CW);
+    a.chunks_y = (int)cdiv(h, CR);
+    a.alpha = alpha;
+    const int64_t nchunk = batch * a.chunks_x * a.chunks_y;
+    const int ncol = a.nicb * a.nocb;
+    // K slices: a multiple of 8 (one per XCD), about two resident rounds of workgroups over all planes
+    // (one workgroup per CU: 101 KB of LDS): the smallest such count that fills whole rounds of the chip, at least two
+    const int64_t ncu = lldwt_num_cus();
+    int64_t slices = 16;
+    for (int64_t s = 8; s <= 64; s += 8)
+        if (planes * ncol * s >= 2 * ncu && (planes * ncol * s) % ncu == 0) { slices = s; break; }
+    while (slices > 8 && slices * 4 > nchunk) slices -= 8;
+    a.slices = (int)slices;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k_wgrad3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) {
+            set_error("conv3x3_wgrad_f16x3: cannot reserve %d bytes of LDS", LDS_TOTAL);
+            return LLDWT_EHIP;
+        }
+        attr = true;
+    }
+    dim3 grid((unsigned)(slices * ncol), 1, (unsigned)planes);
+    hipLaunchKernelGGL(k_wgrad3_f16x3, grid, dim3(256), LDS_TOTAL, st, a);
+    return check_launch("conv3x3_wgrad_f16x3");
+}

@@ -442,6 +442,21 @@ def conv2d_wgrad(x, dy, wshape, K, groups=1, upsample2=False, tap_mask=None, wan
     return dw, db
 
 
+def conv3x3_wgrad_f16x3(x, dy, wshape, want_bias=True, alpha=1.0):
+    """Backward-weights of a dense 3x3 conv on the fp16 matrix cores, split-fp16 operands (lldwt_conv3x3_wgrad_f16x3).
+    x (P,B,cin,h,w), dy (P,B,cout,h,w) -> (dw (P,cout,cin,3,3), dbias (P,cout) or None)."""
+    P, B, cin, h, wd = x.shape
+    cout = dy.shape[2]
+    if tuple(wshape) != (P, cout, cin, 3, 3) or dy.shape != (P, B, cout, h, wd):
+        raise _lib.LLDWTError("conv3x3_wgrad_f16x3: shapes %r %r %r" % (tuple(x.shape), tuple(dy.shape), tuple(wshape)))
+    dw = torch.zeros(wshape, device=x.device, dtype=torch.float32)
+    db = torch.zeros(P, cout, device=x.device, dtype=torch.float32) if want_bias else None
+    slots = torch.empty(P * 128, device=x.device, dtype=torch.float32)
+    check(_lib.load().lldwt_conv3x3_wgrad_f16x3(_chk(x, "x"), _chk(dy, "dy"), _chk(dw), _opt(db), _chk(slots), cin, cout, P, B,
+                                               h, wd, float(alpha), _stream()), "conv3x3_wgrad_f16x3")
+    return dw, db
+
+
 def act_bwd(dy, y, act):
     dx = torch.empty_like(dy)
     check(_lib.load().lldwt_act_bwd(_chk(dy), _chk(y), _chk(dx), dy.numel(), act, _stream()), "act_bwd")

@@ -251,6 +251,14 @@ int lldwt_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias,
 int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, float* dbias, const lldwt_conv_desc* d,
                           int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw,
                           void* stream);
+/* Backward-weights of a DENSE 3x3 conv (groups 1, no placement, no upsampling, no dead taps) on the fp16 matrix cores with
+ * split-fp16 operands (fp32-level accuracy; csrc/conv_wgrad_f16x3.hip): dw (planes,cout,cin,3,3) += alpha * sum over batch
+ * and pixels of dy[.,oc,p] * x[.,ic,p+tap], dbias (planes,cout) += alpha * sum dy (optional).  x (planes,batch,cin,h,w),
+ * dy (planes,batch,cout,h,w), both 16-byte aligned, w % 4 == 0.  slots_ws: planes * 128 floats of scratch (the per-plane
+ * max |x| and max |dy| the power-of-two operand scales come from).  Float atomics: zero dw / dbias first.  The training
+ * path of the 243 -> 243 tree-context conv (LiftingBasedDWT_net.py:271-272); lldwt_conv2d_wgrad covers every other shape. */
+int lldwt_conv3x3_wgrad_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int cin, int cout,
+                              int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, void* stream);
 /* dx = dy * act'(y) elementwise (y = forward output); act as in lldwt_conv_desc. */
 int lldwt_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, void* stream);
 /* backward of the nearest-neighbour 2x upsampling: out (Z,C,h/2,w/2) = sum over each 2x2 block of g (Z,C,h,w). */

@@ -155,3 +155,32 @@ def test_fused_pair_is_what_the_model_runs(monkeypatch):
         b = net._plc_pair([s[0] for s in seqs], [s[2] for s in seqs], parent, ops.ACT_NONE)
     assert len(calls) == 1
     assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 243, 243, 32, 64), (2, 3, 70, 150, 17, 44), (1, 1, 64, 64, 2, 4), (1, 2, 96, 130, 9, 100)])
+def test_wgrad_f16x3_vs_float64_and_fp32_kernel(shape):
+    """lldwt_conv3x3_wgrad_f16x3 (split-fp16 MFMA GEMM over pixels, K split over workgroups, atomics) vs the float64
+    gradient of F.conv2d and vs the fp32 MFMA weight-gradient kernel: ragged channel counts (partial oc / ic blocks), images
+    smaller than a chunk, odd row counts, several images (the reduction runs over them), bias gradient."""
+    ops = _ops()
+    P, B, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(cin + h)
+    x = (torch.rand(P, B, cin, h, w, generator=g) - 0.3) * 2.0
+    dy = torch.randn(P, B, cout, h, w, generator=g) * 1e-3          # gradients are small numbers: the scales must cope
+    dw, db = ops.conv3x3_wgrad_f16x3(x.to(DEV), dy.to(DEV), (P, cout, cin, 3, 3))
+    dw32, db32 = ops.conv2d_wgrad(x.to(DEV), dy.to(DEV), (P, cout, cin, 3, 3), 3)
+    for p in range(P):
+        wz = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        bz = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x[p].double(), wz, bz, padding=1)
+        (y * dy[p].double()).sum().backward()
+        scale = float(wz.grad.abs().max())
+        e16 = float((dw[p].cpu().double() - wz.grad).abs().max()) / scale
+        e32 = float((dw32[p].cpu().double() - wz.grad).abs().max()) / scale
+        assert e16 < 5e-6, (e16, e32)
+        assert e16 < 4 * e32 + 5e-7, (e16, e32)
+        eb = float((db[p].cpu().double() - bz.grad).abs().max()) / float(bz.grad.abs().max())
+        assert eb < 5e-6, eb
+    # accumulation semantics: alpha, and += into an existing buffer is the caller's (zeroed here)
+    dw2, _ = ops.conv3x3_wgrad_f16x3(x.to(DEV), dy.to(DEV), (P, cout, cin, 3, 3), want_bias=False, alpha=-0.5)
+    assert float((dw2 + 0.5 * dw).abs().max()) < 1e-5 * float(dw.abs().max())

@@ -63,6 +63,12 @@ def main():
     t = timeit(lambda: ops.plc_fused(parent, pk1f, pk16, b, C, C), a.iters)
     out["pair_fused"] = {"ms": t * 1e3, "TFLOP/s (algorithmic fp32-equivalent, second conv only)": flop / t / 1e12}
     out["pair_max_abs_diff"] = float((two() - ops.plc_fused(parent, pk1f, pk16, b, C, C)).abs().max())
+    # backward-weights of the same layer: fp32 MFMA kernel vs split-fp16
+    dyg = torch.randn(P, B, C, S, S, device=dev) * 1e-3
+    t = timeit(lambda: ops.conv2d_wgrad(x, dyg, (P, C, C, 3, 3), 3), a.iters)
+    out["wgrad_f32"] = {"ms": t * 1e3, "TFLOP/s": flop / t / 1e12}
+    t = timeit(lambda: ops.conv3x3_wgrad_f16x3(x, dyg, (P, C, C, 3, 3)), a.iters)
+    out["wgrad_f16x3"] = {"ms": t * 1e3, "TFLOP/s (algorithmic fp32-equivalent)": flop / t / 1e12}
     y32 = ops.conv2d(x, w, b, 3, packed=pk32)
     y16 = ops.conv3x3_f16x3(x, pk16, b, C, slots=slots)
     out["max_abs_diff_f16x3_vs_f32"] = float((y32 - y16).abs().max())
