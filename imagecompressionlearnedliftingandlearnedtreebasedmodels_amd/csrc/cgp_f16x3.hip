@@ -143,15 +143,23 @@ struct Cgp16Args {
     int ntaps;
     int tap_dy[25], tap_dx[25];
     int cols;              // 64-pixel columns per image
+    unsigned long long* stamps;   // diagnostics only (LLDWT_CGP_STAMPS = device address): [z][group][column][8] s_memtime stamps
 };
+#define CGP_STAMP(i)                                                                                                    \
+    if (a.stamps && lane == 0)                                                                                          \
+        a.stamps[(((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * a.cols + col) * 8 + (i)] =                           \
+            (i) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
 
 // bias + LeakyReLU + rescale + split of one D tile into the two B fragments (k-steps 0 and 1) of the next layer.
 // The next layer's power-of-two scale commutes with LeakyReLU, so it is folded into the dequantisation factor and into the
 // bias (bsc = bias * snext, prepared once per tile for both pixel blocks): per value one FMA, LeakyReLU as max(t, 0.01 t),
 // then the split.
-__device__ __forceinline__ void load_bias_scaled(const float* __restrict__ bias, int h, float snext, float (&bsc)[16]) {
+// The biases are read from an LDS copy (filled once per workgroup, before the weight stream starts): a per-lane vector
+// load at this point is waited for immediately, and because vmcnt retires in order that wait also drains the whole weight
+// prefetch ring -- one full memory latency per tile (tools/cgp_stamps.py).  LDS reads count on lgkmcnt instead.
+__device__ __forceinline__ void load_bias_scaled(const float* bias_lds, int h, float snext, float (&bsc)[16]) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bsc[q] = bias[drow(q, h)] * snext;
+    for (int q = 0; q < 16; ++q) bsc[q] = bias_lds[drow(q, h)] * snext;
 }
 __device__ __forceinline__ void next_frags(const floatx16& acc, float k, const float (&bsc)[16], half8 (&bh)[2], half8 (&bl)[2]) {
 #pragma unroll
@@ -166,18 +174,23 @@ __device__ __forceinline__ void next_frags(const floatx16& acc, float k, const f
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_cgp16(Cgp16Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_cgp16(Cgp16Args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h5 = lane >> 5, pl = lane & 31;
     const int64_t z = blockIdx.z;
     const int plane = (int)(z / a.batch), g = blockIdx.y;
     const int col = blockIdx.x * 4 + wave;
-    if (col >= a.cols) return;                                   // whole wave: no barrier in this kernel
     const int64_t hw = (int64_t)a.h * a.w;
     const uint8_t* grp = a.packed + ((int64_t)plane * a.groups + g) * GROUP_BYTES;
     const float* hdr = reinterpret_cast<const float*>(grp);
-    const float* bias0 = hdr + 64, * bias1 = hdr + 256, * bias2 = hdr + 320, * bias3 = hdr + 352;
+    __shared__ float sbias[320];                                 // header floats 64 .. 383: the four layers' biases
+    for (int i = threadIdx.x; i < 320; i += 256) sbias[i] = hdr[64 + i];
+    __syncthreads();                                             // the only barrier: before any wave can leave
+    if (col >= a.cols) return;                                   // whole wave
+    const float* bias0 = sbias, * bias1 = sbias + 192, * bias2 = sbias + 256, * bias3 = sbias + 288;
     const uint8_t* wst = grp + HDR_FLOATS * 4 + lane * 16;
+    CGP_STAMP(0)
+    CGP_STAMP(6)
 
     // ---- layer-0 B fragments straight from global memory
     const float* plc = a.plc + (z * a.groups * CPLC + (int64_t)g * CPLC) * hw;
@@ -227,6 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     // ---- scales: input from its maximum, hidden layers from bounds |h_l| <= |h_{l-1}|max * L1max_l + |b_l|max
+    CGP_STAMP(1)
     const float s_in = pow2_scale(amax);
     const float bound0 = amax * hdr[4] + hdr[8];
     const float bound1 = bound0 * hdr[5] + hdr[9];
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     {                                                                                                 \
         ah[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * STEP_BYTES);          \
         al[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * STEP_BYTES + 1024);   \
+        __builtin_amdgcn_sched_barrier(0);   /* the scheduler otherwise sinks these loads down to their use (3 steps later) */ \
     }
 #define CGP16_MMA(ACC, BH, BL)                                                                        \
     {                                                                                                 \
@@ -304,6 +319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 ++step;
             }
     }
+    CGP_STAMP(2)
     // ---- layer 2 (54 -> 18)
     floatx16 acc2[NB];
 #pragma unroll
@@ -327,6 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             ++step;
         }
     }
+    CGP_STAMP(3)
     // ---- layer 3 (18 -> 2)
     floatx16 acc3[NB];
 #pragma unroll
@@ -351,6 +368,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 #undef CGP16_NEXT
 #undef CGP16_MMA
+    CGP_STAMP(4)
     // ---- rows 0 (sigma) and 1 (mu) of the last tile: registers 0, 1 of the lanes with h == 0
     if (h5 == 0) {
         float* out = a.params + (z * 2 * a.groups + 2 * g) * hw;
@@ -361,7 +379,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 out[hw + pix[nb]] = acc3[nb][1] * inv3 + bias3[1];
             }
     }
+    CGP_STAMP(5)
+    CGP_STAMP(7)
 }
+#undef CGP_STAMP
 
 }  // namespace
 }  // namespace lldwt
@@ -402,6 +423,10 @@ extern "C" int lldwt_cgp16_params(const float* plc, const float* xq, const void*
     LLDWT_REQUIRE(n == C0 - CPLC, "cgp16_params: %d live taps, the folded first layer expects %d", n, C0 - CPLC);
     a.ntaps = n;
     a.cols = (int)cdiv(h * w_, 64);
+    {
+        const char* stp = getenv("LLDWT_CGP_STAMPS");
+        a.stamps = stp ? reinterpret_cast<unsigned long long*>(strtoull(stp, nullptr, 0)) : nullptr;
+    }
     dim3 grid((unsigned)cdiv(a.cols, 4), (unsigned)groups, (unsigned)(planes * batch));
     hipLaunchKernelGGL(k_cgp16, grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("cgp16_params");

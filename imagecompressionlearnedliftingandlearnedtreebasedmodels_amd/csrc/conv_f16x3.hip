@@ -392,7 +392,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // rows -- the same for the wave's three pixel blocks, loaded once per chunk a few units ahead of their first use
     typedef float floatx4 __attribute__((ext_vector_type(4)));
     half8 w1h[2], w1l[2];
-    floatx4 b1v[4];
+    floatx4 b1r[4], b1v[4];     // raw bias as loaded; scaled by sx at its FIRST USE (block 0): a multiply at the load site is a
+                                // vmcnt(0) wait there, which drains the whole weight ring (vmcnt retires in order)
 #define F3_FUSED_LOAD(C1)                                                                                             \
     {                                                                                                                 \
         const uint8_t* w1_ = pk1 + F1_HDR + (int64_t)((C1) / F3_CK) * F1_CHUNK_BYTES + lane * 16;                     \
@@ -401,12 +402,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             w1l[ks] = *reinterpret_cast<const half8*>(w1_ + ks * F3_STEP_BYTES + 1024);                               \
         }                                                                                                             \
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                              \
-            b1v[gq] = *reinterpret_cast<const floatx4*>(bias1 + (C1) + 8 * gq + 4 * (lane >> 5)) * sx;                \
+            b1r[gq] = *reinterpret_cast<const floatx4*>(bias1 + (C1) + 8 * gq + 4 * (lane >> 5));                     \
     }
     // channels C1 .. C1+31 of the first conv for pixel block B of this wave -> split -> the LDS image at DST
 #define F3_FUSED_BLOCK(B, DST)                                                                                        \
     {                                                                                                                 \
         floatx16 t_;                                                                                                  \
+        if ((B) == 0) { _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) b1v[gq] = b1r[gq] * sx; }                    \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) t_[q] = 0.f;                                                   \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
             const half8 ch_ = *reinterpret_cast<const half8*>(col1 + (((wave + 4 * (B)) * 2 + ks) * 2 + 0) * 1024);  \
