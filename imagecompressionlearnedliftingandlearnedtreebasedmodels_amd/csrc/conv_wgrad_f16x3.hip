@@ -40,7 +40,8 @@ constexpr int B_IC = (CR + 2) * B_ROW + 16;       // 336 B per channel
 constexpr int B_TX = WIC * B_IC;                  // 10,752 B per horizontal tap
 constexpr int B_PART = 3 * B_TX;                  // 32,256 B (hi or lo)
 constexpr int LDS_A = 0, LDS_B = 2 * A_PART;
-constexpr int LDS_TOTAL = LDS_B + 2 * B_PART;     // 101,376 B
+constexpr int LDS_DUMP = LDS_B + 2 * B_PART;      // 64 B that out-of-range pieces of the shifted copies are stored to (no branch)
+constexpr int LDS_TOTAL = LDS_DUMP + 64;          // 101,440 B
 constexpr int NA4 = WM * CPX / 4 / 256;           // dY float4s per thread and chunk: 8
 constexpr int XSEG = (CW + 8) / 4;                // input float4 segments per row: columns x0-4 .. x0+35 -> 10
 constexpr int NX4 = WIC * (CR + 2) * XSEG / 256;  // 5
@@ -162,27 +163,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             split4v(v, hi, lo);
             // copy tx holds element e = (column - x0 + 1 - tx) of the row, e in [0, 32); this segment's columns are x0-4+4s+i
             uint8_t* rowp = lds + LDS_B + ic * B_IC + row * B_ROW;
+            // every piece is stored unconditionally: out-of-range pieces go to a dump slot (a branch per piece cost more than
+            // the stores)
+            uint8_t* dump = lds + LDS_DUMP;
             const int e1 = 4 * s - 4;                 // tx = 1: an aligned group of four
-            if (e1 >= 0 && e1 < CW) {
-                *reinterpret_cast<half4*>(rowp + B_TX + e1 * 2) = hi;
-                *reinterpret_cast<half4*>(rowp + B_TX + e1 * 2 + B_PART) = lo;
+            {
+                uint8_t* d = (e1 >= 0 && e1 < CW) ? rowp + B_TX + e1 * 2 : dump;
+                *reinterpret_cast<half4*>(d) = hi;
+                *reinterpret_cast<half4*>(d + ((e1 >= 0 && e1 < CW) ? B_PART : 8)) = lo;
             }
 #pragma unroll
             for (int tx = 0; tx < 3; tx += 2) {       // tx = 0: e = 4s-3+i;  tx = 2: e = 4s-5+i  (odd start: 1 + 2 + 1)
                 const int e0 = 4 * s - 3 - tx;
                 uint8_t* cp = rowp + tx * B_TX;
-                if (e0 >= 0 && e0 < CW) {
-                    *reinterpret_cast<_Float16*>(cp + e0 * 2) = hi[0];
-                    *reinterpret_cast<_Float16*>(cp + e0 * 2 + B_PART) = lo[0];
-                }
-                if (e0 + 1 >= 0 && e0 + 1 < CW) {
-                    *reinterpret_cast<half2*>(cp + (e0 + 1) * 2) = half2{hi[1], hi[2]};
-                    *reinterpret_cast<half2*>(cp + (e0 + 1) * 2 + B_PART) = half2{lo[1], lo[2]};
-                }
-                if (e0 + 3 >= 0 && e0 + 3 < CW) {
-                    *reinterpret_cast<_Float16*>(cp + (e0 + 3) * 2) = hi[3];
-                    *reinterpret_cast<_Float16*>(cp + (e0 + 3) * 2 + B_PART) = lo[3];
-                }
+                const bool k0 = e0 >= 0 && e0 < CW, k1 = e0 + 1 >= 0 && e0 + 1 < CW, k3 = e0 + 3 >= 0 && e0 + 3 < CW;
+                uint8_t* d0 = k0 ? cp + e0 * 2 : dump + 16;
+                uint8_t* d1 = k1 ? cp + (e0 + 1) * 2 : dump + 32;
+                uint8_t* d3 = k3 ? cp + (e0 + 3) * 2 : dump + 48;
+                *reinterpret_cast<_Float16*>(d0) = hi[0];
+                *reinterpret_cast<_Float16*>(d0 + (k0 ? B_PART : 2)) = lo[0];
+                *reinterpret_cast<half2*>(d1) = half2{hi[1], hi[2]};
+                *reinterpret_cast<half2*>(d1 + (k1 ? B_PART : 4)) = half2{lo[1], lo[2]};
+                *reinterpret_cast<_Float16*>(d3) = hi[3];
+                *reinterpret_cast<_Float16*>(d3 + (k3 ? B_PART : 2)) = lo[3];
             }
         }
     };
