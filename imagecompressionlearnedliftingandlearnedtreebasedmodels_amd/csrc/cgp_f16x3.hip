@@ -39,7 +39,9 @@ constexpr int NSTEP = NM0 * (NK0 + 2 * NM1) + 2 * NM1 + 2;     // 60 + 4 + 2 = 6
 constexpr int STEP_BYTES = 2048;       // hi fragment + lo fragment
 constexpr int HDR_FLOATS = 64 + 192 + 64 + 32 + 32;            // scalars | b0 | b1 | b2 | b3
 constexpr int GROUP_BYTES = HDR_FLOATS * 4 + (NSTEP + 3) * STEP_BYTES;   // + 3 steps of padding for the prefetch ring
-constexpr int NB = 2;                  // pixel blocks of 32 per wave
+constexpr int NB = 1;                  // pixel blocks of 32 per wave.  One block and two waves per SIMD (232 VGPRs): the other wave
+                                       // computes while this one waits for its 48 input loads (two blocks in one wave at one wave
+                                       // per SIMD share the weight stream, but nothing hides the input latency: 12 % slower)
 
 __device__ __forceinline__ float pow2_scale(float amax) {      // s = 2^k with amax * s in [2^14, 2^15)
     if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
@@ -174,7 +176,7 @@ __device__ __forceinline__ void next_frags(const floatx16& acc, float k, const f
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_cgp16(Cgp16Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cgp16(Cgp16Args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h5 = lane >> 5, pl = lane & 31;
     const int64_t z = blockIdx.z;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float amax = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int64_t p = (int64_t)col * 64 + nb * 32 + pl;
+        const int64_t p = (int64_t)col * (32 * NB) + nb * 32 + pl;
         valid[nb] = p < hw;
         const int pc = (int)(valid[nb] ? p : hw - 1);
         pix[nb] = pc;
@@ -422,7 +424,7 @@ extern "C" int lldwt_cgp16_params(const float* plc, const float* xq, const void*
         }
     LLDWT_REQUIRE(n == C0 - CPLC, "cgp16_params: %d live taps, the folded first layer expects %d", n, C0 - CPLC);
     a.ntaps = n;
-    a.cols = (int)cdiv(h * w_, 64);
+    a.cols = (int)cdiv(h * w_, 32 * NB);
     {
         const char* stp = getenv("LLDWT_CGP_STAMPS");
         a.stamps = stp ? reinterpret_cast<unsigned long long*>(strtoull(stp, nullptr, 0)) : nullptr;

@@ -29,7 +29,7 @@ def main():
     for _ in range(30):
         run()
     torch.cuda.synchronize()
-    cols = S * S // 64
+    cols = S * S // 32
     st = torch.zeros(P * B, G, cols, 8, dtype=torch.int64, device=dev)
     os.environ["LLDWT_CGP_STAMPS"] = str(st.data_ptr())
     run()
