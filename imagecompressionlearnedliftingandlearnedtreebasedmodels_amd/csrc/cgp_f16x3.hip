@@ -1,6 +1,6 @@
 // cgp_f16x3.hip -- the context-fusion MLP of the tree + intra-subband model (cgp_out_xo_list, reference
 // graphs/models/LiftingBasedDWT_net.py:282-289,357-365) on the fp16 matrix cores with split-fp16 operands, as ONE
-// register-resident chain per wave: no LDS, no barrier.
+// register-resident chain per wave (LDS holds only a copy of the biases; one barrier, at the start).
 //
 // Per subband g (groups = 3) and pixel:  [81 tree-context features | 12 causal taps of the quantised subband] (the masked
 // context conv folded into layer 0 on the host, _fold_csc_into_cgp)  -> 162 -> 54 -> 18 -> 2 = (sigma, mu), LeakyReLU(0.01)
@@ -15,7 +15,9 @@
 //     (k = 8 half + j  <->  output row 16 s + 8 (j >> 2) + 4 half + (j & 3); MI355X guide, "an accumulator tile as the next
 //     MFMA's operand").  The next layer's WEIGHTS are packed in that permuted order, so no lane ever moves a value:
 //     bias + LeakyReLU + split happen in place.
-//   * weight fragments are streamed per wave from L2 (1 KB coalesced per load, pre-packed in step order, ring of 4).
+//   * weight fragments are streamed per wave from L2 (1 KB coalesced per load, pre-packed in step order, ring of 4 kept
+//     three steps ahead by a sched_barrier after each load: left alone, the scheduler sinks the loads to their uses).
+//   * one 32-pixel block per wave, two waves per SIMD: the partner wave computes while a wave waits for its inputs.
 // Scales: every operand tensor is multiplied by a power of two before the split so that it cannot overflow fp16; the
 // activations' bounds come from the wave's input maximum and the layers' max row L1 norms (fp16's exponent keeps the full
 // 22-bit split precision over 18 binades, so a loose bound costs nothing).
