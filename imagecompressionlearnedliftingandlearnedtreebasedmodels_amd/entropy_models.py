@@ -199,6 +199,60 @@ class EntropyBottleneck(_EntropyModelBase):
         bits, q = ops.factorized_rate(xi, self.packed()[None].contiguous(), noise)
         return q[0], torch.exp2(-bits[0])
 
+    # ---- real coding (compressai EntropyBottleneck.update / compress / decompress): the tables are a few hundred numbers per
+    # channel, built on the host in float32 like compressai's; the symbols are produced on the GPU
+    def _logits_cumulative(self, inputs):
+        """compressai EntropyBottleneck._logits_cumulative (stop_gradient): inputs (C,1,N) -> logits (C,1,N)."""
+        import torch.nn.functional as F
+        logits = inputs
+        for i in range(len(self.filters) + 1):
+            logits = torch.matmul(F.softplus(getattr(self, "_matrix%d" % i).detach()), logits)
+            logits = logits + getattr(self, "_bias%d" % i).detach()
+            if i < len(self.filters):
+                logits = logits + torch.tanh(getattr(self, "_factor%d" % i).detach()) * torch.tanh(logits)
+        return logits
+
+    def _get_medians(self):
+        return self.quantiles[:, :, 1:2].detach()                       # (C,1,1)
+
+    def update(self, force=False):
+        """compressai EntropyBottleneck.update: one quantised CDF per channel from the learned density, centred on the
+        channel's median; offsets = -ceil(median - lower quantile)."""
+        if self._offset.numel() > 0 and not force:
+            return False
+        dev = self.quantiles.device
+        with torch.no_grad():
+            q = self.quantiles.detach()
+            medians = q[:, 0, 1]
+            minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+            maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+            pmf_start = medians - minima
+            pmf_length = maxima + minima + 1
+            max_length = int(pmf_length.max())
+            samples = torch.arange(max_length, device=dev)[None, :] + pmf_start[:, None, None]      # (C,1,N)
+            lower = self._logits_cumulative(samples - 0.5)
+            upper = self._logits_cumulative(samples + 0.5)
+            sign = -torch.sign(lower + upper)
+            pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+            tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+            self._quantized_cdf = self._pmf_to_cdf(pmf.cpu(), tail_mass.cpu(), pmf_length.cpu(), max_length).to(dev)
+            self._offset = (-minima).int().to(dev)
+            self._cdf_length = (pmf_length + 2).int().to(dev)
+        return True
+
+    def symbols_and_indexes(self, x):
+        """x (..., C, h, w) -> (symbols = round(x - median) int32, indexes = channel number int32), same shape
+        (compressai compress: quantize(x, "symbols", medians), build_indexes)."""
+        C = self.channels
+        med = self._get_medians().reshape(C, 1, 1).to(x.device)
+        sym = torch.round(x - med).int()
+        idx = torch.arange(C, device=x.device, dtype=torch.int32).reshape(C, 1, 1).expand_as(x).contiguous()
+        return sym, idx
+
+    def dequantize_symbols(self, sym):
+        """symbols (..., C, h, w) -> values = symbol + median (compressai decompress)."""
+        return sym.float() + self._get_medians().reshape(self.channels, 1, 1).to(sym.device)
+
     def loss(self):
         """Auxiliary quantile loss |logits(quantiles) - target| (compressai EntropyBottleneck.loss): a 3-point host-side
         evaluation per channel, not on the per-batch hot path."""

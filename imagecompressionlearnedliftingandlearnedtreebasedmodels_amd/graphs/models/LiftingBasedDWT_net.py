@@ -207,6 +207,71 @@ class onlyEZWT(_EntropyLayerBase):
         si_list.reverse()
         return si_xe, si_list, xe_q, q_list
 
+    # ---------------------------------------------------------------- real entropy coding (EXTENSION: the reference's
+    # onlyEZWT defines only forward, :759-840; this is what its compress would be with compressai's own
+    # EntropyBottleneck.compress / GaussianConditional.compress).  Every level's (sigma, mu) depend only on the decoded parent
+    # level, so each tensor is coded in ONE parallel pass (no wavefront): xe and the coarsest level with the factorized
+    # priors, the finer levels with the Gaussian tables of get_scale_table().  One rANS stream per (plane, image, tensor).
+    @staticmethod
+    def _level_params(layers, i, parent):
+        seqs = [l.plc_list[i] for l in layers]
+        t = _plc_pair([s[0] for s in seqs], [s[2] for s in seqs], parent, ops.ACT_LRELU)
+        return _conv([s[4] for s in seqs], t)                                       # (P,B,6,h,w): sigma even, mu odd
+
+    @staticmethod
+    def compress_planes(layers, out_xe, out_xo_list):
+        """-> (strings_xe[p][b], [strings_xo[p][b]] finest first, xe_q, [xo_q] finest first)."""
+        from . import entropy_coding as ec
+        L = len(out_xo_list)
+        with torch.no_grad():
+            s_xe, xe_q = ec.code_factorized([l.ent_out_xe for l in layers], out_xe, out_xe.shape)
+            s, q = ec.code_factorized([l.ent_out_xo for l in layers], out_xo_list[L - 1], out_xo_list[L - 1].shape)
+            s_list, q_list = [s], [q]
+            for i in range(L - 2, -1, -1):
+                tabs = ec._Tables(layers[0].ent_out_xo_list[i], get_scale_table())
+                for l in layers[1:]:
+                    l.ent_out_xo_list[i].update_scale_table(get_scale_table())
+                ms = onlyEZWT._level_params(layers, i, q)
+                s, q = ec.code_gaussian_parallel([l.ent_out_xo_list[i] for l in layers], ms, out_xo_list[i],
+                                                 out_xo_list[i].shape, tabs)
+                s_list.append(s)
+                q_list.append(q)
+        s_list.reverse()
+        q_list.reverse()
+        return s_xe, s_list, xe_q, q_list
+
+    @staticmethod
+    def decompress_planes(layers, strings_xe, strings_xo_list, shape_xe, shapes_xo):
+        """strings -> (xe, [xo] finest first), bit-identical to compress_planes' dequantised tensors."""
+        from . import entropy_coding as ec
+        L = len(shapes_xo)
+        with torch.no_grad():
+            _, xe = ec.code_factorized([l.ent_out_xe for l in layers], None, shape_xe, strings_xe)
+            _, q = ec.code_factorized([l.ent_out_xo for l in layers], None, shapes_xo[L - 1], strings_xo_list[L - 1])
+            q_list = [q]
+            for i in range(L - 2, -1, -1):
+                tabs = ec._Tables(layers[0].ent_out_xo_list[i], get_scale_table())
+                for l in layers[1:]:
+                    l.ent_out_xo_list[i].update_scale_table(get_scale_table())
+                ms = onlyEZWT._level_params(layers, i, q)
+                _, q = ec.code_gaussian_parallel([l.ent_out_xo_list[i] for l in layers], ms, None, shapes_xo[i], tabs,
+                                                 strings_xo_list[i])
+                q_list.append(q)
+        q_list.reverse()
+        return xe, q_list
+
+    @staticmethod
+    def test_planes(layers, out_xe, out_xo_list):
+        """Encode, then decode FROM THE STRINGS (same contract as the conditioned2 layer's test_planes)."""
+        s_xe, s_xo, _, _ = onlyEZWT.compress_planes(layers, out_xe, out_xo_list)
+        xe, xo = onlyEZWT.decompress_planes(layers, s_xe, s_xo, out_xe.shape, [t.shape for t in out_xo_list])
+        return s_xe, s_xo, xe, xo
+
+    def test(self, out_xe, out_xo_list):
+        s_xe, s_xo, xe, xo = self.test_planes([self], out_xe[None].contiguous(), [t[None].contiguous() for t in out_xo_list])
+        one = lambda rows: rows[0][0] if len(rows[0]) == 1 else rows[0]
+        return one(s_xe), [one(r) for r in s_xo], xe[0], [t[0] for t in xo]
+
 
 class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
     """Tree (parent level) + causal intra-subband context model (LiftingBasedDWT_net.py:233-372)."""
@@ -792,8 +857,9 @@ def compress_planes(nets, x):
     x (P,B,C,H,W) -> (xhat, strings_xe[p][b], [strings_xo[p][b] per level])."""
     em = [n.entropymodel for n in nets]
     if not hasattr(type(em[0]), "test_planes"):
-        raise NotImplementedError("real entropy coding exists for conditioned2ZTsepSubbands only, as in the reference "
-                                  "(the other entropy layers have no test(); LiftingBasedDWT_net.py:145-146 would fail there too)")
+        raise NotImplementedError("real entropy coding exists for conditioned2ZTsepSubbands (as in the reference) and, as an "
+                                  "extension, onlyEZWT; the other entropy layers have no test() (LiftingBasedDWT_net.py:"
+                                  "145-146 would fail there too)")
     out_xe, out_xo = encode_planes([n.autoencoder for n in nets], x)
     s_xe, s_xo, xe_q, xo_q = type(em[0]).test_planes(em, out_xe, out_xo)
     xhat = decode_planes([n.autoencoder for n in nets], xe_q, xo_q)

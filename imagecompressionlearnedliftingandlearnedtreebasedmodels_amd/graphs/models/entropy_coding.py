@@ -179,6 +179,78 @@ def code_tree_level(emodels, plc, cgp_packed, cgp_dims, K, tap_bits, y, shape, t
     return (None if sink.decoding else sink.flush()), out
 
 
+class _FactorizedTables:
+    """The per-channel CDF tables of one EntropyBottleneck as host int32 arrays."""
+
+    def __init__(self, emodel):
+        emodel.update()
+        self.cdf = emodel.quantized_cdf.cpu().numpy().astype(np.int32)
+        self.sizes = emodel.cdf_length.cpu().numpy().astype(np.int32)
+        self.offsets = emodel.offset.cpu().numpy().astype(np.int32)
+
+
+def code_factorized(emodels, y, shape, strings=None):
+    """A tensor coded with a factorized prior (EntropyBottleneck; compressai compress / decompress): every coefficient is
+    independent, so symbols and indexes of the whole tensor are produced in one pass; one rANS stream per (plane, image),
+    raster order, channels outermost.  emodels: one per plane.  -> (strings or None, dequantised (P,B,C,h,w))."""
+    P, B, Cc, H, W = shape
+    out = []
+    strs = []
+    for p in range(P):
+        em = emodels[p]
+        tabs = _FactorizedTables(em)
+        if strings is None:
+            sym, idx = em.symbols_and_indexes(y[p])                                     # (B,C,h,w)
+            sh, ih = sym.cpu().numpy(), idx.cpu().numpy()
+            row = []
+            for b in range(B):
+                e = BufferedRansEncoder()
+                e.encode_with_indexes(sh[b].reshape(-1), ih[b].reshape(-1), tabs.cdf, tabs.sizes, tabs.offsets)
+                row.append(e.flush())
+            strs.append(row)
+            out.append(em.dequantize_symbols(sym))
+        else:
+            dev = em.quantiles.device
+            idx = np.broadcast_to(np.arange(Cc, dtype=np.int32).reshape(Cc, 1, 1), (Cc, H, W)).reshape(-1)
+            syms = np.empty((B, Cc, H, W), dtype=np.int32)
+            for b in range(B):
+                d = RansDecoder()
+                d.set_stream(strings[p][b])
+                syms[b] = d.decode_stream(idx, tabs.cdf, tabs.sizes, tabs.offsets, as_numpy=True).reshape(Cc, H, W)
+            out.append(em.dequantize_symbols(torch.from_numpy(syms).to(dev)))
+    return (strs if strings is None else None), torch.stack(out, 0)
+
+
+def code_gaussian_parallel(emodels, params, y, shape, tables, strings=None):
+    """A level whose (sigma, mu) depend only on already decoded tensors (onlyEZWT: the tree context of the parent level,
+    LiftingBasedDWT_net.py:822-835): fully parallel -- indexes and symbols of the whole tensor in one pass, raster order.
+    params (P,B,2C,h,w): sigma on the even, mu on the odd channels.  -> (strings or None, dequantised (P,B,C,h,w))."""
+    P, B, Cc, H, W = shape
+    sigma, mu = params[:, :, 0::2].contiguous(), params[:, :, 1::2].contiguous()
+    idx = emodels[0].build_indexes(sigma)                                               # (P,B,C,h,w) int32
+    ih = idx.cpu().numpy()
+    if strings is None:
+        sym = torch.round(y - mu).int()
+        sh = sym.cpu().numpy()
+        strs = []
+        for p in range(P):
+            row = []
+            for b in range(B):
+                e = BufferedRansEncoder()
+                e.encode_with_indexes(sh[p, b].reshape(-1), ih[p, b].reshape(-1), tables.cdf, tables.sizes, tables.offsets)
+                row.append(e.flush())
+            strs.append(row)
+        return strs, sym.float() + mu
+    syms = np.empty(ih.shape, dtype=np.int32)
+    for p in range(P):
+        for b in range(B):
+            d = RansDecoder()
+            d.set_stream(strings[p][b])
+            syms[p, b] = d.decode_stream(ih[p, b].reshape(-1), tables.cdf, tables.sizes, tables.offsets,
+                                         as_numpy=True).reshape(ih.shape[2:])
+    return None, torch.from_numpy(syms).to(mu.device).float() + mu
+
+
 def ideal_bits(sym, idx, tables):
     """Code length (bits) of integer symbols under the quantised tables; escapes are not modelled (returns their count)."""
     cdf, sizes, offs = tables.cdf, tables.sizes, tables.offsets
