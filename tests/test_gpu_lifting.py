@@ -163,3 +163,36 @@ def test_composed_path_with_strip_correction_equals_sequential(hw, vertical, mon
         outs.append(out_d.cpu())
     monkeypatch.setenv("LLDWT_LF_DBG", "0")
     assert maxdiff(outs[0], outs[1]) < 2e-6, (hw, vertical)
+
+
+def test_composed_path_equals_sequential_on_random_shapes(monkeypatch):
+    """The same comparison on 24 seeded random image sizes (2 .. 130 rows, 2 .. 210 columns, both pass directions): every
+    combination of missing / partial edge strips, tiles overhanging the image, images narrower than the conv reach."""
+    import random
+    ops, gu = _ops()
+    cfg = dict(model.DEFAULT_CFG, filtersize=5, dwtlevels=1)
+    sds = [filled(weights.autoencoder_template(cfg), "m%d." % p) for p in range(1)]
+    taps, packed = gu.lifting_params(sds)
+    rnd = random.Random(1234)
+    g = torch.Generator().manual_seed(21)
+    worst = 0.0
+    for case in range(24):
+        h, w = rnd.randint(2, 130), rnd.randint(2, 210)
+        vertical = case & 1
+        B = rnd.randint(1, 3)
+        src = torch.rand(1, B, 1, h, w, generator=g) - 0.5
+        dst = torch.rand(1, B, 1, h, w, generator=g) - 0.5
+        src_d, dst_d = gu.dev(src), gu.dev(dst)
+        v = lambda t: ops.view_of(t, B, h, w)
+        outs = []
+        for dbg in ("0", "16"):
+            monkeypatch.setenv("LLDWT_LF_DBG", dbg)
+            out_d = torch.empty_like(dst_d)
+            ops.lift_step(v(src_d), v(dst_d), v(out_d), B, B, h, w, taps[2].contiguous(), packed[:, 1, 0].contiguous(), 16, 5,
+                          vertical, 1.0, 0.1)
+            outs.append(out_d.cpu())
+        monkeypatch.setenv("LLDWT_LF_DBG", "0")
+        d = maxdiff(outs[0], outs[1])
+        worst = max(worst, d)
+        assert d < 2e-6, (case, h, w, vertical, d)
+    print("\n[lifting] composed vs sequential over 24 random shapes: worst difference %.3g" % worst)
