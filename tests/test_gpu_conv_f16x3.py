@@ -184,3 +184,31 @@ def test_wgrad_f16x3_vs_float64_and_fp32_kernel(shape):
     # accumulation semantics: alpha, and += into an existing buffer is the caller's (zeroed here)
     dw2, _ = ops.conv3x3_wgrad_f16x3(x.to(DEV), dy.to(DEV), (P, cout, cin, 3, 3), want_bias=False, alpha=-0.5)
     assert float((dw2 + 0.5 * dw).abs().max()) < 1e-5 * float(dw.abs().max())
+
+
+def test_fused_pair_random_shapes():
+    """lldwt_plc_fused vs the two-launch fp32 engine on 16 seeded random shapes: parent sizes from 1x1 up (tiles overhanging
+    the image both ways), channel counts that leave partial chunks / partial output blocks, several planes and images."""
+    import random
+    ops = _ops()
+    rnd = random.Random(99)
+    g = torch.Generator().manual_seed(8)
+    worst = 0.0
+    for case in range(16):
+        P, B = rnd.randint(1, 2), rnd.randint(1, 3)
+        cmid, cout = rnd.choice([17, 64, 100, 243, 256]), rnd.choice([5, 40, 129, 243])
+        hp, wp = rnd.randint(1, 40), rnd.randint(1, 70)
+        act = rnd.choice([0, 2, 1])
+        parent = (torch.rand(P, B, 3, hp, wp, generator=g) - 0.5) * 4.0
+        w1 = (torch.rand(P, cmid, 3, 3, 3, generator=g) - 0.5) * 0.6
+        b1 = torch.rand(P, cmid, generator=g) - 0.5
+        w2 = (torch.rand(P, cout, cmid, 3, 3, generator=g) - 0.5) * (2.0 / (cmid * 9) ** 0.5)
+        b2 = torch.rand(P, cout, generator=g) - 0.5
+        y = ops.plc_fused(parent.to(DEV), ops.plc_fused_pack1(w1.to(DEV), b1.to(DEV)), ops.conv_f16x3_pack(w2.to(DEV)),
+                          b2.to(DEV), cmid, cout, act=act)
+        t32 = ops.conv2d(parent.to(DEV), w1.to(DEV), b1.to(DEV), 3, act=2, upsample2=True)
+        y32 = ops.conv2d(t32, w2.to(DEV), b2.to(DEV), 3, act=act)
+        d = float((y - y32).abs().max()) / max(float(y32.abs().max()), 1e-6)
+        worst = max(worst, d)
+        assert d < 6e-6, (case, P, B, cmid, cout, hp, wp, act, d)      # two fp32-accurate paths: a few 1e-6 apart
+    print("\n[plc_fused] vs the fp32 two-launch engine over 16 random shapes: worst relative difference %.3g" % worst)
