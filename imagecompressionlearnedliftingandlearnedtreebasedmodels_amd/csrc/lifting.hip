@@ -1344,7 +1344,11 @@ static int build_program(lldwt_lift_op* ops, int max_ops, int64_t Z, int64_t H, 
             two_stage(ops, n, max_ops, false, Le, Lo, vLL, vHL, t2L, t2H, hh, wh, 0, blk, so, Z, C);
             if (scale) { push_scale(ops, n, max_ops, 1, vHL, vHL, hh, wh); push_scale(ops, n, max_ops, 2, vLL, vLL, hh, wh); }
             SymView He = sv(B_HROW, 0, hh * w, w, 2), Ho = sv(B_HROW, 1, hh * w, w, 2);          // columns of H (:43-51)
-            two_stage(ops, n, max_ops, false, He, Ho, vLH, vHH, t2L, t2H, hh, wh, 0, blk, so, Z, C);
+            // its own temporaries (the second halves of tmpL / tmpH, free during the column passes): the L and H column
+            // passes are independent, and the eval executor runs step k of both in ONE launch (run_program)
+            const int64_t toff = scale ? 0 : Z * sub;
+            SymView u2L = sv(B_TMPL, toff, sub, wh, 1), u2H = sv(B_TMPH, toff, sub, wh, 1);
+            two_stage(ops, n, max_ops, false, He, Ho, vLH, vHH, u2L, u2H, hh, wh, 0, blk, so, Z, C);
             if (scale) { push_scale(ops, n, max_ops, 1, vHH, vHH, hh, wh); push_scale(ops, n, max_ops, 2, vLH, vLH, hh, wh); }
         }
     } else {
@@ -1366,7 +1370,9 @@ static int build_program(lldwt_lift_op* ops, int max_ops, int64_t Z, int64_t H, 
             inL = vLH; inH = vHH;
             if (scale) { push_scale(ops, n, max_ops, 4, vLH, sL, hh, wh); push_scale(ops, n, max_ops, 3, vHH, sH, hh, wh); inL = sL; inH = sH; }
             SymView He = sv(B_HROW, 0, hh * w, w, 2), Ho = sv(B_HROW, 1, hh * w, w, 2);          // (LH,HH) -> H (:28-33)
-            two_stage(ops, n, max_ops, true, inL, inH, He, Ho, t2L, t2H, hh, wh, 0, blk, so, Z, C);
+            const int64_t toff = scale ? 0 : Z * sub;                                              // see the forward program
+            SymView u2L = sv(B_TMPL, toff, sub, wh, 1), u2H = sv(B_TMPH, toff, sub, wh, 1);
+            two_stage(ops, n, max_ops, true, inL, inH, He, Ho, u2L, u2H, hh, wh, 0, blk, so, Z, C);
             SymView vL = sv(B_LROW, 0, hh * w, w, 1), vH = sv(B_HROW, 0, hh * w, w, 1);
             SymView tL = sv(B_TMPL, 0, hh * w, w, 1), tH = sv(B_TMPH, 0, hh * w, w, 1);
             SymView A = sv(bout, 0, h * w, 2 * w, 1), Bv = sv(bout, w, h * w, 2 * w, 1);        // (L,H) -> rows (:35-37)
@@ -1396,9 +1402,56 @@ struct RunCtx {
     hipStream_t st;
 };
 
+// ops[i .. i+3] and ops[i+4 .. i+7] are the two independent column passes (L and H) of one level: same geometry, same
+// blocks, different buffers (build_program gives the second pass its own temporaries)
+static bool column_pass_pair(const lldwt_lift_op* ops, int n, int i) {
+    if (i + 8 > n) return false;
+    for (int k = 0; k < 4; ++k) {
+        const lldwt_lift_op &a = ops[i + k], &b = ops[i + 4 + k];
+        if (a.kind != 0 || b.kind != 0 || a.vertical != 0 || b.vertical != 0 || a.h != b.h || a.w != b.w || a.tap != b.tap ||
+            a.block != b.block || a.is_u != b.is_u || a.sign != b.sign)
+            return false;
+        if (a.h != ops[i].h || a.w != ops[i].w) return false;
+        if (a.buf_dout == b.buf_dout && a.off_dout == b.off_dout) return false;
+    }
+    // the second pass must not touch what the first one reads or writes (and vice versa): distinct (buffer, offset) pairs
+    for (int k = 0; k < 4; ++k)
+        for (int m = 0; m < 4; ++m) {
+            const lldwt_lift_op &a = ops[i + k], &b = ops[i + 4 + m];
+            auto same = [](int ba, int64_t oa, int bb, int64_t ob) { return ba == bb && oa == ob; };
+            if (same(a.buf_dout, a.off_dout, b.buf_src, b.off_src) || same(a.buf_dout, a.off_dout, b.buf_din, b.off_din) ||
+                same(a.buf_dout, a.off_dout, b.buf_dout, b.off_dout) || same(b.buf_dout, b.off_dout, a.buf_src, a.off_src) ||
+                same(b.buf_dout, b.off_dout, a.buf_din, a.off_din))
+                return false;
+        }
+    return true;
+}
+
 static int run_program(const lldwt_lift_op* ops, int n, float* const* bases, const RunCtx& c) {
+    const bool fused_eval = g_lift_mode == 1 && !c.linear && c.saved == nullptr && c.C == LF_C && c.K == LF_K;
     for (int i = 0; i < n; ++i) {
         const lldwt_lift_op& o = ops[i];
+        if (fused_eval && o.kind == 0 && column_pass_pair(ops, n, i)) {
+            // step k of the L pass and step k of the H pass in one launch (twice the tiles: the deep levels' launches are
+            // too small to fill the chip on their own)
+            const PackOff po = pack_off(c.C, c.K);
+            for (int k = 0; k < 4; ++k) {
+                const lldwt_lift_op &a = ops[i + k], &b = ops[i + 4 + k];
+                auto views = [&](const lldwt_lift_op& q) {
+                    const lldwt_view s_ = resolve(bases, q.buf_src, q.off_src, q.sz_src, q.sy_src, q.sx_src);
+                    const lldwt_view d_ = resolve(bases, q.buf_din, q.off_din, q.sz_din, q.sy_din, q.sx_din);
+                    const lldwt_view o_ = resolve(bases, q.buf_dout, q.off_dout, q.sz_dout, q.sy_dout, q.sx_dout);
+                    return LiftF16Views{s_.p, s_.sz, s_.sy, s_.sx, d_.p, d_.sz, d_.sy, d_.sx, o_.p, o_.sz, o_.sy, o_.sx};
+                };
+                const float* pk = c.packed + ((int64_t)a.block * 2 + a.is_u) * c.total;
+                const LiftF16Views va = views(a), vb = views(b);
+                int r = lift_f16_step2(va, &vb, c.Z, c.batch, a.h, a.w, c.taps + (int64_t)a.tap * c.planes * 3, pk, c.pstride,
+                                       po.orient, po.f16, a.vertical, a.sign, c.rw, c.st);
+                if (r) return r;
+            }
+            i += 7;
+            continue;
+        }
         lldwt_view src = resolve(bases, o.buf_src, o.off_src, o.sz_src, o.sy_src, o.sx_src);
         lldwt_view dout = resolve(bases, o.buf_dout, o.off_dout, o.sz_dout, o.sy_dout, o.sx_dout);
         if (o.kind != 0) {

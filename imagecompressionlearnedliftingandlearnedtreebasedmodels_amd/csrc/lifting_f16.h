@@ -38,5 +38,10 @@ struct LiftF16Views {
 int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, int64_t w, const float* taps,
                   const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical, float sign, float rw,
                   hipStream_t st);
+// the same step for TWO independent view sets of the same geometry and parameters in one launch (v2 may be null): images
+// 0 .. Z-1 use v, images Z .. 2Z-1 use *v2
+int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int64_t batch, int64_t h, int64_t w,
+                   const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical,
+                   float sign, float rw, hipStream_t st);
 
 }  // namespace lldwt

@@ -178,6 +178,11 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
 
 struct LfArgs {
     LiftF16Views v;
+    const float* src2;    // second view set (images zsplit .. of the launch): same geometry, parameters and row / column
+    const float* din2;    // strides as v -- only the bases and the image strides differ
+    float* dout2;
+    int64_t src2_sz, din2_sz, dout2_sz;
+    int64_t zsplit;       // number of images of the first set
     const float* taps;
     const float* packed;
     int64_t pstride;
@@ -366,6 +371,16 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int h = a.h, w = a.w;
     const int tpi = a.tiles_x * a.tiles_y;                     // tiles per image
 
+    // image z of the launch -> its view set and its image index inside that set
+    auto view_of_z = [&](int64_t z, int64_t& zz) -> LiftF16Views {          // by value: scalar selects, no stack
+        const bool second = z >= a.zsplit;
+        zz = second ? z - a.zsplit : z;
+        LiftF16Views r = a.v;
+        r.src = second ? a.src2 : a.v.src;     r.src_sz = second ? a.src2_sz : a.v.src_sz;
+        r.din = second ? a.din2 : a.v.din;     r.din_sz = second ? a.din2_sz : a.v.din_sz;
+        r.dout = second ? a.dout2 : a.v.dout;  r.dout_sz = second ? a.dout2_sz : a.v.dout_sz;
+        return r;
+    };
     auto decode = [&](int64_t t, int64_t& z, int& y0, int& x0) {
         z = t / tpi;
         const int pos = (int)((t - z * tpi + z * 37) % tpi);
@@ -374,13 +389,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         x0 = (pos - ty * a.tiles_x) * TW;
     };
     // branch-free: every load goes to a clamped (valid) address; P0 applies the zero padding when it consumes the values
-    const int ssy = (int)a.v.src_sy, ssx = (int)a.v.src_sx;   // per-image offsets fit 32 bits (checked on the host)
     auto fetch = [&](int64_t t, int tid, LfPre& pr) {
         const int oy_ = tid / TW, ox_ = tid - oy_ * TW;        // this thread's output pixel inside a tile
         int64_t z;
         int y0, x0;
         decode(t, z, y0, x0);
-        const float* sp = a.v.src + z * a.v.src_sz;
+        int64_t zz;
+        const LiftF16Views vw = view_of_z(z, zz);
+        const float* sp = vw.src + zz * vw.src_sz;
+        const int ssy = (int)vw.src_sy, ssx = (int)vw.src_sx;   // per-image offsets fit 32 bits (checked on the host)
         const int dyv = a.vertical ? 1 : 0, dxv = 1 - dyv;
 #pragma unroll
         for (int k = 0; k < NS / NTH; ++k) {
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             pr.p[k] = sp[min(gy + dyv, h - 1) * ssy + min(gx + dxv, w - 1) * ssx];
         }
         const int gy = min(y0 + oy_, h - 1), gx = min(x0 + ox_, w - 1);
-        pr.din = a.v.din[z * a.v.din_sz + gy * (int)a.v.din_sy + gx * (int)a.v.din_sx];
+        pr.din = vw.din[zz * vw.din_sz + gy * (int)vw.din_sy + gx * (int)vw.din_sx];
     };
     // the fetched operands wait for their tile in LDS (each thread's own ten floats, written and read back by that thread
     // only: no barrier), not in registers carried around the tile loop (the register file is full in P2)
@@ -425,7 +442,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int y0, x0;
     decode(tile_i, z, y0, x0);
     const int64_t stamp_tile = (z * a.tiles_y + y0 / TH) * a.tiles_x + x0 / TW;
-    const int plane = (int)(z / a.batch);
+    int64_t zv;
+    const LiftF16Views vout = view_of_z(z, zv);
+    const int plane = (int)(zv / a.batch);
     const float* pk = a.packed + (int64_t)plane * a.pstride;
     const float* bias = pk + a.orient_fp32;
     const _Float16* frag = reinterpret_cast<const _Float16*>(pk + a.f16);
@@ -623,14 +642,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool interior = y0 >= 2 && y0 + TH + 2 <= h && x0 >= 2 && x0 + TW + 2 <= w;
     // strips in t3-region coordinates (20 x 36, origin (y0 - 2, x0 - 2)): rows / columns whose image coordinate is
     // -2, -1 or h, h + 1 (w, w + 1)
-    int nR = 0, nC = 0, Rl[4] = {0, 0, 0, 0}, Cl[4] = {0, 0, 0, 0};
+    int nR = 0, nC = 0, Rl0 = 0, Rl1 = 0, Rl2 = 0, Rl3 = 0, Cl0 = 0, Cl1 = 0, Cl2 = 0, Cl3 = 0;   // scalars, not arrays: no stack
     if (!SEQ && !interior) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int gy = k < 2 ? k - 2 : h + k - 2, gx = k < 2 ? k - 2 : w + k - 2;
             const int r = gy - (y0 - 2), c = gx - (x0 - 2);
-            if (r >= 0 && r < TH + 4) { Rl[nR == 0 ? 0 : nR == 1 ? 1 : nR == 2 ? 2 : 3] = r; ++nR; }
-            if (c >= 0 && c < TW + 4) { Cl[nC == 0 ? 0 : nC == 1 ? 1 : nC == 2 ? 2 : 3] = c; ++nC; }
+            if (r >= 0 && r < TH + 4) { if (nR == 0) Rl0 = r; else if (nR == 1) Rl1 = r; else if (nR == 2) Rl2 = r; else Rl3 = r; ++nR; }
+            if (c >= 0 && c < TW + 4) { if (nC == 0) Cl0 = c; else if (nC == 1) Cl1 = c; else if (nC == 2) Cl2 = c; else Cl3 = c; ++nC; }
         }
     }
     const int nF = nR * R3W + nC * (TH + 4);
@@ -659,11 +678,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (jc < nR * R3W) {
                     const int ir = jc / R3W;
                     c = jc - ir * R3W;
-                    r = ir == 0 ? Rl[0] : ir == 1 ? Rl[1] : ir == 2 ? Rl[2] : Rl[3];
+                    r = ir == 0 ? Rl0 : ir == 1 ? Rl1 : ir == 2 ? Rl2 : Rl3;
                 } else {
                     const int q = jc - nR * R3W, ic = q / (TH + 4);
                     r = q - ic * (TH + 4);
-                    c = ic == 0 ? Cl[0] : ic == 1 ? Cl[1] : ic == 2 ? Cl[2] : Cl[3];
+                    c = ic == 0 ? Cl0 : ic == 1 ? Cl1 : ic == 2 ? Cl2 : Cl3;
                 }
                 const floatx4 acc = conv16_tile_stream<R2W, N2>(lds + LDS_T2, (r * R2W + c) * 16 + halfsel * (N2 * 16), hi_tap,
                                                                 frag + LF_H_C3 + lane * 8);
@@ -759,7 +778,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int dy = 0; dy < LF_K; ++dy) {
                     const int r = oy + dy, gyy = gy - 2 + dy;
                     if (gyy < 0 || gyy >= h) {
-                        const int ir = r == Rl[0] ? 0 : r == Rl[1] ? 1 : r == Rl[2] ? 2 : 3;
+                        const int ir = r == Rl0 ? 0 : r == Rl1 ? 1 : r == Rl2 ? 2 : 3;
                         const float* up = U + (ir * R3W + ox) * LF_KK + dy * LF_K;
 #pragma unroll
                         for (int dx = 0; dx < LF_K; ++dx) corr += up[dx * (LF_KK + 1)];
@@ -768,7 +787,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int dx = 0; dx < LF_K; ++dx) {
                             const int c = ox + dx, gxx = gx - 2 + dx;
                             if (gxx < 0 || gxx >= w) {
-                                const int ic = c == Cl[0] ? 0 : c == Cl[1] ? 1 : c == Cl[2] ? 2 : 3;
+                                const int ic = c == Cl0 ? 0 : c == Cl1 ? 1 : c == Cl2 ? 2 : 3;
                                 corr += U[(nR * R3W + ic * (TH + 4) + r) * LF_KK + dy * LF_K + dx];
                             }
                         }
@@ -779,7 +798,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float skip = S[(oy + 8) * SW + ox + 8];
             const float din = din_pre;
             if (valid)
-                a.v.dout[z * a.v.dout_sz + (int64_t)gy * a.v.dout_sy + (int64_t)gx * a.v.dout_sx] = din + a.sign * (skip + a.rw * net);
+                vout.dout[zv * vout.dout_sz + (int64_t)gy * vout.dout_sy + (int64_t)gx * vout.dout_sx] = din + a.sign * (skip + a.rw * net);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more) stage(tid, nxt);
@@ -898,7 +917,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             net = net * inv4 + bias[a.b4];
             const float skip = S[(oy + 8) * SW + ox + 8];
             const float din = din_pre;
-            a.v.dout[z * a.v.dout_sz + (int64_t)gy * a.v.dout_sy + (int64_t)gx * a.v.dout_sx] = din + a.sign * (skip + a.rw * net);
+            vout.dout[zv * vout.dout_sz + (int64_t)gy * vout.dout_sy + (int64_t)gx * vout.dout_sx] = din + a.sign * (skip + a.rw * net);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -922,6 +941,12 @@ int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float
 int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, int64_t w, const float* taps,
                   const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical, float sign, float rw,
                   hipStream_t st) {
+    return lift_f16_step2(v, nullptr, Z, batch, h, w, taps, packed, pstride, fp32_orient_floats, f16_off, vertical, sign, rw, st);
+}
+
+int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int64_t batch, int64_t h, int64_t w,
+                   const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical,
+                   float sign, float rw, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)k_lift_fused_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess ||
@@ -933,6 +958,15 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
     }
     LfArgs a;
     a.v = v;
+    if (v2 && (v2->src_sy != v.src_sy || v2->src_sx != v.src_sx || v2->din_sy != v.din_sy || v2->din_sx != v.din_sx ||
+               v2->dout_sy != v.dout_sy || v2->dout_sx != v.dout_sx)) {
+        set_error("lift_f16_step2: the two view sets must share their row / column strides");
+        return LLDWT_EINVAL;
+    }
+    a.src2 = v2 ? v2->src : v.src; a.din2 = v2 ? v2->din : v.din; a.dout2 = v2 ? v2->dout : v.dout;
+    a.src2_sz = v2 ? v2->src_sz : v.src_sz; a.din2_sz = v2 ? v2->din_sz : v.din_sz; a.dout2_sz = v2 ? v2->dout_sz : v.dout_sz;
+    a.zsplit = Z;
+    const int64_t Zl = v2 ? 2 * Z : Z;               // images of the launch
     a.taps = taps;
     a.packed = packed;
     a.pstride = pstride;
@@ -951,13 +985,14 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
     const char* stp = getenv("LLDWT_LF_STAMPS");
     a.stamps = stp ? reinterpret_cast<unsigned long long*>(strtoull(stp, nullptr, 0)) : nullptr;
     auto fits = [&](int64_t sy, int64_t sx) { return llabs(sy) * h + llabs(sx) * w < (int64_t)1 << 31; };
-    if (!fits(v.src_sy, v.src_sx) || !fits(v.din_sy, v.din_sx) || !fits(v.dout_sy, v.dout_sx)) {
+    if (!fits(v.src_sy, v.src_sx) || !fits(v.din_sy, v.din_sx) || !fits(v.dout_sy, v.dout_sx) ||
+        (v2 && (!fits(v2->src_sy, v2->src_sx) || !fits(v2->din_sy, v2->din_sx) || !fits(v2->dout_sy, v2->dout_sx)))) {
         set_error("lift_f16_step: per-image strides beyond 32-bit offsets");
         return LLDWT_EINVAL;
     }
     a.tiles_x = (int)cdiv(w, TW);
     a.tiles_y = (int)cdiv(h, TH);
-    a.ntiles = (int64_t)a.tiles_x * a.tiles_y * Z;
+    a.ntiles = (int64_t)a.tiles_x * a.tiles_y * Zl;
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
