@@ -477,7 +477,7 @@ def main():
         out["roofline_lifting"] = {
             "bound": "mfma", "unit": "TFLOP/s",
             "kernel": "learned lifting forward, %d levels (one lldwt_lifting_forward call per step: %s)" % (
-                c["levels"], "48 persistent k_lift_fused_f16 launches, split-fp16" if f16l else "fp32 MFMA launches"),
+                c["levels"], "persistent k_lift_fused_f16 launches (the L / H column passes of a level share a launch), split-fp16" if f16l else "fp32 MFMA launches"),
             "ms_per_step": ms2 / len(dom2["events"]), "calls": len(dom2["events"]),
             "fp32_equivalent_tflops": tf2, "frac_of_fp32_mfma_peak": tf2 / F32_MFMA_PEAK_TFLOPS,
             "achieved": (3.0 if f16l else 1.0) * tf2, "peak": F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS,
