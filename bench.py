@@ -431,9 +431,14 @@ def main():
             roof["peak"] = F16_MFMA_PEAK_TFLOPS
             roof["achieved"] = 3.0 * achieved
             roof["frac"] = 3.0 * achieved / F16_MFMA_PEAK_TFLOPS
-            roof["algorithmic_flop_per_launch"] = 3.0 * dom["work"] / n_launch
+            lpf = 8 * c["levels"]             # kernel launches per forward call (4 row + 4 paired column steps per level)
+            roof["launches_per_forward"] = lpf
+            roof["launches"] = lpf * n_launch
+            roof["avg_launch_ms"] = dom_ms / roof["launches"]
+            roof["algorithmic_flop_per_launch"] = 3.0 * dom["work"] / roof["launches"]
             roof["peak_note"] = ("peak = dense fp16 MFMA (2.5 PFLOP/s); achieved = 3 fp16 products per fp32 MAC x the "
-                                 "transform's algorithmic MACs (SURVEY 8d) / HIP-event time of the whole forward call")
+                                 "transform's algorithmic MACs (SURVEY 8d) / HIP-event time of the whole forward call "
+                                 "(avg_launch_ms = that time / the call's kernel launches)")
     if has_plc:
         mode = ops.plc_mode()
         roof["arithmetic"] = mode
@@ -474,7 +479,7 @@ def main():
         tf2 = dom2["work"] / (ms2 * 1e-3) / 1e12
         from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import _lib as _L2
         f16l = _L2.load().lldwt_get_lift_mode() == 1
-        out["roofline_lifting"] = {
+        lift_roof = {
             "bound": "mfma", "unit": "TFLOP/s",
             "kernel": "learned lifting forward, %d levels (one lldwt_lifting_forward call per step: %s)" % (
                 c["levels"], "persistent k_lift_fused_f16 launches (the L / H column passes of a level share a launch), split-fp16" if f16l else "fp32 MFMA launches"),
@@ -483,6 +488,28 @@ def main():
             "achieved": (3.0 if f16l else 1.0) * tf2, "peak": F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS,
             "frac": (3.0 if f16l else 1.0) * tf2 / (F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS),
             "note": "algorithmic MACs of the transform (SURVEY 8d), halo recomputation not counted; 3 fp16 products per MAC"}
+        # kernel launches of one forward call: per level 4 row-pass steps + 4 column steps (the L and H column passes share
+        # a launch); the fp32 path takes 3 launches for each of the 12 steps of a level.  HIP events bracket the whole call.
+        lpf = (8 if f16l else 36) * c["levels"]
+        lift_roof["launches_per_forward"] = lpf
+        lift_roof["launches"] = lpf * len(dom2["events"])
+        lift_roof["avg_launch_ms"] = ms2 / lift_roof["launches"]
+        lift_roof["algorithmic_flop_per_launch"] = (3.0 if f16l else 1.0) * dom2["work"] / lift_roof["launches"]
+        lift_roof["traffic"], lift_roof["traffic_source"] = None, None
+        try:
+            with open(tpath) as f:
+                tl = json.load(f).get("lifting")
+            if tl and a.config == 2 and not c["overrides"] and f16l:
+                lift_roof["traffic"] = tl["traffic_bytes_per_forward"] / lpf
+                lift_roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), average over the launches of "
+                                               "one forward call; profiles/r02_b_pmc_per_kernel.csv")
+        except (OSError, ValueError, KeyError):
+            pass
+        # `roofline` is the kernel family that took more of the timed region; the other one is reported beside it
+        if ms2 > dom_ms:
+            out["roofline"], out["roofline_second"] = lift_roof, roof
+        else:
+            out["roofline_second"] = lift_roof
     if a.train_steps > 0:
         try:
             out["train"] = train_leg(a, c, dev, rank, world_seen, x)

@@ -66,6 +66,15 @@ def main():
                             "(MI355X guide), so the L2->CU weight traffic is about twice its share of this figure",
               "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 "
                         "--warmup 1 --train-steps 0 --no-cpu-baseline --no-hbm-kernels; profiles/r02_b_pmc_per_kernel.csv"}
+        lk = [k2 for k2 in fetch if "k_lift_fused_f16" in k2]
+        if lk:
+            k2 = lk[0]
+            steps_pmc = 2.0                                    # the PMC passes run --steps 1 --warmup 1
+            tj["lifting"] = {"kernel": k2, "launches_per_forward": nf[k2] / steps_pmc,
+                             "fetch_bytes_per_forward": fetch[k2]["FETCH_SIZE"] * 1024.0 / steps_pmc,
+                             "write_bytes_per_forward": write[k2]["WRITE_SIZE"] * 1024.0 / steps_pmc,
+                             "traffic_bytes_per_forward": (fetch[k2]["FETCH_SIZE"] + write[k2]["WRITE_SIZE"]) * 1024.0 / steps_pmc,
+                             "note": "sum over the launches of ONE lldwt_lifting_forward call (4 B/lane loads: no FETCH_SIZE correction)"}
         json.dump(tj, open(os.path.join(OUT, "traffic_current.json"), "w"), indent=1)
         json.dump(tj, open(os.path.join(OUT, "r02_traffic.json"), "w"), indent=1)
         print(json.dumps(tj))
