@@ -244,3 +244,33 @@ def test_cdf97_vs_pywt_and_round_trip():
     for i in range(3):
         assert maxdiff(yh[i][0].cpu(), oyh[i]) < 5e-5, i
     assert maxdiff(ops.cdf97_inverse(ll, yh), rag) < 5e-5
+
+
+@pytest.mark.parametrize("shape,levels", [((1, 8, 3, 512, 512), 4), ((1, 2, 1, 144, 200), 3), ((1, 1, 3, 64, 64), 4),
+                                          ((3, 2, 1, 96, 160), 5), ((1, 1, 1, 1088, 320), 2), ((1, 5, 1, 80, 72), 3)])
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_cdf97_one_launch_equals_per_level(shape, levels, mode, monkeypatch):
+    """The one-launch transforms (k_cdf97_fwd_all / k_cdf97_inv_all: tiles of every level in one grid, ordered by per-tile flags)
+    run the same tile bodies as the per-level launches: bit-identical subbands and reconstruction.  Repeated on the same (shared, dirty) workspace with
+    another plane count in between, so flags of earlier calls are lying around."""
+    ops, gu = _ops()
+    g = torch.Generator().manual_seed(levels * 1000 + shape[-1])
+    x = gu.dev(torch.rand(*shape, generator=g) - 0.5)
+    monkeypatch.setenv("LLDWT_CDF97_FUSE", "0")
+    ll0, yh0 = ops.cdf97_forward(x, levels)
+    xr0 = ops.cdf97_inverse(ll0, yh0)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("LLDWT_CDF97_FUSE", mode)
+    for rep in range(3):
+        ll1, yh1 = ops.cdf97_forward(x, levels)
+        assert torch.equal(ll0, ll1), rep
+        for a, b in zip(yh0, yh1):
+            assert torch.equal(a, b), rep
+        assert torch.equal(ops.cdf97_inverse(ll1, yh1), xr0), rep
+        # another geometry on the same workspace between the repeats
+        other = gu.dev(torch.rand(1, 1 + rep, 1, 128, 64, generator=g))
+        oll, oyh = ops.cdf97_forward(other, 3)
+        rl, ryh = cdf97.dwt_forward(other[0].cpu(), 3)
+        assert maxdiff(oll[0].cpu(), rl) < 5e-5
+        assert maxdiff(oyh[2][0].cpu(), ryh[2]) < 5e-5
+    assert maxdiff(ops.cdf97_inverse(ll1, yh1), x) < 5e-5

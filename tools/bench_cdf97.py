@@ -1,0 +1,45 @@
+"""Times the fixed CDF 9/7 transform at the BASELINE batch (8x3x512x512, 4 levels): per-level launches against the one-launch
+kernels (LLDWT_CDF97_FUSE=0/1), HIP-event time per call and host time per call (a call that is host-bound shows equal numbers).
+  python tools/bench_cdf97.py [batch] [size] [levels]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+dev = torch.device("cuda:0")
+x = torch.rand(1, B, 3, S, S, device=dev) - 0.5
+nbytes = 2 * x.numel() * 4
+
+
+def timeit(fn, iters=200):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    host = (time.perf_counter() - t0) / iters
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3, host
+
+
+out = {"shape": list(x.shape), "levels": L, "algorithmic_bytes": nbytes}
+for fuse in os.environ.get("CDF_MODES", "0,1,2,3").split(","):
+    os.environ["LLDWT_CDF97_FUSE"] = fuse
+    ll, yh = ops.cdf97_forward(x, L)
+    tf, hf = timeit(lambda: ops.cdf97_forward(x, L))
+    ti, hi = timeit(lambda: ops.cdf97_inverse(ll, yh))
+    out["fuse" + fuse] = {"forward_us": tf * 1e6, "forward_host_us": hf * 1e6, "forward_GBs": nbytes / tf / 1e9,
+                          "inverse_us": ti * 1e6, "inverse_host_us": hi * 1e6, "inverse_GBs": nbytes / ti / 1e9}
+print(json.dumps(out))
