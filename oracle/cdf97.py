@@ -68,24 +68,58 @@ def _sfb1d(lo, hi, dim):
     return torch.roll(y, 1 - L // 2, dims=dim)
 
 
-def dwt_forward(x, levels):
-    """-> (Yl, [Yh_0..]) with Yh_i (B, C, 3, h, w) = (LH, HL, HH), finest first."""
+def _afb1d_periodic(x, dim):
+    """The periodic analysis itself, for any even length: lo[k] = sum_m dec_lo[m] x[(2k + 5 - m) mod N] (same for hi).
+    Equals ``_afb1d`` whenever N >= L = 10; for the shorter level inputs (2, 4, 6, 8 samples) ``_afb1d``'s single fold of the
+    linear convolution drops the taps that wrap more than one period (what pytorch_wavelets' afb1d computes, restated from its
+    source; library absent -> unpinned), whereas PyWavelets' periodization and the HIP kernels use the formula here
+    (tests/golden/cdf97_pywt_small.npz)."""
+    N = x.shape[dim]
+    assert N % 2 == 0
+    k = torch.arange(N // 2)
+    lo = hi = 0
+    for m in range(L):
+        v = x.index_select(dim, (2 * k + 5 - m) % N)
+        lo = lo + DEC_LO[m] * v
+        hi = hi + DEC_HI[m] * v
+    return lo, hi
+
+
+def _sfb1d_periodic(lo, hi, dim):
+    """x[n] = sum over taps t with (n + 4 - t) mod N even of lo[q/2] rec_lo[t] + hi[q/2] rec_hi[t], q = (n + 4 - t) mod N."""
+    N = 2 * lo.shape[dim]
+    n = torch.arange(N)
+    y = 0
+    for t in range(L):
+        q = (n + 4 - t) % N
+        even = (q % 2 == 0).to(lo.dtype)
+        shape = [1, 1, 1, 1]
+        shape[dim] = N
+        y = y + even.reshape(shape) * (REC_LO[t] * lo.index_select(dim, q // 2) + REC_HI[t] * hi.index_select(dim, q // 2))
+    return y
+
+
+def dwt_forward(x, levels, periodic=False):
+    """-> (Yl, [Yh_0..]) with Yh_i (B, C, 3, h, w) = (LH, HL, HH), finest first.  periodic=True: the exact periodic
+    transform at every length (see _afb1d_periodic); the two agree unless a level input is shorter than 10 samples."""
+    afb = _afb1d_periodic if periodic else _afb1d
     Yh = []
     ll = x
     for _ in range(levels):
-        lo_w, hi_w = _afb1d(ll, 3)
-        ll_, lh = _afb1d(lo_w, 2)      # low along width:  (lo_h, hi_h) -> LL, LH
-        hl, hh = _afb1d(hi_w, 2)       # high along width: HL, HH
+        lo_w, hi_w = afb(ll, 3)
+        ll_, lh = afb(lo_w, 2)         # low along width:  (lo_h, hi_h) -> LL, LH
+        hl, hh = afb(hi_w, 2)          # high along width: HL, HH
         Yh.append(torch.stack((lh, hl, hh), dim=2))
         ll = ll_
     return ll, Yh
 
 
-def dwt_inverse(Yl, Yh):
+def dwt_inverse(Yl, Yh, periodic=False):
+    sfb = _sfb1d_periodic if periodic else _sfb1d
     ll = Yl
     for h in Yh[::-1]:
         lh, hl, hh = h[:, :, 0], h[:, :, 1], h[:, :, 2]
-        lo = _sfb1d(ll, lh, 2)
-        hi = _sfb1d(hl, hh, 2)
-        ll = _sfb1d(lo, hi, 3)
+        lo = sfb(ll, lh, 2)
+        hi = sfb(hl, hh, 2)
+        ll = sfb(lo, hi, 3)
     return ll

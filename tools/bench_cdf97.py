@@ -1,5 +1,5 @@
-"""Times the fixed CDF 9/7 transform at the BASELINE batch (8x3x512x512, 4 levels): per-level launches against the one-launch
-kernels (LLDWT_CDF97_FUSE=0/1), HIP-event time per call and host time per call (a call that is host-bound shows equal numbers).
+"""Times the fixed CDF 9/7 transform at the BASELINE batch (8x3x512x512, 4 levels): HIP-event time per call and host time per
+call (a call that is host-bound shows equal numbers).
   python tools/bench_cdf97.py [batch] [size] [levels]"""
 import json
 import os
@@ -35,11 +35,10 @@ def timeit(fn, iters=200):
 
 
 out = {"shape": list(x.shape), "levels": L, "algorithmic_bytes": nbytes}
-for fuse in os.environ.get("CDF_MODES", "0,1,2,3").split(","):
-    os.environ["LLDWT_CDF97_FUSE"] = fuse
+for fuse in ("",):
     ll, yh = ops.cdf97_forward(x, L)
     tf, hf = timeit(lambda: ops.cdf97_forward(x, L))
     ti, hi = timeit(lambda: ops.cdf97_inverse(ll, yh))
-    out["fuse" + fuse] = {"forward_us": tf * 1e6, "forward_host_us": hf * 1e6, "forward_GBs": nbytes / tf / 1e9,
+    out["per_level"] = {"forward_us": tf * 1e6, "forward_host_us": hf * 1e6, "forward_GBs": nbytes / tf / 1e9,
                           "inverse_us": ti * 1e6, "inverse_host_us": hi * 1e6, "inverse_GBs": nbytes / ti / 1e9}
 print(json.dumps(out))
