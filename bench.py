@@ -77,12 +77,18 @@ def parse_args():
     return ap.parse_args()
 
 
+# LLDWT_BENCH_REHEARSE=1: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks -- the ranks share the visible
+# GPU(s) and exchange over gloo instead of RCCL.  The line says so ("backend": "gloo", "rehearsal": true): its value is the
+# throughput of N processes time-slicing one GPU, NOT a scaling measurement.
+REHEARSE = os.environ.get("LLDWT_BENCH_REHEARSE", "") not in ("", "0")
+
+
 def self_launch(a):
     """--gpus N > 1 without a launcher: start N rank processes BEFORE anything touches the GPU, pass their output
     through and exit with their status.  torch.cuda.device_count() does not initialise the GPU."""
     import torch
     n_dev = torch.cuda.device_count()
-    if n_dev < a.gpus:
+    if n_dev < a.gpus and not REHEARSE:
         print("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run fewer ranks than asked"
               % (a.gpus, n_dev), file=sys.stderr)
         sys.exit(2)
@@ -194,12 +200,24 @@ def train_leg(a, c, dev, rank, world, x):
                       netType=c["netType"], entropy_layer=c["entropy_layer"])
     if x.shape[0] * x.shape[2] * x.shape[3] > 8 * 1024 * 1024:
         return {"skipped": "training leg is sized for <= 8 Mpixel per GPU per step (saved activations)"}
-    torch.manual_seed(1337)
-    agent = LiftingBasedDWTAgent(cfg)                     # random-init weights (same on every rank: replicated model)
-    agent.model.train()
-    torch.manual_seed(parallel.rank_seed(1337, rank))
-    torch.cuda.empty_cache()
-    agent.train_step(x)                                   # warm-up (allocator, packs)
+    # pre-flight, rank-local (no collective): build the agent and take one step.  Then the ranks agree whether ALL of them got
+    # here; a rank that failed must not leave the others waiting in the gradient all-reduce
+    err = None
+    try:
+        torch.manual_seed(1337)
+        agent = LiftingBasedDWTAgent(cfg)                 # random-init weights (same on every rank: replicated model)
+        agent.model.train()
+        torch.manual_seed(parallel.rank_seed(1337, rank))
+        torch.cuda.empty_cache()
+        agent.train_step(x, allreduce=False)              # warm-up (allocator, packs)
+        torch.cuda.synchronize()
+    except Exception as e:
+        err = "%s: %s" % (type(e).__name__, str(e)[:200])
+        log("train leg pre-flight failed on rank %d: %s" % (rank, err))
+    if not parallel.all_ranks_ok(err is None, dev):
+        return {"error": err or "the pre-flight step failed on another rank"}
+    parallel.broadcast_parameters(agent.model)            # the local step used rank-local noise: replicas identical again
+    agent.train_step(x)                                   # warm-up of the exchange (first RCCL all-reduce)
     torch.cuda.synchronize()
     parallel.barrier()
     t0 = time.perf_counter()
@@ -273,6 +291,10 @@ def main():
         print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a mislabelled line"
               % (a.gpus, env_world), file=sys.stderr)
         sys.exit(2)
+    wd = float(os.environ.get("LLDWT_BENCH_WATCHDOG", "0") or 0)
+    if wd > 0:                                            # diagnosis: after wd seconds dump every thread's stack and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True, file=sys.__stderr__)
     if a.plc_mode:
         os.environ["LLDWT_PLC_MODE"] = a.plc_mode
     if a.storage:
@@ -281,9 +303,12 @@ def main():
     import torch
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
     rank, world, local = parallel.env_rank()
+    if REHEARSE:                                             # ranks share the visible GPU(s), exchange over gloo
+        local %= max(torch.cuda.device_count(), 1)
+        os.environ["LOCAL_RANK"] = str(local)                # the agent picks cuda:LOCAL_RANK
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    parallel.init("nccl", dev)                               # backend "nccl" == RCCL over xGMI; no-op for N == 1
+    parallel.init("gloo" if REHEARSE else "nccl", dev)       # backend "nccl" == RCCL over xGMI; no-op for N == 1
     world_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     assert world_seen == a.gpus, (world_seen, a.gpus)
 
@@ -471,7 +496,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_string(c, a), "note": c["note"], "per_gpu_images": Bx, "image_hw": [Hx, Wx],
                    "sharding": "batch over ranks, no data-path collective",
-                   "backend": parallel.backend_name(), "world_size_seen": world_seen},
+                   "backend": parallel.backend_name(), "world_size_seen": world_seen,
+                   **({"rehearsal": True} if REHEARSE else {})},
         "roofline": roof,
     }
     if dom2["events"]:

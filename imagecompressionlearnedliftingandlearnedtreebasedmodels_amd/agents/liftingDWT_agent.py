@@ -70,9 +70,11 @@ class LiftingBasedDWTAgent(BaseAgent):
         loss, mse, r1, r2 = loss_fn.forward3(xs, xhat, si_xe, si_xo)
         return loss, mse, r1, r2, xhat
 
-    def train_step(self, x, noise_fn=None):
+    def train_step(self, x, noise_fn=None, allreduce=True):
         """One optimisation step on a batch x (B,3,H,W) in [0,1] (agents/liftingDWT_agent.py:78-98): zero_grad, forward
-        (training noise), loss / grad_acc_iters, backward (HIP kernels), gradient all-reduce over ranks, Adam step."""
+        (training noise), loss / grad_acc_iters, backward (HIP kernels), gradient all-reduce over ranks, Adam step.
+        allreduce=False keeps the step rank-local (no collective: bench.py's pre-flight step, after which the ranks agree
+        whether all of them can run the leg at all)."""
         if self._bucket is None:
             self._bucket = parallel.FlatGradBucket(self.model.parameters())     # one flat fp32 bucket for RCCL
         self._bucket.zero_()
@@ -86,7 +88,8 @@ class LiftingBasedDWTAgent(BaseAgent):
             xhat, si_xe, si_xo = xh[0], si_xe[0], [t[0] for t in si_xo]
         loss, mse, r1, r2 = self.train_loss.forward3_train(xs, xhat, si_xe, si_xo)
         (loss / self.grad_acc_iters).float().backward()                        # :97
-        self._bucket.all_reduce_mean()                                          # data-parallel: mean gradient over ranks
+        if allreduce:
+            self._bucket.all_reduce_mean()                                      # data-parallel: mean gradient over ranks
         self.optimizer.step()                                                   # :98
         self.current_iteration += 1
         return loss, mse, r1, r2

@@ -54,12 +54,34 @@ def barrier():
         dist.barrier()
 
 
+def _all_reduce(t, op):
+    """dist.all_reduce; with the gloo backend (CPU rehearsals of the N > 1 path, also with ranks sharing one GPU) a device
+    tensor is staged through the host, so the call does not depend on gloo having been built with GPU support."""
+    if dist.get_backend() == "gloo" and t.device.type != "cpu":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def max_over_ranks(value, device="cpu"):
     if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _all_reduce(t, dist.ReduceOp.MAX)
     return float(t)
+
+
+def all_ranks_ok(ok, device="cpu"):
+    """True iff ``ok`` holds on EVERY rank.  Call it at a point every rank reaches whatever happened before (outside the
+    try block): a rank that failed locally must not leave its peers waiting in a collective it will never join."""
+    if not dist.is_initialized():
+        return bool(ok)
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+    _all_reduce(t, dist.ReduceOp.MIN)
+    return bool(float(t) > 0.5)
 
 
 def mean_over_ranks(values, device="cpu"):
@@ -70,7 +92,7 @@ def mean_over_ranks(values, device="cpu"):
     if not dist.is_initialized():
         return vals
     t = torch.tensor(vals, dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    _all_reduce(t, dist.ReduceOp.SUM)
     return (t / dist.get_world_size()).tolist()
 
 
@@ -83,13 +105,18 @@ def broadcast_parameters(module, src=0):
     if dist.is_initialized():
         for t in list(module.parameters()) + list(module.buffers()):
             if t.numel():
-                dist.broadcast(t.data, src=src)
+                if dist.get_backend() == "gloo" and t.device.type != "cpu":
+                    h = t.data.cpu()
+                    dist.broadcast(h, src=src)
+                    t.data.copy_(h)
+                else:
+                    dist.broadcast(t.data, src=src)
 
 
 def sum_over_ranks(t):
     """In-place all-reduce(sum) of a tensor (scalars that are logged, or the flat gradient bucket)."""
     if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce(t, dist.ReduceOp.SUM)
     return t
 
 
@@ -112,6 +139,6 @@ class FlatGradBucket:
 
     def all_reduce_mean(self):
         if dist.is_initialized():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            _all_reduce(self.flat, dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
         return self.flat

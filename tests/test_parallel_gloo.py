@@ -39,6 +39,10 @@ def _worker(rank, world, port, q):
     bucket.all_reduce_mean()
     g = torch.Generator().manual_seed(parallel.rank_seed(1337, rank))
     noise0 = float(torch.rand(1, generator=g))
+    # a rank-local failure (here: rank 1 "fails") is seen by every rank, and nobody is left waiting in a collective
+    ok_all = parallel.all_ranks_ok(rank != 1)
+    ok_all2 = parallel.all_ranks_ok(True)
+    assert ok_all is False and ok_all2 is True
     parallel.barrier()
     q.put((rank, mine.shape[0], float(n), float(tot), tmax, float(lin.weight.grad.mean()), float(lin.bias.grad.mean()), noise0))
     dist.destroy_process_group()
