@@ -113,6 +113,15 @@ def test_train_step_inside_nccl_group():
             l1 = float(ag.train_step(x)[0])
         assert l1 < l0
         assert parallel.mean_over_ranks([2.5], ag.device) == [2.5]
+        # what bench.py's N > 1 training leg does besides the bucket exchange: the agreement flag, the broadcast of every
+        # parameter and buffer (all their dtypes must be ones RCCL takes), the max-over-ranks clock
+        assert parallel.all_ranks_ok(True, ag.device) is True and parallel.all_ranks_ok(False, ag.device) is False
+        snap = [t.detach().clone() for t in list(ag.model.parameters()) + list(ag.model.buffers())]
+        parallel.broadcast_parameters(ag.model)
+        for a, b in zip(snap, list(ag.model.parameters()) + list(ag.model.buffers())):
+            assert torch.equal(a, b)
+        assert parallel.max_over_ranks(1.25, ag.device) == 1.25
+        parallel.barrier()
     finally:
         dist.destroy_process_group()
 
