@@ -35,10 +35,9 @@ def timeit(fn, iters=200):
 
 
 out = {"shape": list(x.shape), "levels": L, "algorithmic_bytes": nbytes}
-for fuse in ("",):
-    ll, yh = ops.cdf97_forward(x, L)
-    tf, hf = timeit(lambda: ops.cdf97_forward(x, L))
-    ti, hi = timeit(lambda: ops.cdf97_inverse(ll, yh))
-    out["per_level"] = {"forward_us": tf * 1e6, "forward_host_us": hf * 1e6, "forward_GBs": nbytes / tf / 1e9,
-                          "inverse_us": ti * 1e6, "inverse_host_us": hi * 1e6, "inverse_GBs": nbytes / ti / 1e9}
+ll, yh = ops.cdf97_forward(x, L)
+tf, hf = timeit(lambda: ops.cdf97_forward(x, L))
+ti, hi = timeit(lambda: ops.cdf97_inverse(ll, yh))
+out["per_level"] = {"forward_us": tf * 1e6, "forward_host_us": hf * 1e6, "forward_GBs": nbytes / tf / 1e9,
+                    "inverse_us": ti * 1e6, "inverse_host_us": hi * 1e6, "inverse_GBs": nbytes / ti / 1e9}
 print(json.dumps(out))
