@@ -68,6 +68,10 @@ SIGNATURES = {
                                          _i, _p, _i64, _p, _p]),
     "lldwt_lifting_inverse_train": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _i, _f, _i,
                                          _p, _i64, _p, _p]),
+    "lldwt_lifting_forward_train_ex": (_i, [_p, _p, C.POINTER(_p), _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _i, _i, _f,
+                                            _i, _p, _p, _p, _i64, _p, _p]),
+    "lldwt_lifting_inverse_train_ex": (_i, [_p, C.POINTER(_p), _p, _i64, _i64, _i64, _i64, _i, _p, _p, _i, _i, _i, _i, _f, _i,
+                                            _p, _p, _p, _i64, _p, _p]),
     "lldwt_lift_bwd_pre": (_i, [View, View, _p, _i64, _i64, _i64, _p]),
     "lldwt_lift_bwd_fin": (_i, [_p, _p, _p, View, _i64, _i64, _i64, _i64, _p, _p, _i, _f, _f, _p]),
     "lldwt_lift_step_bwd_ws_bytes": (_i64, [_i64, _i64, _i64, _i]),

@@ -299,8 +299,11 @@ def _pack_forward(W, nblocks):
 class _LiftBackward:
     """Executes the step program in reverse over gradient buffers of the forward layout (include/lldwt.h)."""
 
-    def __init__(self, meta, taps, W, saved, P, B, H, W_):
+    def __init__(self, meta, taps, W, saved, P, B, H, W_, nh=None, nl=None):
         self.m, self.taps, self.W, self.saved = meta, taps, W, saved
+        self.nh, self.nl = nh, nl                                   # (P,) effective gains of config.scale == 1, or None
+        self.dnh = torch.zeros_like(nh) if nh is not None else None
+        self.dnl = torch.zeros_like(nl) if nl is not None else None
         self.P, self.B, self.H, self.Wd = P, B, H, W_
         self.Z = P * B
         self.dtaps = torch.zeros_like(taps)
@@ -314,15 +317,40 @@ class _LiftBackward:
             self.packs[key] = ops.conv_pack(self.W[name][blk, u], self.m["K"], transposed=True, swap_hw=not vertical)
         return self.packs[key]
 
+    def _scale_bwd(self, op, G, n):
+        """Gain op of config.scale == 1 (wavelet_forward_v2.py:76-80, wavelet_inverse_v2.py:70-74): kind 1/2 y = v * s,
+        kind 3/4 y = v / s with s = nh (1, 3) or nl (2, 4) per plane; v is what the forward kept in `saved`.
+        G[src] = dL/dv (SET: an op's src view is either its own dout or read by nobody else), d(s) accumulates."""
+        P, B, h, w = self.P, self.B, op.h, op.w
+        s, ds = (self.nh, self.dnh) if op.kind in (1, 3) else (self.nl, self.dnl)
+        if s is None:
+            raise RuntimeError("lifting program with gain ops but no gains were given")
+        v = self.saved[op.saved_off:op.saved_off + n].view(P, B, h, w)
+
+        def gview(buf, off, sz, sy, sx):
+            t = G[buf]
+            return torch.as_strided(t, (P, B, h, w), (B * sz, sz, sy, sx), t.storage_offset() + off)
+        gy = gview(op.buf_dout, op.off_dout, op.sz_dout, op.sy_dout, op.sx_dout)
+        sv = s.view(P, 1, 1, 1)
+        dot = (gy * v).sum(dim=(1, 2, 3))
+        if op.kind <= 2:
+            ds += dot
+            gv = gy * sv
+        else:
+            ds -= dot / (s * s)
+            gv = gy / sv
+        gview(op.buf_src, op.off_src, op.sz_src, op.sy_src, op.sx_src).copy_(gv)
+
     def run(self, program, G):
         m, Z, B = self.m, self.Z, self.B
         C_, K, rw = m["C"], m["K"], m["rw"]
         epi = ops.EPI_NONE if m["linear"] else ops.EPI_TANH_BWD
         for op in reversed(program):
-            if op.kind != 0:
-                raise RuntimeError("training with config.scale == 1 is not supported on the HIP path")
             h, w = op.h, op.w
             n = Z * h * w
+            if op.kind != 0:
+                self._scale_bwd(op, G, n)
+                continue
             base = self.saved[op.saved_off:op.saved_off + n * (2 + 3 * C_)]
             srcv = base[:n]
             skip = base[n:2 * n].view(self.P, B, 1, h, w)
@@ -384,20 +412,24 @@ def _grad_buffers(P, B, H, W, levels, dev):
 
 
 class LiftingFn(torch.autograd.Function):
-    """x (P,B,1,H,W) -> (ll, yh_0..yh_{L-1}); parameters: taps (4,P,3) and the 8 stacked P/U-block tensors
-    (nblocks,2,P,...).  Forward = lldwt_lifting_forward_train; backward = reversed step program."""
+    """x (P,B,1,H,W) -> (ll, yh_0..yh_{L-1}); parameters: taps (4,P,3), the effective gains nh, nl (P,) of
+    config.scale == 1 (None otherwise) and the 8 stacked P/U-block tensors (nblocks,2,P,...).
+    Forward = lldwt_lifting_forward_train_ex; backward = reversed step program."""
 
     @staticmethod
-    def forward(ctx, x, taps, meta, *Wt):
+    def forward(ctx, x, taps, meta, nh, nl, *Wt):
         W = dict(zip(_W_KEYS, Wt))
         P, B, _, H, Wd = x.shape
         nblocks = Wt[0].shape[0]
-        prog, nsaved = ops.lifting_program(P * B, H, Wd, meta["levels"], meta["different"], 0, False, meta["C"])
+        scale = nh is not None
+        prog, nsaved = ops.lifting_program(P * B, H, Wd, meta["levels"], meta["different"], 0, False, meta["C"], scale)
         saved = torch.empty(nsaved, device=x.device, dtype=torch.float32)
         packed = _pack_forward(W, nblocks)
+        nh_, nl_ = (nh.detach().contiguous(), nl.detach().contiguous()) if scale else (None, None)
         ll, yh = ops.lifting_forward_train(x, taps, packed, meta["levels"], meta["C"], meta["K"], meta["rw"], meta["linear"],
-                                           meta["different"], 0, saved)
+                                           meta["different"], 0, saved, nh_, nl_)
         ctx.save_for_backward(taps, saved, *Wt)
+        ctx.gains = (nh_, nl_)
         ctx.meta, ctx.prog, ctx.shape = meta, prog, (P, B, H, Wd)
         return (ll, *yh)
 
@@ -412,28 +444,31 @@ class LiftingFn(torch.autograd.Function):
         G[_BUF_LL] = g_ll.contiguous().clone()
         for i in range(L):
             G[_BUF_YH0 + i] = g_yh[i].contiguous().clone()
-        bw = _LiftBackward(ctx.meta, taps, W, saved, P, B, H, Wd)
+        bw = _LiftBackward(ctx.meta, taps, W, saved, P, B, H, Wd, *ctx.gains)
         bw.run(ctx.prog, G)
-        return (G[_BUF_X], bw.dtaps, None, *[bw.dW[k] for k in _W_KEYS])
+        return (G[_BUF_X], bw.dtaps, None, bw.dnh, bw.dnl, *[bw.dW[k] for k in _W_KEYS])
 
 
 class LiftingInvFn(torch.autograd.Function):
     """(ll, yh_0..yh_{L-1}) -> x (inverse transform); same parameters as LiftingFn."""
 
     @staticmethod
-    def forward(ctx, taps, meta, nlev, *rest):
+    def forward(ctx, taps, meta, nlev, nh, nl, *rest):
         ll, yh, Wt = rest[0], list(rest[1:1 + nlev]), rest[1 + nlev:]
         W = dict(zip(_W_KEYS, Wt))
         P, B, _, hl, wl = ll.shape
         H, Wd = hl << nlev, wl << nlev
         nblocks = Wt[0].shape[0]
         off = 2 * nlev if meta["different"] else 0     # lifting_dwt_nets.py:718-722
-        prog, nsaved = ops.lifting_program(P * B, H, Wd, nlev, False, off, True, meta["C"])
+        scale = nh is not None
+        prog, nsaved = ops.lifting_program(P * B, H, Wd, nlev, False, off, True, meta["C"], scale)
         saved = torch.empty(nsaved, device=ll.device, dtype=torch.float32)
         packed = _pack_forward(W, nblocks)
+        nh_, nl_ = (nh.detach().contiguous(), nl.detach().contiguous()) if scale else (None, None)
         x = ops.lifting_inverse_train(ll.contiguous(), [t.contiguous() for t in yh], taps, packed, meta["C"], meta["K"],
-                                      meta["rw"], meta["linear"], off, saved)
+                                      meta["rw"], meta["linear"], off, saved, nh_, nl_)
         ctx.save_for_backward(taps, saved, *Wt)
+        ctx.gains = (nh_, nl_)
         ctx.meta, ctx.prog, ctx.shape, ctx.nlev = meta, prog, (P, B, H, Wd), nlev
         return x
 
@@ -448,6 +483,7 @@ class LiftingInvFn(torch.autograd.Function):
         G[_BUF_LL] = torch.empty(P, B, 1, H >> L, Wd >> L, device=taps.device, dtype=torch.float32)
         for i in range(L):
             G[_BUF_YH0 + i] = torch.empty(P, B, 3, H >> (i + 1), Wd >> (i + 1), device=taps.device, dtype=torch.float32)
-        bw = _LiftBackward(ctx.meta, taps, W, saved, P, B, H, Wd)
+        bw = _LiftBackward(ctx.meta, taps, W, saved, P, B, H, Wd, *ctx.gains)
         bw.run(ctx.prog, G)
-        return (bw.dtaps, None, None, G[_BUF_LL], *[G[_BUF_YH0 + i] for i in range(L)], *[bw.dW[k] for k in _W_KEYS])
+        return (bw.dtaps, None, None, bw.dnh, bw.dnl, G[_BUF_LL], *[G[_BUF_YH0 + i] for i in range(L)],
+                *[bw.dW[k] for k in _W_KEYS])

@@ -6,7 +6,7 @@
 //   synthesis: x[n]  = sum_t [ (n+4-t) mod N even ] ( lo[((n+4-t) mod N)/2] * rec_lo[t] + hi[..] * rec_hi[t] )
 // Every tap wraps periodically at every length (PyWavelets' periodization).  For level inputs shorter than the 10 taps
 // pytorch_wavelets folds the linear convolution back once only and differs; from 10 samples up the two are the same
-// transform (oracle/cdf97.py, tests/golden/cdf97_pywt_small.npz).
+// transform (tests/golden/cdf97_pywt_small.npz).
 #include "common.h"
 
 namespace lldwt {

@@ -884,13 +884,15 @@ __global__ __launch_bounds__(NT) void k_lift_c(const float* __restrict__ skip, c
 }
 
 // out = in * s[plane]  (or / s[plane]) on views; config.scale == 1 only (wavelet_forward_v2.py:76-80)
+// training: the input v goes to `save` (dense Z,h,w) -- the backward needs it for d(gain) and the op may be in place
 __global__ void k_scale_view(CView in, lldwt_view out, int batch, int h, int w, const float* __restrict__ s,
-                             int divide) {
+                             int divide, float* __restrict__ save) {
     const int64_t z = blockIdx.z;
     const float f = s[z / batch];
     for (int y = blockIdx.y; y < h; y += gridDim.y)
         for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
             const float v = in.p[z * in.sz + (int64_t)y * in.sy + (int64_t)x * in.sx];
+            if (save) save[(z * h + y) * w + x] = v;
             out.p[z * out.sz + (int64_t)y * out.sy + (int64_t)x * out.sx] = divide ? v / f : v * f;
         }
 }
@@ -1294,7 +1296,7 @@ static void push_op(lldwt_lift_op* ops, int& n, int max_ops, int kind, SymView s
         o.h = (int32_t)h; o.w = (int32_t)w; o.vertical = vertical; o.tap = tap; o.block = block; o.is_u = is_u;
         o.sign = sign; o.saved_off = saved_off;
     }
-    if (kind == 0) saved_off += saved_step_floats(Z, h, w, C);
+    saved_off += kind == 0 ? saved_step_floats(Z, h, w, C) : Z * h * w;      // a scale op keeps its input
     ++n;
 }
 
@@ -1316,9 +1318,9 @@ static void two_stage(lldwt_lift_op* ops, int& n, int max_ops, bool inverse, Sym
 }
 
 // scale ops (config.scale == 1): kind 1 = dout = src * nh, 2 = * nl, 3 = / nh, 4 = / nl (per plane)
-static void push_scale(lldwt_lift_op* ops, int& n, int max_ops, int kind, SymView src, SymView dout, int64_t h, int64_t w) {
-    int64_t dummy = 0;
-    push_op(ops, n, max_ops, kind, src, src, dout, h, w, 0, 0, 0, 0, 1.f, dummy, 0, 0);
+static void push_scale(lldwt_lift_op* ops, int& n, int max_ops, int kind, SymView src, SymView dout, int64_t h, int64_t w,
+                       int64_t& so, int64_t Z) {
+    push_op(ops, n, max_ops, kind, src, src, dout, h, w, 0, 0, 0, 0, 1.f, so, Z, 0);
 }
 
 static int build_program(lldwt_lift_op* ops, int max_ops, int64_t Z, int64_t H, int64_t W, int levels, int different,
@@ -1336,20 +1338,20 @@ static int build_program(lldwt_lift_op* ops, int max_ops, int64_t Z, int64_t H, 
             SymView vL = sv(B_LROW, 0, hh * w, w, 1), vH = sv(B_HROW, 0, hh * w, w, 1);
             SymView tL = sv(B_TMPL, 0, hh * w, w, 1), tH = sv(B_TMPH, 0, hh * w, w, 1);
             two_stage(ops, n, max_ops, false, A, Bv, vL, vH, tL, tH, hh, w, 1, blk, so, Z, C);
-            if (scale) { push_scale(ops, n, max_ops, 1, vH, vH, hh, w); push_scale(ops, n, max_ops, 2, vL, vL, hh, w); }
+            if (scale) { push_scale(ops, n, max_ops, 1, vH, vH, hh, w, so, Z); push_scale(ops, n, max_ops, 2, vL, vL, hh, w, so, Z); }
             SymView vLL = sv(bll, 0, sub, wh, 1);
             SymView vLH = sv(byh, 0, 3 * sub, wh, 1), vHL = sv(byh, sub, 3 * sub, wh, 1), vHH = sv(byh, 2 * sub, 3 * sub, wh, 1);
             SymView t2L = sv(B_TMPL, 0, sub, wh, 1), t2H = sv(B_TMPH, 0, sub, wh, 1);
             SymView Le = sv(B_LROW, 0, hh * w, w, 2), Lo = sv(B_LROW, 1, hh * w, w, 2);          // columns of L (:32-39)
             two_stage(ops, n, max_ops, false, Le, Lo, vLL, vHL, t2L, t2H, hh, wh, 0, blk, so, Z, C);
-            if (scale) { push_scale(ops, n, max_ops, 1, vHL, vHL, hh, wh); push_scale(ops, n, max_ops, 2, vLL, vLL, hh, wh); }
+            if (scale) { push_scale(ops, n, max_ops, 1, vHL, vHL, hh, wh, so, Z); push_scale(ops, n, max_ops, 2, vLL, vLL, hh, wh, so, Z); }
             SymView He = sv(B_HROW, 0, hh * w, w, 2), Ho = sv(B_HROW, 1, hh * w, w, 2);          // columns of H (:43-51)
             // its own temporaries (the second halves of tmpL / tmpH, free during the column passes): the L and H column
             // passes are independent, and the eval executor runs step k of both in ONE launch (run_program)
             const int64_t toff = scale ? 0 : Z * sub;
             SymView u2L = sv(B_TMPL, toff, sub, wh, 1), u2H = sv(B_TMPH, toff, sub, wh, 1);
             two_stage(ops, n, max_ops, false, He, Ho, vLH, vHH, u2L, u2H, hh, wh, 0, blk, so, Z, C);
-            if (scale) { push_scale(ops, n, max_ops, 1, vHH, vHH, hh, wh); push_scale(ops, n, max_ops, 2, vLH, vLH, hh, wh); }
+            if (scale) { push_scale(ops, n, max_ops, 1, vHH, vHH, hh, wh, so, Z); push_scale(ops, n, max_ops, 2, vLH, vLH, hh, wh, so, Z); }
         }
     } else {
         const int blk = block_offset;       // lifting_dwt_nets.py:718-722: every inverse level uses the same pair
@@ -1364,11 +1366,11 @@ static int build_program(lldwt_lift_op* ops, int max_ops, int64_t Z, int64_t H, 
             SymView inL = vLL, inH = vHL;
             // scratch for the scaled copies (config.scale == 1, wavelet_inverse_v2.py:70-74): second halves of tmpL/tmpH
             SymView sL = sv(B_TMPL, Z * (H / 2) * W / 2, sub, wh, 1), sH = sv(B_TMPH, Z * (H / 2) * W / 2, sub, wh, 1);
-            if (scale) { push_scale(ops, n, max_ops, 4, vLL, sL, hh, wh); push_scale(ops, n, max_ops, 3, vHL, sH, hh, wh); inL = sL; inH = sH; }
+            if (scale) { push_scale(ops, n, max_ops, 4, vLL, sL, hh, wh, so, Z); push_scale(ops, n, max_ops, 3, vHL, sH, hh, wh, so, Z); inL = sL; inH = sH; }
             SymView Le = sv(B_LROW, 0, hh * w, w, 2), Lo = sv(B_LROW, 1, hh * w, w, 2);          // (LL,HL) -> L (:21-26)
             two_stage(ops, n, max_ops, true, inL, inH, Le, Lo, t2L, t2H, hh, wh, 0, blk, so, Z, C);
             inL = vLH; inH = vHH;
-            if (scale) { push_scale(ops, n, max_ops, 4, vLH, sL, hh, wh); push_scale(ops, n, max_ops, 3, vHH, sH, hh, wh); inL = sL; inH = sH; }
+            if (scale) { push_scale(ops, n, max_ops, 4, vLH, sL, hh, wh, so, Z); push_scale(ops, n, max_ops, 3, vHH, sH, hh, wh, so, Z); inL = sL; inH = sH; }
             SymView He = sv(B_HROW, 0, hh * w, w, 2), Ho = sv(B_HROW, 1, hh * w, w, 2);          // (LH,HH) -> H (:28-33)
             const int64_t toff = scale ? 0 : Z * sub;                                              // see the forward program
             SymView u2L = sv(B_TMPL, toff, sub, wh, 1), u2H = sv(B_TMPH, toff, sub, wh, 1);
@@ -1376,7 +1378,7 @@ static int build_program(lldwt_lift_op* ops, int max_ops, int64_t Z, int64_t H, 
             SymView vL = sv(B_LROW, 0, hh * w, w, 1), vH = sv(B_HROW, 0, hh * w, w, 1);
             SymView tL = sv(B_TMPL, 0, hh * w, w, 1), tH = sv(B_TMPH, 0, hh * w, w, 1);
             SymView A = sv(bout, 0, h * w, 2 * w, 1), Bv = sv(bout, w, h * w, 2 * w, 1);        // (L,H) -> rows (:35-37)
-            if (scale) { push_scale(ops, n, max_ops, 4, vL, vL, hh, w); push_scale(ops, n, max_ops, 3, vH, vH, hh, w); }
+            if (scale) { push_scale(ops, n, max_ops, 4, vL, vL, hh, w, so, Z); push_scale(ops, n, max_ops, 3, vH, vH, hh, w, so, Z); }
             two_stage(ops, n, max_ops, true, vL, vH, A, Bv, tL, tH, hh, w, 1, blk, so, Z, C);
         }
     }
@@ -1457,7 +1459,8 @@ static int run_program(const lldwt_lift_op* ops, int n, float* const* bases, con
         if (o.kind != 0) {
             const float* f = (o.kind == 1 || o.kind == 3) ? c.nh : c.nl;
             dim3 grid((unsigned)cdiv(o.w, 256), (unsigned)(o.h < 1024 ? o.h : 1024), (unsigned)c.Z);
-            hipLaunchKernelGGL(k_scale_view, grid, dim3(256), 0, c.st, cv(src), dout, (int)c.batch, o.h, o.w, f, o.kind >= 3);
+            hipLaunchKernelGGL(k_scale_view, grid, dim3(256), 0, c.st, cv(src), dout, (int)c.batch, o.h, o.w, f, o.kind >= 3,
+                               c.saved ? c.saved + o.saved_off : nullptr);
             continue;
         }
         lldwt_view din = resolve(bases, o.buf_din, o.off_din, o.sz_din, o.sy_din, o.sx_din);
@@ -1668,7 +1671,6 @@ static int lifting_run(const char* who, int inverse, float* x, float* ll, float*
     LLDWT_REQUIRE(x && ll && yh && taps && packed && ws, "%s: null pointer", who);
     LLDWT_REQUIRE(nblocks >= 2 && block_offset >= 0 && block_offset + ((different && !inverse) ? 2 * levels : 2) <= nblocks,
                   "%s: block_offset=%d exceeds nblocks=%d", who, block_offset, nblocks);
-    LLDWT_REQUIRE(!(saved && scale_nh), "%s: training with config.scale == 1 is not supported", who);
     const int64_t Z = planes * batch;
     if (ws_bytes < lldwt_lifting_ws_bytes(Z, H, W, C)) {
         set_error("%s: workspace %ld < %ld bytes", who, (long)ws_bytes, (long)lldwt_lifting_ws_bytes(Z, H, W, C));
@@ -1720,9 +1722,20 @@ extern "C" int lldwt_lifting_forward_train(const float* x, float* ll, float* con
                                            int64_t H, int64_t W, int levels, const float* taps, const float* packed,
                                            int nblocks, int block_offset, int different, int C, int K, float res_weight,
                                            int linear, void* ws, int64_t ws_bytes, float* saved, void* stream) {
+    return lldwt_lifting_forward_train_ex(x, ll, yh, planes, batch, H, W, levels, taps, packed, nblocks, block_offset, different,
+                                          C, K, res_weight, linear, nullptr, nullptr, ws, ws_bytes, saved, stream);
+}
+
+// + the gains of config.scale == 1 (per plane; both null = no scaling): the scale ops keep their inputs in `saved` too
+// (lldwt_lifting_program with scale = 1 gives the offsets)
+extern "C" int lldwt_lifting_forward_train_ex(const float* x, float* ll, float* const* yh, int64_t planes, int64_t batch,
+                                              int64_t H, int64_t W, int levels, const float* taps, const float* packed,
+                                              int nblocks, int block_offset, int different, int C, int K, float res_weight,
+                                              int linear, const float* scale_nh, const float* scale_nl, void* ws,
+                                              int64_t ws_bytes, float* saved, void* stream) {
     LLDWT_REQUIRE(saved, "lifting_forward_train: null saved buffer");
     return lifting_run("lifting_forward_train", 0, const_cast<float*>(x), ll, yh, planes, batch, H, W, levels, taps, packed,
-                       nblocks, block_offset, different, C, K, res_weight, linear, nullptr, nullptr, ws, ws_bytes, saved,
+                       nblocks, block_offset, different, C, K, res_weight, linear, scale_nh, scale_nl, ws, ws_bytes, saved,
                        stream);
 }
 
@@ -1731,8 +1744,17 @@ extern "C" int lldwt_lifting_inverse_train(const float* ll, const float* const* 
                                            const float* packed, int nblocks, int block_offset, int C, int K,
                                            float res_weight, int linear, void* ws, int64_t ws_bytes, float* saved,
                                            void* stream) {
+    return lldwt_lifting_inverse_train_ex(ll, yh, x, planes, batch, H, W, levels, taps, packed, nblocks, block_offset, C, K,
+                                          res_weight, linear, nullptr, nullptr, ws, ws_bytes, saved, stream);
+}
+
+extern "C" int lldwt_lifting_inverse_train_ex(const float* ll, const float* const* yh, float* x, int64_t planes,
+                                              int64_t batch, int64_t H, int64_t W, int levels, const float* taps,
+                                              const float* packed, int nblocks, int block_offset, int C, int K,
+                                              float res_weight, int linear, const float* scale_nh, const float* scale_nl,
+                                              void* ws, int64_t ws_bytes, float* saved, void* stream) {
     LLDWT_REQUIRE(saved, "lifting_inverse_train: null saved buffer");
     return lifting_run("lifting_inverse_train", 1, x, const_cast<float*>(ll), const_cast<float* const*>(yh), planes, batch,
-                       H, W, levels, taps, packed, nblocks, block_offset, 0, C, K, res_weight, linear, nullptr, nullptr, ws,
+                       H, W, levels, taps, packed, nblocks, block_offset, 0, C, K, res_weight, linear, scale_nh, scale_nl, ws,
                        ws_bytes, saved, stream);
 }

@@ -21,7 +21,7 @@ from ... import ops
 from ...entropy_models import EntropyBottleneck, GaussianConditional
 from ...packed_cache import PackedOwnerMixin, cached
 from ..layers.lifting_dwt_nets import (DWTPytorchWaveletsLayer, LiftingBasedNeuralWaveletv4, _stack,
-                                       decode_planes, encode_planes)
+                                       decode_planes, encode_planes, lifting_coeff)
 from ..layers.masked_conv2d import MaskedConv2d
 
 SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
@@ -611,7 +611,11 @@ def _lift_params(nets):
     n0 = nets[0]
     meta = dict(levels=n0.waveletLevel, C=n0.depth_scale, K=n0.conv_filter_size, rw=n0.res_connection_weight,
                 linear=n0.linearityflag != 1, different=n0.blockprop != "same")
-    return taps.contiguous(), meta, Wt
+    nh = nl = None
+    if n0.config.scale == 1:                              # wavelet_forward_v2.py:76-80: gains 0.8698.. + 0.1 nh, 1.1496.. + 0.1 nl
+        nh = _tstack(nets, lambda n: lifting_coeff[4] + n.nh.reshape(()) * 0.1).contiguous()
+        nl = _tstack(nets, lambda n: lifting_coeff[5] + n.nl.reshape(()) * 0.1).contiguous()
+    return taps.contiguous(), meta, Wt, nh, nl
 
 
 def _eb_train(ebs):
@@ -801,11 +805,9 @@ def forward_planes_train(nets, x, noise_fn=None):
 
     lifting = isinstance(aenc[0], LiftingBasedNeuralWaveletv4)
     if lifting:
-        if aenc[0].config.scale == 1:
-            raise NotImplementedError("training with config.scale == 1 is not built")
         L = aenc[0].waveletLevel
-        taps, meta, Wt = _lift_params(aenc)
-        outs = ag.LiftingFn.apply(x, taps, meta, *Wt)
+        taps, meta, Wt, nh, nl = _lift_params(aenc)
+        outs = ag.LiftingFn.apply(x, taps, meta, nh, nl, *Wt)
         ll, yh = outs[0], list(outs[1:])
     else:
         L = aenc[0].dwtlevels
@@ -820,7 +822,7 @@ def forward_planes_train(nets, x, noise_fn=None):
     Yl = _ae_train([n.Yl_ae for n in aenc], xe_q, True)
     Yh = [_ae_train([n.Yh_ae[i] for n in aenc], q_list[i], True) for i in range(L)]
     if lifting:
-        xhat = ag.LiftingInvFn.apply(taps, meta, L, Yl, *Yh, *Wt)
+        xhat = ag.LiftingInvFn.apply(taps, meta, L, nh, nl, Yl, *Yh, *Wt)
     else:
         Yh6 = [t.reshape(t.shape[0], t.shape[1], t.shape[2] // 3, 3, t.shape[3], t.shape[4]) for t in Yh]
         xhat = ag.Cdf97InvFn.apply(Yl, *Yh6)

@@ -654,21 +654,24 @@ def ycc_to_rgb_bwd(grgb):
     return g
 
 
-def lifting_program(Z, H, W, levels, different, block_offset, inverse, Cc):
-    """-> (list of LiftOp, saved_floats): the step program of the transform (include/lldwt.h lldwt_lifting_program)."""
+def lifting_program(Z, H, W, levels, different, block_offset, inverse, Cc, scale=False):
+    """-> (list of LiftOp, saved_floats): the step program of the transform (include/lldwt.h lldwt_lifting_program).
+    scale=True: with the gain ops of config.scale == 1 (kind 1..4; each keeps its input in the saved buffer)."""
     lib = _lib.load()
     tot = C.c_int64(0)
-    n = lib.lldwt_lifting_program(None, 0, Z, H, W, levels, int(bool(different)), block_offset, int(bool(inverse)), 0, Cc,
+    sc = int(bool(scale))
+    n = lib.lldwt_lifting_program(None, 0, Z, H, W, levels, int(bool(different)), block_offset, int(bool(inverse)), sc, Cc,
                                   C.byref(tot))
     if n < 0:
         check(n, "lifting_program")
     arr = (_lib.LiftOp * n)()
-    lib.lldwt_lifting_program(arr, n, Z, H, W, levels, int(bool(different)), block_offset, int(bool(inverse)), 0, Cc,
+    lib.lldwt_lifting_program(arr, n, Z, H, W, levels, int(bool(different)), block_offset, int(bool(inverse)), sc, Cc,
                               C.byref(tot))
     return list(arr), int(tot.value)
 
 
-def lifting_forward_train(x, taps, packed, levels, Cc, K, res_weight, linear, different, block_offset, saved):
+def lifting_forward_train(x, taps, packed, levels, Cc, K, res_weight, linear, different, block_offset, saved, scale_nh=None,
+                          scale_nl=None):
     lib = _lib.load()
     P, B, _, H, W = x.shape
     dev = x.device
@@ -676,14 +679,14 @@ def lifting_forward_train(x, taps, packed, levels, Cc, K, res_weight, linear, di
     yh = [torch.empty(P, B, 3, H >> (i + 1), W >> (i + 1), device=dev, dtype=torch.float32) for i in range(levels)]
     nb = lib.lldwt_lifting_ws_bytes(P * B, H, W, Cc)
     ws = workspace(nb, dev)
-    check(lib.lldwt_lifting_forward_train(_chk(x, "x"), _chk(ll), _ptr_array(yh), P, B, H, W, levels, _chk(taps),
-                                          _chk(packed), int(packed.shape[1]), int(block_offset), int(bool(different)), Cc, K,
-                                          float(res_weight), int(bool(linear)), C.c_void_p(ws.data_ptr()), nb,
-                                          _chk(saved), _stream()), "lifting_forward_train")
+    check(lib.lldwt_lifting_forward_train_ex(_chk(x, "x"), _chk(ll), _ptr_array(yh), P, B, H, W, levels, _chk(taps),
+                                             _chk(packed), int(packed.shape[1]), int(block_offset), int(bool(different)), Cc, K,
+                                             float(res_weight), int(bool(linear)), _opt(scale_nh), _opt(scale_nl),
+                                             C.c_void_p(ws.data_ptr()), nb, _chk(saved), _stream()), "lifting_forward_train")
     return ll, yh
 
 
-def lifting_inverse_train(ll, yh, taps, packed, Cc, K, res_weight, linear, block_offset, saved):
+def lifting_inverse_train(ll, yh, taps, packed, Cc, K, res_weight, linear, block_offset, saved, scale_nh=None, scale_nl=None):
     lib = _lib.load()
     levels = len(yh)
     P, B, _, hl, wl = ll.shape
@@ -693,10 +696,10 @@ def lifting_inverse_train(ll, yh, taps, packed, Cc, K, res_weight, linear, block
         _chk(t, "yh")
     nb = lib.lldwt_lifting_ws_bytes(P * B, H, W, Cc)
     ws = workspace(nb, ll.device)
-    check(lib.lldwt_lifting_inverse_train(_chk(ll), _ptr_array(yh), _chk(x), P, B, H, W, levels, _chk(taps), _chk(packed),
-                                          int(packed.shape[1]), int(block_offset), Cc, K, float(res_weight),
-                                          int(bool(linear)), C.c_void_p(ws.data_ptr()), nb, _chk(saved), _stream()),
-          "lifting_inverse_train")
+    check(lib.lldwt_lifting_inverse_train_ex(_chk(ll), _ptr_array(yh), _chk(x), P, B, H, W, levels, _chk(taps), _chk(packed),
+                                             int(packed.shape[1]), int(block_offset), Cc, K, float(res_weight),
+                                             int(bool(linear)), _opt(scale_nh), _opt(scale_nl), C.c_void_p(ws.data_ptr()), nb,
+                                             _chk(saved), _stream()), "lifting_inverse_train")
     return x
 
 

@@ -151,6 +151,18 @@ int lldwt_lifting_inverse_train(const float* ll, const float* const* yh, float* 
                                 int64_t H, int64_t W, int levels, const float* taps, const float* packed, int nblocks,
                                 int block_offset, int C, int K, float res_weight, int linear, void* ws, int64_t ws_bytes,
                                 float* saved, void* stream);
+/* the same with the per-plane gains of config.scale == 1 (wavelet_forward_v2.py:76-80, wavelet_inverse_v2.py:70-74; both
+ * null = no scaling).  Build the program with scale = 1: every scale op (kind 1..4) then owns h*w*Z floats of `saved` at
+ * its saved_off and keeps its INPUT there (dense Z,h,w), which the host-side backward needs for d(gain). */
+int lldwt_lifting_forward_train_ex(const float* x, float* ll, float* const* yh, int64_t planes, int64_t batch, int64_t H,
+                                   int64_t W, int levels, const float* taps, const float* packed, int nblocks,
+                                   int block_offset, int different, int C, int K, float res_weight, int linear,
+                                   const float* scale_nh, const float* scale_nl, void* ws, int64_t ws_bytes, float* saved,
+                                   void* stream);
+int lldwt_lifting_inverse_train_ex(const float* ll, const float* const* yh, float* x, int64_t planes, int64_t batch,
+                                   int64_t H, int64_t W, int levels, const float* taps, const float* packed, int nblocks,
+                                   int block_offset, int C, int K, float res_weight, int linear, const float* scale_nh,
+                                   const float* scale_nl, void* ws, int64_t ws_bytes, float* saved, void* stream);
 /* backward pieces of one step (chained by the host with lldwt_conv2d / lldwt_conv2d_wgrad_ex):
  *   pre: g (dense Z,h,w) = G[dst_out];  G[dst_in] = g
  *   fin: dskip = sign*(g + res_weight*dsk);  G[src] += taps^T (x) dskip;  dtaps (planes,3) += sum dskip * src shifted */

@@ -188,17 +188,28 @@ def _lift_stacks(sds, nblocks, gu):
     return gu.dev(taps), [gu.dev(t) for t in W]
 
 
-@pytest.mark.parametrize("K,different,linear", [(5, False, False), (3, True, False), (3, False, True)])
-def test_lifting_forward_backward(K, different, linear):
-    """LiftingFn / LiftingInvFn gradients (input, skip-filter taps, every P/U-block parameter) vs torch autograd on the oracle."""
+@pytest.mark.parametrize("K,different,linear,scale", [(5, False, False, False), (3, True, False, False), (3, False, True, False),
+                                                      (5, False, False, True), (3, False, True, True)])
+def test_lifting_forward_backward(K, different, linear, scale):
+    """LiftingFn / LiftingInvFn gradients (input, skip-filter taps, every P/U-block parameter, and with config.scale == 1 the
+    gains nh / nl of wavelet_forward_v2.py:76-80) vs torch autograd on the oracle."""
     ag, ops, gu = _mods()
     from helpers import filled
     from oracle import lifting, model, weights
     L, P, B, H, W = 2, 2, 2, 16, 32
     cfg = dict(model.DEFAULT_CFG, dwtlevels=L, filtersize=K, block_property="different" if different else "same",
-               linearity_flag=0 if linear else 1)
+               linearity_flag=0 if linear else 1, scale=1 if scale else 0)
     nblocks = 2 * 2 * L if different else 2
     sds = [filled(weights.autoencoder_template(cfg), "bw%d." % p) for p in range(P)]
+
+    def gains():
+        if not scale:
+            return None, None
+        nh = torch.stack([lifting.LIFTING_COEFF[4] + sd["nh"].reshape(()) * 0.1 for sd in sds]).float()
+        nl = torch.stack([lifting.LIFTING_COEFF[5] + sd["nl"].reshape(()) * 0.1 for sd in sds]).float()
+        return gu.dev(nh).requires_grad_(True), gu.dev(nl).requires_grad_(True)
+    nh, nl = gains()
+    nh2, nl2 = gains()
     meta = dict(levels=L, C=16, K=K, rw=0.1, linear=linear, different=different)
     g = torch.Generator().manual_seed(21)
     x = torch.rand(P, B, 1, H, W, generator=g) - 0.5
@@ -207,7 +218,7 @@ def test_lifting_forward_backward(K, different, linear):
     for t in Wt:
         t.requires_grad_(True)
     xd = gu.dev(x).requires_grad_(True)
-    outs = ag.LiftingFn.apply(xd, taps, meta, *Wt)
+    outs = ag.LiftingFn.apply(xd, taps, meta, nh, nl, *Wt)
     gouts = [torch.rand(o.shape, generator=g) - 0.5 for o in outs]
     torch.autograd.backward(outs, [gu.dev(t) for t in gouts])
     # inverse on the same coefficients
@@ -216,7 +227,7 @@ def test_lifting_forward_backward(K, different, linear):
     for t in Wt2:
         t.requires_grad_(True)
     cin = [o.detach().clone().requires_grad_(True) for o in outs]
-    xr = ag.LiftingInvFn.apply(taps2, meta, L, *cin, *Wt2)
+    xr = ag.LiftingInvFn.apply(taps2, meta, L, nh2, nl2, *cin, *Wt2)
     gx = torch.rand(xr.shape, generator=g) - 0.5
     xr.backward(gu.dev(gx))
     for p in range(P):
@@ -242,6 +253,10 @@ def test_lifting_forward_backward(K, different, linear):
                         else:
                             assert maxdiff(got, r) < 5e-4 * max(1.0, float(r.abs().max())), (n, k, b, kind)
                 idx += 1
+        if scale:       # d/d(sd.nh) = 0.1 d/d(gain)
+            for got, key in ((nh, "nh"), (nl, "nl")):
+                r = sd[key].grad.reshape(())
+                assert abs(float(got.grad[p]) * 0.1 - float(r)) < 5e-4 * max(1.0, abs(float(r))), key
         # inverse
         sd2 = {k: v.clone().requires_grad_(True) for k, v in sds[p].items()}
         ci = [c[p].detach().cpu().clone().requires_grad_(True) for c in cin]
@@ -254,6 +269,10 @@ def test_lifting_forward_backward(K, different, linear):
             assert maxdiff(taps2.grad[j, p].cpu(), sd2["preProcessingList.%d.weight" % j].grad.reshape(3)) < 2e-3
         r = sd2["U_blocks.%d.conv2.weight" % (2 * L if different else 0)].grad
         assert maxdiff(Wt2[2].grad[2 * L if different else 0, 1, p].cpu(), r) < 5e-4 * max(1.0, float(r.abs().max()))
+        if scale:
+            for got, key in ((nh2, "nh"), (nl2, "nl")):
+                r = sd2[key].grad.reshape(())
+                assert abs(float(got.grad[p]) * 0.1 - float(r)) < 5e-4 * max(1.0, abs(float(r))), key
 
 
 def test_gauss_rate_backward():
