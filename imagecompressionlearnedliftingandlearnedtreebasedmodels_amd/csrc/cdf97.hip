@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_cdf97_fwd_level(V3 in, V3 ll, V3 lh, V3
     }
 }
 
-// Fast variant of the forward level for rows of contiguous pixels, w % 4 == 0 and h, w >= CIN (every level of a 512^2
+// Fast variant of the forward level for rows of contiguous pixels, w % 4 == 0 and h, w >= 64 (every level of a 512^2
 // or larger image but the deepest ones).  Same arithmetic as k_cdf97_fwd_level (the zero taps of the table are skipped),
 // organised for the memory pipe:
 //   * the input patch arrives as dwordx4 loads (the patch starts at a multiple of 4 pixels, so a vector never straddles
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void k_cdf97_inv_level(V3 ll, V3 lh, V3 hl, V3
     }
 }
 
-// Fast variant of the inverse level (contiguous rows, subband edges >= CS and even): dwordx2 loads of the four subband
+// Fast variant of the inverse level (contiguous rows, subband edges >= 32 and even): dwordx2 loads of the four subband
 // patches, 8-byte LDS words, each thread reconstructs an (even, odd) row pair of two columns in the height pass and four
 // consecutive pixels in the width pass (both parities share their five input rows / columns); zero taps are skipped.
 constexpr float REC_LO[10] = {0.0f, -0.064538882628697f, -0.040689417609164f, 0.418092273221617f, 0.788485616405583f,
@@ -562,7 +562,8 @@ extern "C" int lldwt_cdf97_forward_ex(const float* x, float* ll, float* const* y
         V3 vLL{llout, sub, wh, 1}, vLH{y, 3 * sub, wh, 1}, vHL{y + sub, 3 * sub, wh, 1}, vHH{y + 2 * sub, 3 * sub, wh, 1};
         if (!adj) {       // fused level: one read of the input, one write of the four subbands
             dim3 grid((unsigned)(cdiv(wh, CT) * cdiv(hh, CT) * Z));
-            if (h >= CIN && w >= CIN && w % 4 == 0 && in.sx == 1)
+            // one conditional wrap per index is enough from 64 samples up (the 72-wide patch of the last tile ends below 2 h)
+            if (h >= 2 * CT && w >= 2 * CT && w % 4 == 0 && in.sx == 1)
                 hipLaunchKernelGGL(k_cdf97_fwd_level_v, grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
             else
                 hipLaunchKernelGGL(k_cdf97_fwd_level, grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
@@ -601,7 +602,8 @@ extern "C" int lldwt_cdf97_inverse_ex(const float* ll, const float* const* yh, f
         V3 vo{out, h * w, w, 1};
         if (!adj) {
             dim3 grid((unsigned)(cdiv(w, 2 * CT) * cdiv(h, 2 * CT) * Z));
-            if (hh >= CS && wh >= CS && wh % 2 == 0)
+            // the same for the 36-wide subband patches from 32 samples up
+            if (hh >= CT && wh >= CT && wh % 2 == 0)
                 hipLaunchKernelGGL(k_cdf97_inv_level_v, grid, dim3(256), 0, st, vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
             else
                 hipLaunchKernelGGL(k_cdf97_inv_level, grid, dim3(256), 0, st, vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
