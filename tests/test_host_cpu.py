@@ -154,3 +154,32 @@ def test_csc_fold_algebra_matches_the_unfused_layers():
     gfold = grads()
     for a, b in zip(gfold, gref):
         assert float((a - b).abs().max()) < 1e-9
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("scale", [False, True])
+def test_lifting_program_layout_host_side(inverse, scale):
+    """lldwt_lifting_program is host code (no GPU): per level 12 lifting steps (+ 6 gain ops with scale == 1,
+    wavelet_forward_v2.py:76-80 / wavelet_inverse_v2.py:70-74); every op owns a disjoint slice of the saved buffer -- a
+    lifting step (2 + 3 C) floats per element, a gain op one float per element (its input, which the backward needs) --
+    and the slices tile [0, saved_floats) in program order."""
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    Z, H, W, L, C_ = 6, 64, 96, 3, 16
+    prog, total = ops.lifting_program(Z, H, W, L, False, 0, inverse, C_, scale)
+    steps = [o for o in prog if o.kind == 0]
+    gains = [o for o in prog if o.kind != 0]
+    assert len(steps) == 12 * L and len(gains) == (6 * L if scale else 0)
+    assert {o.kind for o in gains} == (set() if not scale else ({3, 4} if inverse else {1, 2}))
+    off = 0
+    for o in prog:
+        assert o.saved_off == off
+        n = Z * o.h * o.w
+        off += n * (2 + 3 * C_) if o.kind == 0 else n
+    assert off == total
+    # the gain ops of the forward transform work in place; the inverse's first ones write scaled copies elsewhere
+    for o in gains:
+        same = (o.buf_src, o.off_src) == (o.buf_dout, o.off_dout)
+        assert same or inverse
+    # without gains the program and its saved size are what they were before gain ops kept anything
+    prog0, total0 = ops.lifting_program(Z, H, W, L, False, 0, inverse, C_, False)
+    assert total0 == sum(Z * o.h * o.w * (2 + 3 * C_) for o in prog0)
