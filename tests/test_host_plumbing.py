@@ -361,3 +361,20 @@ def test_world2_real_autograd_through_flat_bucket_keeps_replicas_identical():
     (_, w0, lr0, c0), (_, w1, lr1, c1) = res
     assert w0 == w1                                                   # bit-identical parameters after 12 steps
     assert lr0 == lr1 and c0 == c1                                    # same plateau decisions
+
+
+def test_bench_refuses_mislabelled_world_sizes():
+    """bench.py never reports a line for another number of ranks than --gpus asks for: without enough visible GPUs the
+    self-launcher exits with code 2 before touching a device, and under a launcher whose WORLD_SIZE differs from --gpus it
+    exits with code 2 as well (both paths run without a GPU)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LLDWT_BENCH_REHEARSE")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+    env2 = dict(env, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
