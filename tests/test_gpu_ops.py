@@ -267,3 +267,18 @@ def test_cdf97_short_levels_vs_pywt():
     for i in range(5):
         assert maxdiff(yh[i][0].cpu(), oyh[i]) < 5e-5, i
     assert maxdiff(ops.cdf97_inverse(ll, yh).cpu(), x) < 5e-5
+
+
+@pytest.mark.parametrize("shape,levels", [((1, 2, 1, 68, 136), 1), ((1, 1, 2, 140, 72), 2), ((1, 1, 1, 64, 64), 1)])
+def test_cdf97_fast_kernels_near_their_size_limit(shape, levels):
+    """The fast tile kernels take levels from 64 samples (forward) / 32-sample subbands (inverse): the 72-wide patch of a
+    tile is then wider than what is left of the image and wraps -- including a second, nearly empty tile (68 rows -> 34
+    subband rows).  Compared with the oracle's periodic transform, and inverted."""
+    ops, gu = _ops()
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[-1])) - 0.5
+    ll, yh = ops.cdf97_forward(gu.dev(x), levels)
+    oll, oyh = cdf97.dwt_forward(x[0], levels, periodic=True)
+    assert maxdiff(ll[0].cpu(), oll) < 5e-5
+    for i in range(levels):
+        assert maxdiff(yh[i][0].cpu(), oyh[i]) < 5e-5, i
+    assert maxdiff(ops.cdf97_inverse(ll, yh).cpu(), x) < 5e-5
