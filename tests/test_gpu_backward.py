@@ -64,11 +64,14 @@ def test_conv_backward(case):
         assert maxdiff(bd.grad[p].cpu(), br.grad) < 2e-4 * max(1.0, float(br.grad.abs().max())), case
 
 
-def test_conv_backward_residual_and_large():
-    """Residual branch gradient + a spatial size that is not a multiple of the 8x16 wgrad chunk."""
+@pytest.mark.parametrize("hw", [(21, 37), (72, 136)])
+def test_conv_backward_residual_and_large(hw):
+    """Residual branch gradient + a spatial size that is not a multiple of the 8x16 wgrad chunk; 72x136 has interior
+    tiles of every conv-engine tile shape and several weight-gradient chunks per K slice."""
     ag, ops, gu = _mods()
     g = torch.Generator().manual_seed(5)
-    P, B, C, K, h, w = 1, 2, 16, 5, 21, 37
+    P, B, C, K = 1, 2, 16, 5
+    h, w = hw
     x = torch.rand(P, B, C, h, w, generator=g) - 0.5
     wt = (torch.rand(P, C, C, K, K, generator=g) - 0.5) * 0.2
     b = torch.rand(P, C, generator=g) - 0.5
@@ -87,13 +90,15 @@ def test_conv_backward_residual_and_large():
 
 @pytest.mark.parametrize("cin,cout", [(16, 16), (1, 16), (16, 1)])
 @pytest.mark.parametrize("K", [3, 5])
-@pytest.mark.parametrize("swap", [False, True])
-def test_wgrad_lifting_shapes(cin, cout, K, swap):
+@pytest.mark.parametrize("swap,geom", [(False, (2, 3, 29, 43)), (True, (2, 3, 29, 43)),
+                                       # many 8x16 chunks per K slice, several slices per plane
+                                       (False, (1, 2, 136, 200)), (True, (1, 1, 128, 96))])
+def test_wgrad_lifting_shapes(cin, cout, K, swap, geom):
     """The dedicated P-block weight-gradient kernels (16 -> 16 tap-tiled, 1 <-> 16 thin): ragged spatial size, several
     K slices, alpha scaling, accumulation into a non-zero dW, and the (kh,kw)-swapped output of the row passes."""
     ag, ops, gu = _mods()
     g = torch.Generator().manual_seed(100 * cin + 10 * cout + K)
-    P, B, h, w = 2, 3, 29, 43
+    P, B, h, w = geom
     x = torch.rand(P, B, cin, h, w, generator=g) - 0.5
     gy = torch.rand(P, B, cout, h, w, generator=g) - 0.5
     dw0 = torch.rand(P, cout, cin, K, K, generator=g) - 0.5
@@ -111,13 +116,18 @@ def test_wgrad_lifting_shapes(cin, cout, K, swap):
         assert maxdiff(db[p].cpu(), db0[p] + alpha * br.grad) < 2e-5 * max(1.0, float(br.grad.abs().max()))
 
 
-@pytest.mark.parametrize("dims,hw", [((162, 162, 54, 18), (9, 13)), ((20, 12, 8, 4), (8, 24))])
-def test_cgp_fused_forward_backward(dims, hw):
+@pytest.mark.parametrize("dims,hw,PB", [((162, 162, 54, 18), (9, 13), (2, 2)), ((20, 12, 8, 4), (8, 24), (2, 2)),
+                                        # 24 576 pixels = 384 columns of 64: every persistent workgroup
+                                        # of k_cgp_rate<true> / k_cgp_bwd walks several 8-column groups with register prefetch
+                                        ((162, 162, 54, 18), (128, 192), (1, 1)), ((162, 162, 54, 18), (67, 131), (2, 1))])
+def test_cgp_fused_forward_backward(dims, hw, PB):
     """CgpRateFn (fused cgp stack + Gaussian rate, forward and backward) vs torch autograd over the same maths: ragged
-    pixel count (not a multiple of the 64-pixel column), the reference widths and a narrow stack."""
+    pixel count (not a multiple of the 64-pixel column), the reference widths and a narrow stack, and sizes at which the
+    kernels' multi-column persistence runs (LiftingBasedDWT_net.py:282-289,357-365)."""
     ag, ops, gu = _mods()
     g = torch.Generator().manual_seed(sum(dims))
-    P, B, G = 2, 2, 3
+    P, B = PB
+    G = 3
     h, w = hw
     c = list(dims) + [2]
     cat = torch.randn(P, B, G * c[0], h, w, generator=g)
@@ -188,15 +198,21 @@ def _lift_stacks(sds, nblocks, gu):
     return gu.dev(taps), [gu.dev(t) for t in W]
 
 
-@pytest.mark.parametrize("K,different,linear,scale", [(5, False, False, False), (3, True, False, False), (3, False, True, False),
-                                                      (5, False, False, True), (3, False, True, True)])
-def test_lifting_forward_backward(K, different, linear, scale):
+@pytest.mark.parametrize("K,different,linear,scale,geom", [
+    (5, False, False, False, (2, 2, 16, 32)), (3, True, False, False, (2, 2, 16, 32)), (3, False, True, False, (2, 2, 16, 32)),
+    (5, False, False, True, (2, 2, 16, 32)), (3, False, True, True, (2, 2, 16, 32)),
+    # sizes where the 16x32 lifting tiles have INTERIOR tiles and a persistent workgroup walks several
+    # tiles (level-0 half arrays 128x96 / 64x96 ..., level 1 64x48): the fast paths the training leg of bench.py runs
+    (5, False, False, False, (1, 1, 128, 192)), (3, True, False, True, (1, 2, 96, 160))])
+def test_lifting_forward_backward(K, different, linear, scale, geom):
     """LiftingFn / LiftingInvFn gradients (input, skip-filter taps, every P/U-block parameter, and with config.scale == 1 the
-    gains nh / nl of wavelet_forward_v2.py:76-80) vs torch autograd on the oracle."""
+    gains nh / nl of wavelet_forward_v2.py:76-80) vs torch autograd on the oracle -- at border-only sizes and at sizes with
+    interior tiles (agents/liftingDWT_agent.py:96-98 through wavelet_forward_v2.py:58-81)."""
     ag, ops, gu = _mods()
     from helpers import filled
     from oracle import lifting, model, weights
-    L, P, B, H, W = 2, 2, 2, 16, 32
+    L = 2
+    P, B, H, W = geom
     cfg = dict(model.DEFAULT_CFG, dwtlevels=L, filtersize=K, block_property="different" if different else "same",
                linearity_flag=0 if linear else 1, scale=1 if scale else 0)
     nblocks = 2 * 2 * L if different else 2
@@ -240,7 +256,8 @@ def test_lifting_forward_backward(K, different, linear, scale):
         torch.autograd.backward(ref, [t[p] for t in gouts])
         assert maxdiff(xd.grad[p].cpu(), xp.grad) < 2e-4
         for j in range(4):
-            assert maxdiff(taps.grad[j, p].cpu(), sd["preProcessingList.%d.weight" % j].grad.reshape(3)) < 2e-3
+            rt = sd["preProcessingList.%d.weight" % j].grad.reshape(3)        # sums over every pixel: relative at large sizes
+            assert maxdiff(taps.grad[j, p].cpu(), rt) < 2e-3 * max(1.0, float(rt.abs().max())), j
         idx = 0
         for n in (1, 2, 3, 4):
             for k in ("weight", "bias"):
@@ -266,7 +283,8 @@ def test_lifting_forward_backward(K, different, linear, scale):
         for a, b_ in zip(cin, ci):
             assert maxdiff(a.grad[p].cpu(), b_.grad) < 2e-4
         for j in range(4):
-            assert maxdiff(taps2.grad[j, p].cpu(), sd2["preProcessingList.%d.weight" % j].grad.reshape(3)) < 2e-3
+            rt = sd2["preProcessingList.%d.weight" % j].grad.reshape(3)
+            assert maxdiff(taps2.grad[j, p].cpu(), rt) < 2e-3 * max(1.0, float(rt.abs().max())), j
         r = sd2["U_blocks.%d.conv2.weight" % (2 * L if different else 0)].grad
         assert maxdiff(Wt2[2].grad[2 * L if different else 0, 1, p].cpu(), r) < 5e-4 * max(1.0, float(r.abs().max()))
         if scale:
