@@ -147,7 +147,7 @@ struct Cgp16Args {
     int ntaps;
     int tap_dy[25], tap_dx[25];
     int cols;              // 64-pixel columns per image
-    unsigned long long* stamps;   // diagnostics only (LLDWT_CGP_STAMPS = device address): [z][group][column][8] s_memtime stamps
+    unsigned long long* stamps;   // diagnostics only (lldwt_set_diagnostics kind 2): [z][group][column][8] s_memtime stamps
 };
 #define CGP_STAMP(i)                                                                                                    \
     if (a.stamps && lane == 0)                                                                                          \
@@ -392,6 +392,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }  // namespace lldwt
 using namespace lldwt;
 
+static unsigned long long* g_cgp_stamps = nullptr;
+static int64_t g_cgp_stamps_bytes = 0;
+namespace lldwt { void cgp16_set_stamps(void* p, int64_t nbytes) { g_cgp_stamps = reinterpret_cast<unsigned long long*>(p); g_cgp_stamps_bytes = p ? nbytes : 0; } }
+
 extern "C" int64_t lldwt_cgp16_packed_bytes(int c0, int c1, int c2, int c3, int groups) {
     if (c0 != C0 || c1 != C1 || c2 != C2 || c3 != C3 || groups <= 0) return -1;     // the reference's dimensions only
     return (int64_t)groups * GROUP_BYTES;
@@ -427,9 +431,9 @@ extern "C" int lldwt_cgp16_params(const float* plc, const float* xq, const void*
     LLDWT_REQUIRE(n == C0 - CPLC, "cgp16_params: %d live taps, the folded first layer expects %d", n, C0 - CPLC);
     a.ntaps = n;
     a.cols = (int)cdiv(h * w_, 32 * NB);
-    {
-        const char* stp = getenv("LLDWT_CGP_STAMPS");
-        a.stamps = stp ? reinterpret_cast<unsigned long long*>(strtoull(stp, nullptr, 0)) : nullptr;
+    {   // diagnostics (tools/cgp_stamps.py, lldwt_set_diagnostics): only when the registered buffer holds this grid's stamps
+        const int64_t need = (int64_t)planes * batch * groups * a.cols * 8 * 8;
+        a.stamps = (g_cgp_stamps && g_cgp_stamps_bytes >= need) ? g_cgp_stamps : nullptr;
     }
     dim3 grid((unsigned)cdiv(a.cols, 4), (unsigned)groups, (unsigned)(planes * batch));
     hipLaunchKernelGGL(k_cgp16, grid, dim3(256), 0, (hipStream_t)stream, a);

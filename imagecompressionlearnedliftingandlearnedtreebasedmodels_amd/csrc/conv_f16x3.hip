@@ -197,7 +197,7 @@ struct F3Args {
     int64_t plane_bytes1;
     int cin, cout, act, batch, h, w, tiles_x, nch;
     int64_t plane_bytes;
-    unsigned long long* stamps;   // diagnostics only (LLDWT_F3_STAMPS = device address): [workgroup][wave][16] s_memtime stamps
+    unsigned long long* stamps;   // diagnostics only (lldwt_set_diagnostics kind 1): [workgroup][wave][16] s_memtime stamps
 };
 // in-kernel clock stamps of a diagnostic run (tools/plc_stamps.py); a null pointer (always, outside that tool) skips them
 #define F3_STAMP(i)                                                                                                     \
@@ -696,6 +696,10 @@ extern "C" int lldwt_plc_fused_pack1(const float* w1, const float* b1, void* pac
     return check_launch("plc_fused_pack1");
 }
 
+static unsigned long long* g_f3_stamps = nullptr;
+static int64_t g_f3_stamps_bytes = 0;
+namespace lldwt { void f3_set_stamps(void* p, int64_t nbytes) { g_f3_stamps = reinterpret_cast<unsigned long long*>(p); g_f3_stamps_bytes = p ? nbytes : 0; } }
+
 extern "C" int lldwt_plc_fused(const float* parent, float* y, const void* packed1, const void* packed2, const float* bias2,
                                int cmid, int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream) {
     LLDWT_REQUIRE(parent && y && packed1 && packed2, "plc_fused: null pointer");
@@ -709,13 +713,13 @@ extern "C" int lldwt_plc_fused(const float* parent, float* y, const void* packed
     a.parent = parent; a.packed1 = reinterpret_cast<const uint8_t*>(packed1); a.plane_bytes1 = f1_plane_bytes(cmid);
     a.cin = cmid; a.cout = cout; a.act = act; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
     a.tiles_x = (int)cdiv(w_, F3_TW);
-    {
-        const char* stp = getenv("LLDWT_F3_STAMPS");
-        a.stamps = stp ? reinterpret_cast<unsigned long long*>(strtoull(stp, nullptr, 0)) : nullptr;
-    }
     a.nch = f3_nch(cmid);
     a.plane_bytes = f3_plane_bytes(cmid, cout);
     const int tiles_y = (int)cdiv(h, F3_TH);
+    {   // diagnostics (tools/plc_stamps.py, lldwt_set_diagnostics): only when the registered buffer holds this grid's stamps
+        const int64_t need = (int64_t)a.tiles_x * tiles_y * f3_nocb(cout) * planes * batch * 4 * 16 * 8;
+        a.stamps = (g_f3_stamps && g_f3_stamps_bytes >= need) ? g_f3_stamps : nullptr;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)k_conv3_f16x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS) != hipSuccess) {

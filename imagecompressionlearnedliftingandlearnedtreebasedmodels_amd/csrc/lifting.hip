@@ -1479,6 +1479,20 @@ using namespace lldwt;
 
 extern "C" int64_t lldwt_pblock_packed_floats(int C, int K) { return pack_off(C, K).total; }
 
+extern "C" int lldwt_set_diagnostics(int kind, void* stamps, int64_t nbytes, int flags) {
+    LLDWT_REQUIRE(kind >= 0 && kind <= 2, "set_diagnostics: kind %d (0 = fused lifting step, 1 = tree-pair conv, 2 = cgp chain)", kind);
+    LLDWT_REQUIRE(nbytes >= 0 && (stamps != nullptr || nbytes == 0), "set_diagnostics: bad buffer");
+    if (kind == 0) {
+        lift_f16_set_stamps(stamps, nbytes);
+        lift_f16_set_debug(flags);
+    } else if (kind == 1) {
+        f3_set_stamps(stamps, nbytes);
+    } else {
+        cgp16_set_stamps(stamps, nbytes);
+    }
+    return LLDWT_OK;
+}
+
 extern "C" int lldwt_set_lift_mode(int mode) {
     LLDWT_REQUIRE(mode == 0 || mode == 1, "set_lift_mode: 0 (fp32 MFMA kernels) or 1 (fused split-fp16 kernel)");
     g_lift_mode = mode;

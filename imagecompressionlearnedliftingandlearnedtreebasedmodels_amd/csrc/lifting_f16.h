@@ -44,4 +44,11 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
                    const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical,
                    float sign, float rw, hipStream_t st);
 
+// diagnostics (lldwt_set_diagnostics): debug mask of the fused step (bit i = skip phase i+1, 16 = sequential conv3 / conv4,
+// 32 = no vertical reuse) and the stamp buffers of the three split-fp16 kernel families
+void lift_f16_set_debug(int dbg);
+void lift_f16_set_stamps(void* p, int64_t nbytes);
+void f3_set_stamps(void* p, int64_t nbytes);
+void cgp16_set_stamps(void* p, int64_t nbytes);
+
 }  // namespace lldwt

@@ -54,9 +54,31 @@ constexpr int NS16 = NS + 48;                                         // copy 1 
 constexpr int LDS_TOTAL = LDS_S16 + 4 * NS16 * 2;                     // at odd columns); tails zeroed; copy 1 starts 16 banks after
 static_assert((2 * NS16 * 2) % 128 == 64, "even- and odd-column lanes read different banks");   // copy 0.  159,360 B
 constexpr int LDS_T3 = LDS_T1, LDS_D = LDS_T2;
-constexpr int LDS_STG = LDS_T2 + 20480;                               // next tile's operands, 10 floats per thread, inside T2
+constexpr int LDS_STG = LDS_T2 + 20480;                               // sequential path: next tile's operands, 10 floats per thread, inside T2
 static_assert(ND * 8 * 4 <= 20480 && 20480 + 10 * NTH * 4 <= 4 * N2 * 16, "staging fits T2 behind the sequential path's D image");
 static_assert(4 * N3 * 16 <= 4 * N1 * 16 && ND * 8 * 4 <= 4 * N2 * 16, "aliases fit");
+// ---- vertical reuse (composed path).  A workgroup walks DOWN a column of tiles (a "run"); the tile below needs t1 on image
+// rows y0 + 10 .. y0 + 38 and t2 on y0 + 12 .. y0 + 36, of which the first 12 (t1) and 8 (t2) rows are the LAST rows of this
+// tile's T images: they are handed down (moved to the top of the images through registers while the skip patch of the next
+// tile is built), and the tile below computes 16 new rows of each instead of 28 / 24 -- 44 conv1 tiles instead of 77, 40
+// conv2 tiles instead of 60.  Everything that used to alias T1 / T2 now lives in the rows that die:
+//   T1 rows 0..15 of each of the four arrays (11 264 B): a quarter of the D image (output rows 4k..4k+3, 7 680 B), then a
+//   quarter of the border strips' t3v (56 positions x 64 B);  T2 rows 8..15 (5 120 B per array): the next tile's staged
+//   operands (20 480 B across the four arrays).
+constexpr int KEEP1 = 12, KEEP2 = 8;                                  // rows handed down
+constexpr int T1A = N1 * 16, T2A = N2 * 16;                           // bytes per array
+constexpr int NT1C = (N1 - KEEP1 * R1W) / 16, NT2C = (N2 - KEEP2 * R2W) / 16;      // 44, 40
+static_assert((KEEP1 * R1W) % 16 == 0 && (KEEP2 * R2W) % 16 == 0, "a continuing tile starts on a whole MFMA tile");
+constexpr int DPIECE_PX = 4 * R2W, DPIECE_BYTES = DPIECE_PX * 12 * 4;  // 160 px, 7 680 B
+constexpr int T3V_PER = 56;
+constexpr int T2HALF = KEEP2 * R2W * 16;                              // 5 120 B: rows 0..7 (and rows 8..15) of a T2 array
+static_assert(DPIECE_BYTES + T3V_PER * LF_C * 4 <= (N1 - KEEP1 * R1W) * 16, "D quarter + t3v quarter fit the dying rows of a T1 array");
+static_assert(10 * NTH * 4 <= 4 * T2HALF && 2 * T2HALF == (N2 - KEEP2 * R2W) * 16, "a staging quarter fits half of the dying rows of a T2 array");
+static_assert(4 * T3V_PER >= 4 * R3W + 4 * (TH + 4), "the strip buffer holds every tile's border strips");
+constexpr int LDS_W4L = LDS_TOTAL;                                    // conv4's fp32 weights [tap][channel] (border tiles)
+constexpr int LDS_CORR = LDS_W4L + LF_KK * LF_C * 4;                  // per output pixel: sum of the conv4 taps that fall outside the image
+constexpr int LDS_TOTAL2 = LDS_CORR + TH * TW * 4;                    // 163 008 B
+static_assert(LDS_TOTAL2 <= 160 * 1024, "one workgroup per CU");
 constexpr float ACT_SCALE = 16384.f;                                  // tanh outputs: |t| <= 1 -> |t * 2^14| < fp16 max
 
 __device__ __forceinline__ float pow2_scale(float amax) {             // s = 2^k with amax * s in [2^14, 2^15)
@@ -203,10 +225,11 @@ struct LfArgs {
     int f16;              // float offset of this orientation's f16 section
     int batch, h, w, vertical;
     float sign, rw;
-    int dbg;              // diagnostics only (LLDWT_LF_DBG): bit i set = skip the tile loop of phase P(i+1); results are then wrong
-    unsigned long long* stamps;   // diagnostics only (LLDWT_LF_STAMPS = device address): [tile][wave][16] s_memtime stamps
+    int dbg;              // diagnostics only (lldwt_set_diagnostics flags): bit i set = skip the tile loop of phase P(i+1); results are then wrong
+    unsigned long long* stamps;   // diagnostics only (lldwt_set_diagnostics kind 0): [tile][wave][16] s_memtime stamps
     int tiles_x, tiles_y;
-    int64_t ntiles;               // tiles_x * tiles_y * Z
+    int rl, nseg;                 // run length (tiles a workgroup walks down before it moves to another column) and runs per column
+    int nitems;                   // runs of the launch: Z * tiles_x * nseg
 };
 // in-kernel clock stamps of a diagnostic run (tools/lift_stamps.py); a null pointer (always, outside that tool) skips them
 #define LF_STAMP(i)                                                                                                     \
@@ -315,6 +338,43 @@ __device__ __forceinline__ void conv16_tile2(const uint8_t* __restrict__ img, in
     }
 }
 
+// one tile, same pipeline (a continuing tile has 5 conv2 tiles per wave: two pairs and this one).  A single accumulation chain
+// of this MFMA needs no second accumulator for throughput (MI355X guide); the slice of the previous pair's epilogue rides here
+template <int WIN, int NIN, class Piece>
+__device__ __forceinline__ void conv16_tile1(const uint8_t* __restrict__ img, int base0, bool hi_tap, const half8 (&ah)[LF_KS],
+                                             const half8 (&al)[LF_KS], floatx4& acc0, Piece&& piece) {
+    acc0 = floatx4{0.f, 0.f, 0.f, 0.f};
+    half8 bh0[2], bl0[2];
+    const int dA = hi_tap ? 16 : 0, dW = hi_tap ? (WIN - 4) * 16 : 0;
+    const uint8_t* q0[3] = {img + base0 + dA, img + base0 + dW, img + base0};
+    auto load = [&](int ks, int set) {
+        const int ta = 2 * ks;
+        const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16;
+        const int sel = ks == LF_KS - 1 ? 2 : (ta % LF_K == LF_K - 1 ? 1 : 0);
+        bh0[set] = *reinterpret_cast<const half8*>(q0[sel] + offa);
+        bl0[set] = *reinterpret_cast<const half8*>(q0[sel] + 2 * NIN * 16 + offa);
+    };
+    load(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < LF_KS; ++ks) {
+        const int c = ks & 1;
+        if (ks + 1 < LF_KS) load(ks + 1, c ^ 1);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh0[c], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl0[c], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh0[c], acc0, 0, 0, 0);
+        piece(ks);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if (i == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // scheduling hint for a region that holds NM MFMAs next to LDS reads and vector work: one MFMA, one LDS read, a few VALU
 template <int NM>
 __device__ __forceinline__ void interleave_hint() {
@@ -392,19 +452,25 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         r.dout = second ? a.dout2 : a.v.dout;  r.dout_sz = second ? a.dout2_sz : a.v.dout_sz;
         return r;
     };
-    auto decode = [&](int64_t t, int64_t& z, int& y0, int& x0) {
-        z = t / tpi;
-        const int pos = (int)((t - z * tpi + z * 37) % tpi);
-        const int ty = pos / a.tiles_x;
-        y0 = ty * TH;
-        x0 = (pos - ty * a.tiles_x) * TW;
+    // work item = a RUN: rl vertically consecutive tiles of one column strip of one image (the last run of a column may be
+    // shorter).  The position of a run inside its image is rotated by the image index, so that a workgroup does not meet the
+    // (slower) border columns of every image.
+    const int ipi = a.tiles_x * a.nseg;                        // runs per image
+    auto decode = [&](int item, int j, int64_t& z, int& y0, int& x0, int& seglen) {
+        const int zi = item / ipi;
+        const int pos = (item - zi * ipi + zi * 37) % ipi;
+        const int sx = pos / a.nseg, seg = pos - sx * a.nseg;
+        z = zi;
+        y0 = (seg * a.rl + j) * TH;
+        x0 = sx * TW;
+        seglen = min(a.rl, a.tiles_y - seg * a.rl);
     };
     // branch-free: every load goes to a clamped (valid) address; P0 applies the zero padding when it consumes the values
-    auto fetch = [&](int64_t t, int tid, LfPre& pr) {
+    auto fetch = [&](int item, int j, int tid, LfPre& pr) {
         const int oy_ = tid / TW, ox_ = tid - oy_ * TW;        // this thread's output pixel inside a tile
         int64_t z;
-        int y0, x0;
-        decode(t, z, y0, x0);
+        int y0, x0, seglen_;
+        decode(item, j, z, y0, x0, seglen_);
         int64_t zz;
         const LiftF16Views vw = view_of_z(z, zz);
         const float* sp = vw.src + zz * vw.src_sz;
@@ -424,23 +490,32 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     // the fetched operands wait for their tile in LDS (each thread's own ten floats, written and read back by that thread
     // only: no barrier), not in registers carried around the tile loop (the register file is full in P2)
-    float* STG = reinterpret_cast<float*>(lds + LDS_STG);
+    // slot v (0..9) of thread tid.  Composed path: 20 KB laid across rows 8..15 of the four T2 arrays (rows 16..23 are handed
+    // down in place, rows 0..7 receive the handed-down rows at the start of the next tile); sequential path: behind its D image
+    auto stg = [&](int v, int tid) -> float* {
+        if constexpr (SEQ) return reinterpret_cast<float*>(lds + LDS_STG) + v * NTH + tid;
+        else {
+            const int off = (v * NTH + tid) * 4, arr = off / T2HALF;
+            return reinterpret_cast<float*>(lds + LDS_T2 + arr * T2A + T2HALF + (off - arr * T2HALF));
+        }
+    };
     auto stage = [&](int tid, const LfPre& pr) {
 #pragma unroll
         for (int k = 0; k < NS / NTH; ++k) {
-            STG[(3 * k + 0) * NTH + tid] = pr.c[k];
-            STG[(3 * k + 1) * NTH + tid] = pr.m[k];
-            STG[(3 * k + 2) * NTH + tid] = pr.p[k];
+            *stg(3 * k + 0, tid) = pr.c[k];
+            *stg(3 * k + 1, tid) = pr.m[k];
+            *stg(3 * k + 2, tid) = pr.p[k];
         }
-        STG[9 * NTH + tid] = pr.din;
+        *stg(9, tid) = pr.din;
     };
 
-    if ((int64_t)blockIdx.x < a.ntiles) {
+    if ((int)blockIdx.x < a.nitems) {
         LfPre pr0;
-        fetch(blockIdx.x, tid0, pr0);
+        fetch((int)blockIdx.x, 0, tid0, pr0);
         stage(tid0, pr0);
     }
-    for (int64_t tile_i = blockIdx.x; tile_i < a.ntiles; tile_i += gridDim.x) {
+    int item_i = (int)blockIdx.x, run_j = 0;
+    while (item_i < a.nitems) {
     // every per-lane index below derives from an OPAQUE copy of the thread id: otherwise the compiler hoists all the
     // tile-invariant per-lane address arithmetic of all phases out of the tile loop and spills it
     int tid = tid0;
@@ -450,8 +525,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool hi_tap = kg >= 2;
     const int halfsel = kg & 1;
     int64_t z;
-    int y0, x0;
-    decode(tile_i, z, y0, x0);
+    int y0, x0, seglen;
+    decode(item_i, run_j, z, y0, x0, seglen);
+    const bool cont = !SEQ && run_j > 0;                       // the tile above handed down its last T1 / T2 rows
+    const bool hand_down = !SEQ && run_j + 1 < seglen;
+    const int next_item = hand_down ? item_i : item_i + (int)gridDim.x, next_j = hand_down ? run_j + 1 : 0;
     const int64_t stamp_tile = (z * a.tiles_y + y0 / TH) * a.tiles_x + x0 / TW;
     int64_t zv;
     const LiftF16Views vout = view_of_z(z, zv);
@@ -464,11 +542,31 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     LfPre pre;
 #pragma unroll
     for (int k = 0; k < NS / NTH; ++k) {
-        pre.c[k] = STG[(3 * k + 0) * NTH + tid];
-        pre.m[k] = STG[(3 * k + 1) * NTH + tid];
-        pre.p[k] = STG[(3 * k + 2) * NTH + tid];
+        pre.c[k] = *stg(3 * k + 0, tid);
+        pre.m[k] = *stg(3 * k + 1, tid);
+        pre.p[k] = *stg(3 * k + 2, tid);
     }
-    const float din_pre = STG[9 * NTH + tid];
+    const float din_pre = *stg(9, tid);
+    // the rows handed down by the tile above: T1 rows 16..27 -> 0..11, T2 rows 16..23 -> 0..7 (source and destination rows are
+    // disjoint, the destinations are dead since the barrier that ended the tile above; P1 / P2 read them two barriers later)
+    if (cont) {
+        typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
+        constexpr int MV1 = 4 * KEEP1 * R1W, MV2 = 4 * KEEP2 * R2W;                   // 16-byte pieces: 2112, 1280
+#pragma unroll
+        for (int k = 0; k < (MV1 + NTH - 1) / NTH; ++k) {
+            const int c = tid + k * NTH, arr = c / (KEEP1 * R1W), px = c - arr * (KEEP1 * R1W);
+            if (c < MV1)
+                *reinterpret_cast<uintx4_t*>(lds + LDS_T1 + arr * T1A + px * 16) =
+                    *reinterpret_cast<const uintx4_t*>(lds + LDS_T1 + arr * T1A + ((N1 - KEEP1 * R1W) + px) * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < (MV2 + NTH - 1) / NTH; ++k) {
+            const int c = tid + k * NTH, arr = c / (KEEP2 * R2W), px = c - arr * (KEEP2 * R2W);
+            if (c < MV2)
+                *reinterpret_cast<uintx4_t*>(lds + LDS_T2 + arr * T2A + px * 16) =
+                    *reinterpret_cast<const uintx4_t*>(lds + LDS_T2 + arr * T2A + ((N2 - KEEP2 * R2W) + px) * 16);
+        }
+    }
     LF_STAMP(0)
     LF_STAMP(14)
     if (a.stamps && lane == 0)          // slot 13: which CU (XCC_ID << 32 | HW_ID)
@@ -547,16 +645,18 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // scheduler: one tile alone is a latency chain LDS -> MFMA x3 -> tanh -> split -> store); tiles past the end repeat the
     // last one (same bytes stored again)
     if (!(a.dbg & 1)) {
-        constexpr int NIT1 = (NT1 + 2 * NWAVE - 1) / (2 * NWAVE);      // 5
+        // a continuing tile computes rows 12..27 only (tiles 33..76)
+        const int nt1 = cont ? NT1C : NT1, tb1 = NT1 - nt1;
+        const int nit1 = (nt1 + 2 * NWAVE - 1) / (2 * NWAVE);           // 5, or 3
 #pragma unroll 1
-        for (int it = 0; it < NIT1; ++it) {
+        for (int it = 0; it < nit1; ++it) {
             floatx4 acc[2];
             int pq[2];
             float msk[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int tile = wave + (2 * it + t) * NWAVE;
-                const int p = (tile < NT1 ? tile : NT1 - 1) * 16 + pl;
+                const int p = (tb1 + (tile < nt1 ? tile : nt1 - 1)) * 16 + pl;
                 const int r = p / R1W, c = p - r * R1W;
                 acc[t] = conv1_tile(s16, r * SW + c, kgoff0, kgoff1, a1h, a1l);
                 const int gy = y0 - 6 + r, gx = x0 - 6 + c;
@@ -594,9 +694,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float inv2c = inv2 * TWO_LOG2E;
         // software pipeline over PAIRS of tiles (wave + 16 it, wave + 16 it + 8): the MFMA chains of pair it+1 are issued
         // next to the tanh / split / store work of pair it, so the vector ALU and the matrix pipe overlap inside one wave
-        constexpr int NIT2 = (NT2 + 2 * NWAVE - 1) / (2 * NWAVE);      // 4
+        // a continuing tile computes rows 8..23 only (tiles 20..59): 5 tiles per wave = two pairs and a single one; a first
+        // tile 60 = four pairs (the last one half empty for waves 4..7)
+        static_assert(NT2C == 5 * NWAVE, "a continuing tile: two pairs and one single conv2 tile per wave");
+        const int nt2 = cont ? NT2C : NT2, tb2 = NT2 - nt2;
+        const int nit2 = cont ? 2 : (NT2 + 2 * NWAVE - 1) / (2 * NWAVE);
         auto tile_base = [&](int tile, int& p_out) {
-            const int tcl = tile < NT2 ? tile : NT2 - 1;               // past the end: the last tile again (same bytes stored twice)
+            const int tcl = tb2 + (tile < nt2 ? tile : nt2 - 1);       // past the end: the last tile again (same bytes stored twice)
             const int p = tcl * 16 + pl;
             const int r = p / R2W, c = p - r * R2W;
             p_out = p;
@@ -630,8 +734,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 pin[0] = in_image(pp[0]);
                 pin[1] = in_image(pp[1]);
             }
-#pragma unroll
-            for (int it = 1; it < NIT2; ++it) {
+#pragma unroll 1
+            for (int it = 1; it < nit2; ++it) {
                 floatx4 n0, n1;
                 int q0, q1;
                 const int b0 = tile_base(wave + 16 * it, q0), b1 = tile_base(wave + 16 * it + NWAVE, q1);
@@ -640,8 +744,20 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 pin[0] = in_image(q0);
                 pin[1] = in_image(q1);
             }
+            if (cont) {
+                floatx4 n0;
+                int q0;
+                const int b0 = tile_base(wave + 4 * NWAVE, q0);
+                conv16_tile1<R1W, N1>(lds + LDS_T1, b0, hi_tap, ah, al, n0, slice);
+                const float pin0 = in_image(q0);
+                float v[4];
 #pragma unroll
-            for (int ks = 0; ks < 10; ++ks) slice(ks);
+                for (int q = 0; q < 4; ++q) v[q] = tanh_scaled(n0[q], inv2c, bvc[q]) * pin0;
+                timg_store<N2>(lds + LDS_T2, q0, oc0, v);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 10; ++ks) slice(ks);
+            }
         }
     }
     LF_STAMP(5)
@@ -675,16 +791,25 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if constexpr (!SEQ) {
         constexpr int NPC = TH * R2W, NTC = NPC / 16;           // 640 pixels (16 rows x 40 T2 columns), 40 tiles
         constexpr int DP = 12;                                  // floats per pixel in the D image (9 used)
-        static_assert(NPC % 16 == 0 && NPC * DP * 4 <= 4 * N1 * 16, "D image fits the T1 region");
+        static_assert(NPC % 16 == 0 && NPC == 4 * DPIECE_PX && DPIECE_PX % 16 == 0, "the D image is four quarters of whole tiles");
         const float* tail = pk + a.f16 + LF_H_END / 2;
         const float swc = tail[4];
-        float* D = reinterpret_cast<float*>(lds + LDS_T1);      // T1 is dead after P2
-        float* T3V = D + NPC * DP;                              // [strip position][16 channels] fp32, after the D image
-        float* U = T3V + (4 * R3W + 4 * (TH + 4)) * LF_C;        // [strip position][25 taps]: sum over channels of w4 * t3v
-        float* W4L = U + (4 * R3W + 4 * (TH + 4)) * LF_KK;       // conv4's fp32 weights as [tap][channel]
-        static_assert((NPC * DP + (4 * R3W + 4 * (TH + 4)) * (LF_C + LF_KK) + LF_KK * LF_C) * 4 <= 4 * N1 * 16, "D, t3v, U, w4 fit T1");
+        // rows 0..15 of the four T1 arrays are dead after P2 (rows 16..27 are handed down): D quarter k = output rows 4k..4k+3
+        auto Dp = [&](int p) -> float* {                        // pixel p (16 rows x 40 T2 columns) of the D image
+            const int k = p / DPIECE_PX;
+            return reinterpret_cast<float*>(lds + LDS_T1 + k * T1A) + (p - k * DPIECE_PX) * DP;
+        };
+        auto T3Vp = [&](int j) -> float* {                      // [strip position][16 channels] fp32, behind the D quarters
+            const int k = j / T3V_PER;
+            return reinterpret_cast<float*>(lds + LDS_T1 + k * T1A + DPIECE_BYTES) + (j - k * T3V_PER) * LF_C;
+        };
+        float* W4L = reinterpret_cast<float*>(lds + LDS_W4L);   // conv4's fp32 weights as [tap][channel]
+        float* CORR = reinterpret_cast<float*>(lds + LDS_CORR);
+        const bool more = next_item < a.nitems;
+        LfPre nxt;
         if (!interior) {                                        // before the composite loop: what it needs from P1 dies here
             if (tid < LF_C * LF_KK) W4L[(tid % LF_KK) * LF_C + tid / LF_KK] = bias[a.w4 + tid];
+            CORR[tid] = 0.f;
             const half8 c1h = *reinterpret_cast<const half8*>(frag + LF_H_C1 + lane * 8);
             const half8 c1l = *reinterpret_cast<const half8*>(frag + LF_H_C1 + 512 + lane * 8);
             float bv[4];
@@ -709,7 +834,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 floatx4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = acc[q] * inv3 + accr[q] * inv1 + bv[q];
-                if (j < nF) *reinterpret_cast<floatx4*>(T3V + j * LF_C + oc0) = v;
+                if (j < nF) *reinterpret_cast<floatx4*>(T3Vp(j) + oc0) = v;
             }
         }
         float rs = 0.f;
@@ -720,6 +845,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 ah[ks] = *reinterpret_cast<const half8*>(frag + LF_H_CC + (ks * 2 + 0) * 512 + lane * 8);
                 al[ks] = *reinterpret_cast<const half8*>(frag + LF_H_CC + (ks * 2 + 1) * 512 + lane * 8);
             }
+            // operands of the NEXT tile of this workgroup: issued here, in flight during the composite loop (~2 us of matrix
+            // work, an HBM round trip under load), staged in LDS at the tile's end (issued behind the loop they were waited for
+            // at full latency).  AFTER the weight fragments: vmcnt retires in order, so a wait for a younger L2 hit would
+            // otherwise wait for these HBM loads too
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) fetch(next_item, next_j, tid, nxt);
+            __builtin_amdgcn_sched_barrier(0);
             const uint8_t* img = lds + LDS_T2;
             static_assert(NTC == 5 * NWAVE, "five composite tiles per wave");
             // (w4 o w1) * skip, 81 fp32 taps on the skip patch for this thread's output pixel: vector work with no MFMA of
@@ -744,8 +876,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc, 0, 0, 0);
                 }
                 // rows = dx: lanes kg 0 hold dx 0-3, kg 1 dx 4-7, kg 2 dx 8 (register 0)
-                if (kg < 2) *reinterpret_cast<floatx4*>(D + p * DP + 4 * kg) = acc;
-                if (kg == 2) D[p * DP + 8] = acc[0];
+                float* dq = Dp(p);
+                if (kg < 2) *reinterpret_cast<floatx4*>(dq + 4 * kg) = acc;
+                if (kg == 2) dq[8] = acc[0];
 #pragma unroll
                 for (int j = 17 * it; j < 17 * it + 17 && j < 81; ++j) rs += tail[32 + j] * Sc[(j / 9) * SW + j % 9];
 #pragma unroll
@@ -759,23 +892,38 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         LF_STAMP(7)
         __syncthreads();
         LF_STAMP(8)
-        // operands of the NEXT tile of this workgroup: in flight during the rest of this one, staged in LDS at its end (T2 is
-        // dead from here on)
-        const bool more = tile_i + gridDim.x < a.ntiles;
-        LfPre nxt;
-        if (more) fetch(tile_i + gridDim.x, tid, nxt);
-        if (!interior) {           // U[position][tap] = sum_oc w4[oc][tap] * t3v[position][oc]: dense over (position, tap) items
+        if (!interior) {
+            // SCATTER of the correction: strip position (r, c) and conv4 tap (dy, dx) -> output pixel (r - dy, c - dx) of this tile,
+            // u = sum_oc w4[oc][tap] * t3v[position][oc] added to that pixel's CORR (LDS float add); dense over (position, tap)
+            // items, no per-pixel gather.  A column-strip position whose row is also outside the image belongs to the row strip.
             for (int i = tid; i < nF * LF_KK; i += NTH) {
                 const int pos = i / LF_KK, tap = i - pos * LF_KK;
-                const floatx4* tv = reinterpret_cast<const floatx4*>(T3V + pos * LF_C);
-                const floatx4* wv = reinterpret_cast<const floatx4*>(W4L + tap * LF_C);
-                float u = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const floatx4 t = tv[q], ww = wv[q];
-                    u += t[0] * ww[0] + t[1] * ww[1] + t[2] * ww[2] + t[3] * ww[3];
+                const int dy = tap / LF_K, dx = tap - dy * LF_K;
+                int r, c;
+                bool dup = false;
+                if (pos < nR * R3W) {
+                    const int ir = pos / R3W;
+                    c = pos - ir * R3W;
+                    r = ir == 0 ? Rl0 : ir == 1 ? Rl1 : ir == 2 ? Rl2 : Rl3;
+                } else {
+                    const int q = pos - nR * R3W, ic = q / (TH + 4);
+                    r = q - ic * (TH + 4);
+                    c = ic == 0 ? Cl0 : ic == 1 ? Cl1 : ic == 2 ? Cl2 : Cl3;
+                    const int gyy = y0 - 2 + r;
+                    dup = gyy < 0 || gyy >= h;
                 }
-                U[i] = u;
+                const int oy = r - dy, ox = c - dx;
+                if (!dup && oy >= 0 && oy < TH && ox >= 0 && ox < TW) {
+                    const floatx4* tv = reinterpret_cast<const floatx4*>(T3Vp(pos));
+                    const floatx4* wv = reinterpret_cast<const floatx4*>(W4L + tap * LF_C);
+                    float u = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const floatx4 t = tv[q], ww = wv[q];
+                        u += t[0] * ww[0] + t[1] * ww[1] + t[2] * ww[2] + t[3] * ww[3];
+                    }
+                    __hip_atomic_fetch_add(CORR + oy * TW + ox, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
             __syncthreads();
         }
@@ -784,36 +932,16 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int gy = y0 + oy, gx = x0 + ox;
             const float invc = (1.f / ACT_SCALE) * (1.f / swc);
             float net = 0.f;
+            const float* drow = Dp(oy * R2W) + ox * DP;          // a row of the D image lies inside one quarter
 #pragma unroll
-            for (int dx = 0; dx < 9; ++dx) net += D[(oy * R2W + ox + dx) * DP + dx];
+            for (int dx = 0; dx < 9; ++dx) net += drow[dx * DP + dx];
             net *= invc;
             float cst = bias[a.b4];
 #pragma unroll
             for (int oc = 0; oc < LF_C; ++oc) cst += (bias[a.b3 + oc] + bias[a.b1 + oc]) * tail[16 + oc];
             net += rs + cst;
             const bool valid = gy < h && gx < w;
-            if (!interior && valid) {          // the conv4 taps of this pixel that land outside the image
-                float corr = 0.f;
-                for (int dy = 0; dy < LF_K; ++dy) {
-                    const int r = oy + dy, gyy = gy - 2 + dy;
-                    if (gyy < 0 || gyy >= h) {
-                        const int ir = r == Rl0 ? 0 : r == Rl1 ? 1 : r == Rl2 ? 2 : 3;
-                        const float* up = U + (ir * R3W + ox) * LF_KK + dy * LF_K;
-#pragma unroll
-                        for (int dx = 0; dx < LF_K; ++dx) corr += up[dx * (LF_KK + 1)];
-                    } else {
-#pragma unroll
-                        for (int dx = 0; dx < LF_K; ++dx) {
-                            const int c = ox + dx, gxx = gx - 2 + dx;
-                            if (gxx < 0 || gxx >= w) {
-                                const int ic = c == Cl0 ? 0 : c == Cl1 ? 1 : c == Cl2 ? 2 : 3;
-                                corr += U[(nR * R3W + ic * (TH + 4) + r) * LF_KK + dy * LF_K + dx];
-                            }
-                        }
-                    }
-                }
-                net -= corr;
-            }
+            if (!interior) net -= CORR[tid];    // the conv4 taps of this pixel that land outside the image
             const float skip = S[(oy + 8) * SW + ox + 8];
             const float din = din_pre;
             if (valid)
@@ -885,9 +1013,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();            // T3 complete; every wave is done reading T2 -- D may now overwrite it
     LF_STAMP(8)
-    const bool more = tile_i + gridDim.x < a.ntiles;                         // the NEXT tile's operands (see the composed path)
+    const bool more = next_item < a.nitems;                                  // the NEXT tile's operands (see the composed path)
     LfPre nxt;
-    if (more) fetch(tile_i + gridDim.x, tid, nxt);
+    if (more) fetch(next_item, next_j, tid, nxt);
 
     // ---------------- P4: D[dx][pixel] = sum over (dy, channel) of t3 * w4 on 16 x 36
     {
@@ -945,11 +1073,20 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     LF_STAMP(15)
     }                           // sequential path
     __syncthreads();            // S, the T / D images and the fp16 skip images are rewritten by the next tile
+    item_i = next_item;
+    run_j = next_j;
     }                           // tile loop
 }
 #undef LF_STAMP
 
 }  // namespace
+
+// diagnostics state (read per launch; set through the C-ABI, never from the environment on the launch path)
+static int g_lf_dbg = [] { const char* e = getenv("LLDWT_LF_DBG"); return e ? atoi(e) : 0; }();
+static unsigned long long* g_lf_stamps = nullptr;
+static int64_t g_lf_stamps_bytes = 0;
+void lift_f16_set_debug(int dbg) { g_lf_dbg = dbg; }
+void lift_f16_set_stamps(void* p, int64_t nbytes) { g_lf_stamps = reinterpret_cast<unsigned long long*>(p); g_lf_stamps_bytes = p ? nbytes : 0; }
 
 int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, float* packed, int64_t plane_stride,
                   int f16_off, int planes, hipStream_t st) {
@@ -968,9 +1105,9 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
                    float sign, float rw, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_lift_fused_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_lift_fused_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) {
-            set_error("lift_f16_step: cannot reserve %d bytes of LDS", LDS_TOTAL);
+        if (hipFuncSetAttribute((const void*)k_lift_fused_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_lift_fused_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess) {
+            set_error("lift_f16_step: cannot reserve %d bytes of LDS", LDS_TOTAL2);
             return LLDWT_EHIP;
         }
         attr = true;
@@ -999,10 +1136,8 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
     a.f16 = f16_off + orient * LF_ORIENT_FLOATS;
     a.batch = (int)batch; a.h = (int)h; a.w = (int)w; a.vertical = vertical;
     a.sign = sign; a.rw = rw;
-    const char* dbg = getenv("LLDWT_LF_DBG");
-    a.dbg = dbg ? atoi(dbg) : 0;
-    const char* stp = getenv("LLDWT_LF_STAMPS");
-    a.stamps = stp ? reinterpret_cast<unsigned long long*>(strtoull(stp, nullptr, 0)) : nullptr;
+    a.dbg = g_lf_dbg;
+    a.stamps = nullptr;
     auto fits = [&](int64_t sy, int64_t sx) { return llabs(sy) * h + llabs(sx) * w < (int64_t)1 << 31; };
     if (!fits(v.src_sy, v.src_sx) || !fits(v.din_sy, v.din_sx) || !fits(v.dout_sy, v.dout_sx) ||
         (v2 && (!fits(v2->src_sy, v2->src_sx) || !fits(v2->din_sy, v2->din_sx) || !fits(v2->dout_sy, v2->dout_sx)))) {
@@ -1011,7 +1146,14 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
     }
     a.tiles_x = (int)cdiv(w, TW);
     a.tiles_y = (int)cdiv(h, TH);
-    a.ntiles = (int64_t)a.tiles_x * a.tiles_y * Zl;
+    if ((int64_t)a.tiles_x * a.tiles_y * Zl >= (int64_t)1 << 30) {
+        set_error("lift_f16_step: more than 2^30 tiles in one launch");
+        return LLDWT_EINVAL;
+    }
+    if (g_lf_stamps) {              // diagnostics (tools/lift_stamps.py): only when the registered buffer holds every tile's stamps
+        const int64_t need = (int64_t)a.tiles_x * a.tiles_y * Zl * NWAVE * 16 * 8;
+        if (g_lf_stamps_bytes >= need) a.stamps = g_lf_stamps;
+    }
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
@@ -1022,9 +1164,25 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
         }
         ncu = prop.multiProcessorCount;
     }
-    const unsigned grid = (unsigned)(a.ntiles < ncu ? a.ntiles : ncu);      // one resident workgroup per CU
-    if (a.dbg & 16) hipLaunchKernelGGL(k_lift_fused_f16<true>, dim3(grid), dim3(NTH), LDS_TOTAL, st, a);
-    else hipLaunchKernelGGL(k_lift_fused_f16<false>, dim3(grid), dim3(NTH), LDS_TOTAL, st, a);
+    // the sequential evaluation hands nothing down (its T3 / D images overwrite T1 / T2)
+    const bool seq = (a.dbg & 16) != 0;
+    // run length: a tile that continues a run costs ~0.8 of a first tile; runs are dealt round-robin to one resident
+    // workgroup per CU, so the launch takes rounds x (cost of a run) -- the longest run that still fills whole rounds
+    int best_rl = 1;
+    if (!seq && !(a.dbg & 32)) {
+        double best = 1e30;
+        for (int rl = 1; rl <= a.tiles_y; ++rl) {
+            const int64_t items = (int64_t)Zl * a.tiles_x * cdiv(a.tiles_y, rl);
+            const double cost = (double)cdiv(items, ncu) * (1.0 + 0.8 * (rl - 1));
+            if (cost < best - 1e-9) { best = cost; best_rl = rl; }
+        }
+    }
+    a.rl = best_rl;
+    a.nseg = (int)cdiv(a.tiles_y, a.rl);
+    a.nitems = (int)(Zl * a.tiles_x * a.nseg);
+    const unsigned grid = (unsigned)(a.nitems < ncu ? a.nitems : ncu);      // one resident workgroup per CU
+    if (seq) hipLaunchKernelGGL(k_lift_fused_f16<true>, dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
+    else hipLaunchKernelGGL(k_lift_fused_f16<false>, dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
     return check_launch("lift_f16_step");
 }
 

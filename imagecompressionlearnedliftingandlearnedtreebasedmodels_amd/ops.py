@@ -28,6 +28,19 @@ def plc_mode():
     return m
 
 
+_diag_keep = {}
+
+
+def set_diagnostics(kind, stamps=None, flags=0):
+    """Diagnostics hook of the split-fp16 kernels (lldwt_set_diagnostics; tools/*_stamps.py and the composed-vs-sequential
+    tests only): kind 0 = fused lifting step (flags = its debug mask), 1 = tree-pair conv, 2 = cgp chain.  ``stamps``: an
+    int64 device tensor the kernels write s_memtime stamps into (kept alive here until it is replaced), None = off."""
+    _diag_keep[kind] = stamps
+    ptr = C.c_void_p(stamps.data_ptr()) if stamps is not None else C.c_void_p(0)
+    nbytes = stamps.numel() * stamps.element_size() if stamps is not None else 0
+    check(_lib.load().lldwt_set_diagnostics(int(kind), ptr, nbytes, int(flags)), "lldwt_set_diagnostics")
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -79,6 +79,13 @@ int64_t lldwt_pblock_packed_floats(int C, int K);
  * launch per step with the 16 -> 16 convolutions on the fp16 matrix cores, split-fp16 operands, intermediates in LDS
  * (csrc/lifting_f16.hip); 0 = the three fp32-MFMA launches (exact fp32 products; also what training uses).       */
 int lldwt_set_lift_mode(int mode);
+/* Diagnostics hook of the three split-fp16 kernel families (tools/lift_stamps.py, plc_stamps.py, cgp_stamps.py; the
+ * product never calls it).  kind 0 = fused lifting step, 1 = tree-pair conv, 2 = cgp chain.  stamps / nbytes: a device
+ * buffer the kernels of that kind write s_memtime stamps into (null = off); a launch whose stamps would not fit in
+ * nbytes ignores the buffer.  flags (kind 0 only): debug mask -- bit 0..3 skip a phase (results are then wrong),
+ * 16 = sequential conv3 / conv4 for every tile (the check of the composed 9x9 kernel), 32 = no vertical reuse
+ * between the tiles of a column.  The caller keeps the buffer alive until it unregisters it.                      */
+int lldwt_set_diagnostics(int kind, void* stamps, int64_t nbytes, int flags);
 int lldwt_get_lift_mode(void);
 int lldwt_pack_pblock(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                       const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,

@@ -138,10 +138,11 @@ def test_bad_arguments_fail_loudly():
 
 @pytest.mark.parametrize("hw", [(16, 32), (33, 70), (8, 12), (100, 200)])
 @pytest.mark.parametrize("vertical", [1, 0])
-def test_composed_path_with_strip_correction_equals_sequential(hw, vertical, monkeypatch):
+def test_composed_path_with_strip_correction_equals_sequential(hw, vertical):
     """The fused lifting step evaluates conv4(conv3(.)) through the composed 9x9 kernel for EVERY tile; border tiles
-    subtract the conv4 taps that fall outside the image (t3v on the <= 2-pixel frame).  LLDWT_LF_DBG=16 runs the
-    sequential evaluation (t3 on the halo region, then conv4) for every tile instead: both must agree to fp32 rounding on
+    subtract the conv4 taps that fall outside the image (t3v on the <= 2-pixel frame).  Debug flag 16 (ops.set_diagnostics)
+    runs the sequential evaluation (t3 on the halo region, then conv4) for every tile instead, flag 32 the composed path
+    without the vertical hand-down of T1 / T2 rows between the tiles of a column: all three must agree to fp32 rounding on
     single-tile images (all four edges in one tile), ragged multi-tile images, and images smaller than a tile."""
     ops, gu = _ops()
     cfg = dict(model.DEFAULT_CFG, filtersize=5, dwtlevels=1)
@@ -155,19 +156,23 @@ def test_composed_path_with_strip_correction_equals_sequential(hw, vertical, mon
     Z = P * B
     v = lambda t: ops.view_of(t, Z, h, w)
     outs = []
-    for dbg in ("0", "16"):
-        monkeypatch.setenv("LLDWT_LF_DBG", dbg)
-        out_d = torch.empty_like(dst_d)
-        ops.lift_step(v(src_d), v(dst_d), v(out_d), Z, B, h, w, taps[0].contiguous(), packed[:, 0, 0].contiguous(), 16, 5,
-                      vertical, -1.0, 0.1)
-        outs.append(out_d.cpu())
-    monkeypatch.setenv("LLDWT_LF_DBG", "0")
+    try:
+        for dbg in (0, 16, 32):
+            ops.set_diagnostics(0, None, dbg)
+            out_d = torch.empty_like(dst_d)
+            ops.lift_step(v(src_d), v(dst_d), v(out_d), Z, B, h, w, taps[0].contiguous(), packed[:, 0, 0].contiguous(), 16, 5,
+                          vertical, -1.0, 0.1)
+            outs.append(out_d.cpu())
+    finally:
+        ops.set_diagnostics(0, None, 0)
     assert maxdiff(outs[0], outs[1]) < 2e-6, (hw, vertical)
+    assert maxdiff(outs[0], outs[2]) < 2e-6, (hw, vertical)
 
 
-def test_composed_path_equals_sequential_on_random_shapes(monkeypatch):
+def test_composed_path_equals_sequential_on_random_shapes():
     """The same comparison on 24 seeded random image sizes (2 .. 130 rows, 2 .. 210 columns, both pass directions): every
-    combination of missing / partial edge strips, tiles overhanging the image, images narrower than the conv reach."""
+    combination of missing / partial edge strips, tiles overhanging the image, images narrower than the conv reach -- and
+    runs of up to 9 vertically consecutive tiles that hand their last T1 / T2 rows down."""
     import random
     ops, gu = _ops()
     cfg = dict(model.DEFAULT_CFG, filtersize=5, dwtlevels=1)
@@ -185,13 +190,15 @@ def test_composed_path_equals_sequential_on_random_shapes(monkeypatch):
         src_d, dst_d = gu.dev(src), gu.dev(dst)
         v = lambda t: ops.view_of(t, B, h, w)
         outs = []
-        for dbg in ("0", "16"):
-            monkeypatch.setenv("LLDWT_LF_DBG", dbg)
-            out_d = torch.empty_like(dst_d)
-            ops.lift_step(v(src_d), v(dst_d), v(out_d), B, B, h, w, taps[2].contiguous(), packed[:, 1, 0].contiguous(), 16, 5,
-                          vertical, 1.0, 0.1)
-            outs.append(out_d.cpu())
-        monkeypatch.setenv("LLDWT_LF_DBG", "0")
+        try:
+            for dbg in (0, 16):
+                ops.set_diagnostics(0, None, dbg)
+                out_d = torch.empty_like(dst_d)
+                ops.lift_step(v(src_d), v(dst_d), v(out_d), B, B, h, w, taps[2].contiguous(), packed[:, 1, 0].contiguous(), 16, 5,
+                              vertical, 1.0, 0.1)
+                outs.append(out_d.cpu())
+        finally:
+            ops.set_diagnostics(0, None, 0)
         d = maxdiff(outs[0], outs[1])
         worst = max(worst, d)
         assert d < 2e-6, (case, h, w, vertical, d)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of ONE lifting step at the level-0 row-pass shape of BASELINE configs[2] (24 planes*images of
-256 x 512): fused split-fp16 kernel vs the three fp32-MFMA launches; LLDWT_LF_DBG masks phases for attribution."""
+256 x 512): fused split-fp16 kernel vs the three fp32-MFMA launches; the debug mask (ops.set_diagnostics) skips phases for
+attribution (1 = conv1, 2 = conv2, 16 = sequential conv3 / conv4, 32 = no vertical reuse)."""
 import json
 import os
 import sys
@@ -45,10 +46,10 @@ def main():
     res["f32_three_launches_us"] = timeit()
     ref = out.clone()
     lib.lldwt_set_lift_mode(1)
-    for dbg in (0, 16, 1, 2, 4, 8, 15):
-        os.environ["LLDWT_LF_DBG"] = str(dbg)
+    for dbg in (0, 32, 16, 1, 2, 3, 1 + 32, 2 + 32, 3 + 32):
+        ops.set_diagnostics(0, None, dbg)
         res["fused_dbg%d_us" % dbg] = timeit()
-    os.environ["LLDWT_LF_DBG"] = "0"
+    ops.set_diagnostics(0, None, 0)
     run()
     res["max_abs_diff_vs_f32"] = float((out - ref).abs().max())
     print(json.dumps(res))

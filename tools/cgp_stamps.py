@@ -31,10 +31,10 @@ def main():
     torch.cuda.synchronize()
     cols = S * S // 32
     st = torch.zeros(P * B, G, cols, 8, dtype=torch.int64, device=dev)
-    os.environ["LLDWT_CGP_STAMPS"] = str(st.data_ptr())
+    ops.set_diagnostics(2, st)
     run()
     torch.cuda.synchronize()
-    del os.environ["LLDWT_CGP_STAMPS"]
+    ops.set_diagnostics(2, None)
     s = st.cpu().numpy().astype(np.int64)
     d = np.diff(s[..., :6], axis=-1)
     names = ["inputs (48 loads per lane per block) + |max|", "layers 0 + 1 (60 weight steps, 360 MFMAs)", "layer 2", "layer 3", "store"]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Diagnostic: in-kernel clock stamps (s_memtime) of the fused lifting step at the level-0 row-pass shape of BASELINE
 configs[2]: per-phase cycles of every wave, barrier waits, in-kernel clock.  The kernel writes stamps only when
-LLDWT_LF_STAMPS holds a device address (this tool); a normal run executes none.   python tools/lift_stamps.py"""
+a stamp buffer is registered through lldwt_set_diagnostics (this tool); a normal run executes none.   python tools/lift_stamps.py"""
 import json
 import os
 import sys
@@ -37,13 +37,13 @@ def main():
         run()
     torch.cuda.synchronize()
     abl = None
-    os.environ["LLDWT_LF_DBG"] = "0"
+    dbg = int(os.environ.get("LLDWT_LF_DBG", "0"))
     for _ in range(20):
         run()
-    os.environ["LLDWT_LF_STAMPS"] = str(st.data_ptr())
+    ops.set_diagnostics(0, st, dbg)
     run()
     torch.cuda.synchronize()
-    del os.environ["LLDWT_LF_STAMPS"]
+    ops.set_diagnostics(0, None, 0)
     s = st.cpu().numpy().astype(np.int64)
     gx, gy = w // 32, h // 16
     s = s.reshape(P * B, gy, gx, 8, 16)
@@ -58,6 +58,16 @@ def main():
     res["interior_max_over_waves_mean"] = {n: float(d[..., i].max(axis=-1).mean()) for i, n in enumerate(names)}
     tot = si[..., 9] - si[..., 0]
     res["interior_total_cycles_mean"] = float(tot.mean())
+    # vertical reuse: with a run length of RL tiles (LLDWT_STAMPS_RL, default 8 at this shape) the tiles at ty % RL == 0 start a
+    # run (all 28 / 24 rows of t1 / t2), the others continue one (16 new rows each)
+    rl = int(os.environ.get("LLDWT_STAMPS_RL", "8"))
+    ty = np.arange(gy)[:, None] * np.ones((1, gx), int)
+    for name, sel in (("first_of_run", interior & (ty % rl == 0)), ("continuing", interior & (ty % rl != 0))):
+        if sel.any():
+            sx_ = s[:, sel]
+            dd = np.diff(sx_[..., :10], axis=-1)
+            res["interior_%s_mean_cycles_per_wave" % name] = {n: float(dd[..., i].mean()) for i, n in enumerate(names)}
+            res["interior_%s_total" % name] = float((sx_[..., 9] - sx_[..., 0]).mean())
     real = (si[..., 15] - si[..., 14]).astype(np.float64)      # 100 MHz ticks
     ok = real > 0
     res["in_kernel_clock_GHz"] = float(np.median(tot[ok] / real[ok]) * 0.1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Diagnostic: in-kernel clock stamps (s_memtime) of the fused tree-context pair (k_conv3_f16x3<2>) at the level-0 shape of
 BASELINE configs[2] (3 planes x 8 images, parent 128 x 128 -> 243 channels at 256 x 256).  The kernel writes stamps only
-when LLDWT_F3_STAMPS holds a device address (this tool).   python tools/plc_stamps.py"""
+when a stamp buffer is registered through lldwt_set_diagnostics (this tool).   python tools/plc_stamps.py"""
 import json
 import os
 import sys
@@ -32,10 +32,10 @@ def main():
     torch.cuda.synchronize()
     nwg = (S // 32) * (S // 8) * 2 * P * B
     st = torch.zeros(nwg, 4, 16, dtype=torch.int64, device=dev)
-    os.environ["LLDWT_F3_STAMPS"] = str(st.data_ptr())
+    ops.set_diagnostics(1, st)
     run()
     torch.cuda.synchronize()
-    del os.environ["LLDWT_F3_STAMPS"]
+    ops.set_diagnostics(1, None)
     s = st.cpu().numpy().astype(np.int64)
     res = {"workgroups": nwg}
     d = np.diff(s[..., :12], axis=-1)
