@@ -47,6 +47,28 @@ CONFIGS = {
 }
 
 
+def source_hashes():
+    """git blob hashes (sha1 of "blob <n>\\0" + bytes: what `git hash-object` prints) of the kernel sources a PMC traffic
+    figure was measured on: profiles/traffic_current.json carries them, and a figure whose source has changed since is
+    dropped from the line instead of being reported stale."""
+    import hashlib
+    out = {}
+    d = os.path.join(REPO, "imagecompressionlearnedliftingandlearnedtreebasedmodels_amd", "csrc")
+    for name in ("conv_f16x3.hip", "lifting_f16.hip", "split_f16.h", "lifting_f16.h"):
+        try:
+            with open(os.path.join(d, name), "rb") as f:
+                b = f.read()
+            out[name] = hashlib.sha1(b"blob %d\0" % len(b) + b).hexdigest()
+        except OSError:
+            out[name] = None
+    return out
+
+
+def traffic_is_current(tj, names):
+    have, now = tj.get("source_hashes") or {}, source_hashes()
+    return all(have.get(n) is not None and have.get(n) == now.get(n) for n in names)
+
+
 def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
 
@@ -227,11 +249,22 @@ def train_leg(a, c, dev, rank, world, x):
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     log("train leg done: %.3f s for %d steps" % (dt, a.train_steps))
+    # the gradient exchange alone (it runs after backward, not overlapped with it: this is what an N > 1 step pays for it)
+    ar_ms = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        parallel.barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            agent._bucket.all_reduce_mean()
+        torch.cuda.synchronize()
+        ar_ms = parallel.max_over_ranks(time.perf_counter() - t1, dev) / 5 * 1e3
     return {"ms_per_step": dt / a.train_steps * 1e3,
             "Mpixels/s": x.shape[0] * x.shape[2] * x.shape[3] * world * a.train_steps / dt / 1e6,
             "steps": a.train_steps, "loss": float(loss.detach()), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
             "grad_allreduce": "one flat fp32 bucket of %d floats, backend %s, world %d" % (
                 agent._bucket.flat.numel(), parallel.backend_name(), world),
+            "allreduce_ms": ar_ms, "allreduce_exposed": "not overlapped with backward (issued after it); 0 for one rank",
             "what": "forward (noise) + hand-written backward + flat-bucket gradient all-reduce (mean over ranks) + Adam, "
                     "same workload, batch sharded over ranks"}
 
@@ -433,7 +466,10 @@ def main():
             tj = json.load(f)
         fused_now = ops.plc_mode() == "f16x3" and ops.plc_fuse() and ops.storage_dtype() != "fp16"
         if tj.get("plc_mode", "f32") == ops.plc_mode() and bool(tj.get("fused", False)) == fused_now:
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source")
+            if traffic_is_current(tj, ("conv_f16x3.hip", "split_f16.h")):
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source")
+            else:
+                traffic_src = "dropped: csrc/conv_f16x3.hip changed since profiles/traffic_current.json was measured"
     dom_ms = sum(e0.elapsed_time(e1) for e0, e1 in dom["events"])
     n_launch = max(len(dom["events"]), 1)
     scale = 1e12 if roof["unit"] == "TFLOP/s" else 1e9
@@ -489,11 +525,19 @@ def main():
                                  "the same launches with the fp32 MFMA roof (157.3 TF) of the reference arithmetic")
         else:
             roof["peak_note"] = "peak = dense fp32-input MFMA (157.3 TFLOP/s); exact fp32 arithmetic (LLDWT_PLC_MODE=f32)"
+    # what executes: every tensor in HBM is fp32; the matrix work of the eval path runs as three fp16 MFMA products per fp32 MAC
+    # (split-fp16, fp32 accumulate) unless the fp32 kernels were selected
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import _lib as _L0
+    f16_lift = lifting and _L0.load().lldwt_get_lift_mode() == 1
+    f16_plc = has_plc and ops.plc_mode() == "f16x3"
+    dtype = "f32 storage, f16x3 arithmetic (3 fp16 MFMA products per fp32 MAC, fp32 accumulate)" if (f16_lift or f16_plc) else "f32"
+    if roof.get("fp32_equivalent_tflops") is not None and roof["unit"] == "TFLOP/s":
+        roof["frac_algorithmic"] = roof["fp32_equivalent_tflops"] / roof["peak"]     # the conv's own MACs only, same roof
     out = {
-        "metric": "Mpixels/sec (lifting DWT + entropy-model fwd) at 512x512 RGB",
+        "metric": "Mpixels/sec (lifting DWT + entropy-model fwd) at %dx%d RGB" % (c["H"], c["W"]),
         "value": pixels / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world_seen, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": dtype, "data": "synthetic",
         "config": {"workload": workload_string(c, a), "note": c["note"], "per_gpu_images": Bx, "image_hw": [Hx, Wx],
                    "sharding": "batch over ranks, no data-path collective",
                    "backend": parallel.backend_name(), "world_size_seen": world_seen,
@@ -514,6 +558,7 @@ def main():
             "achieved": (3.0 if f16l else 1.0) * tf2, "peak": F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS,
             "frac": (3.0 if f16l else 1.0) * tf2 / (F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS),
             "note": "algorithmic MACs of the transform (SURVEY 8d), halo recomputation not counted; 3 fp16 products per MAC"}
+        lift_roof["frac_algorithmic"] = tf2 / lift_roof["peak"]
         # kernel launches of one forward call: per level 4 row-pass steps + 4 column steps (the L and H column passes share
         # a launch); the fp32 path takes 3 launches for each of the 12 steps of a level.  HIP events bracket the whole call.
         lpf = (8 if f16l else 36) * c["levels"]
@@ -526,9 +571,14 @@ def main():
             with open(tpath) as f:
                 tl = json.load(f).get("lifting")
             if tl and a.config == 2 and not c["overrides"] and f16l:
-                lift_roof["traffic"] = tl["traffic_bytes_per_forward"] / lpf
-                lift_roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), average over the launches of "
-                                               "one forward call; profiles/r02_b_pmc_per_kernel.csv")
+                with open(tpath) as f:
+                    tj2 = json.load(f)
+                if traffic_is_current(tj2, ("lifting_f16.hip", "lifting_f16.h", "split_f16.h")):
+                    lift_roof["traffic"] = tl["traffic_bytes_per_forward"] / lpf
+                    lift_roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), average over the "
+                                                   "launches of one forward call; " + str(tj2.get("csv", "profiles/")))
+                else:
+                    lift_roof["traffic_source"] = "dropped: csrc/lifting_f16.hip changed since profiles/traffic_current.json was measured"
         except (OSError, ValueError, KeyError):
             pass
         # `roofline` is the kernel family that took more of the timed region; the other one is reported beside it
@@ -543,7 +593,8 @@ def main():
             out["train"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if rank == 0 and not a.no_hbm_kernels:
         try:
-            out["roofline_hbm"] = hbm_kernels(dev, 8, 512)
+            # the BASELINE batch (25 MB per call: latency-bound) and batch 96 (bandwidth-bound) side by side
+            out["roofline_hbm"] = hbm_kernels(dev, 8, 512) + [dict(r, kernel=r["kernel"] + " @batch96") for r in hbm_kernels(dev, 96, 512)]
         except Exception as e:
             out["roofline_hbm"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if rank == 0 and world_seen == 1 and not a.no_cpu_baseline:

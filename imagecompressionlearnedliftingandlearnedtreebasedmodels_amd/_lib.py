@@ -54,6 +54,7 @@ SIGNATURES = {
     "lldwt_pblock_packed_floats": (_i64, [_i, _i]),
     "lldwt_set_lift_mode": (_i, [_i]),
     "lldwt_set_diagnostics": (_i, [_i, _p, _i64, _i]),
+    "lldwt_set_cdf97_short_levels": (_i, [_i]),
     "lldwt_get_lift_mode": (_i, []),
     "lldwt_pack_pblock": (_i, [_p] * 9 + [_i, _i, _i, _p]),
     "lldwt_pack_pblock_train": (_i, [_p] * 9 + [_i, _i, _i, _p]),

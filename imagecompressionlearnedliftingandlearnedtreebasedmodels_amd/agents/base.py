@@ -74,11 +74,16 @@ class BaseAgent:
                          self.config.checkpoint_dir, ckpt["epoch"], ckpt["iteration"])
         return True
 
-    def save_checkpoint(self, file_name="checkpoint.pth.tar", is_best=0):
+    def save_checkpoint(self, file_name="checkpoint.pth.tar", is_best=0, collective=True):
         """agents/base.py:97-128.  Data-parallel: the replicas are identical, so rank 0 alone writes; everyone then
-        meets at a barrier so that no rank reads a half-written file."""
+        meets at a barrier so that no rank reads a half-written file.  ``collective=False`` is the emergency save of a
+        rank that is about to die (run()'s exception handler): its peers sit in some other collective, so it must not
+        enter a barrier -- it writes its own rank-suffixed file (whatever its rank) and returns."""
         from .. import parallel
-        if parallel.is_rank0():
+        if not collective:
+            file_name = "%s.rank%d%s" % (file_name[:-len(".pth.tar")], parallel.rank(), ".pth.tar") \
+                if file_name.endswith(".pth.tar") else "%s.rank%d" % (file_name, parallel.rank())
+        if parallel.is_rank0() or not collective:
             state = {"epoch": self.current_epoch, "iteration": self.current_iteration,
                      "best_valid_loss": float(self.best_valid_loss), "state_dict": self.model.state_dict(),
                      "optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict()}
@@ -91,9 +96,10 @@ class BaseAgent:
             path = os.path.join(self.config.checkpoint_dir, file_name)
             torch.save(state, path + ".tmp")
             os.replace(path + ".tmp", path)
-            if is_best:
+            if is_best and collective:
                 shutil.copyfile(path, os.path.join(self.config.checkpoint_dir, "model_best.pth.tar"))
-        parallel.barrier()
+        if collective:
+            parallel.barrier()
 
     def run(self):
         """Mode dispatch (agents/base.py:130-154): exceptions save a checkpoint and re-raise, Ctrl-C is swallowed."""
@@ -117,8 +123,16 @@ class BaseAgent:
         except AssertionError:
             raise
         except Exception:
-            if getattr(self, "optimizer", None) is not None and "checkpoint_dir" in self.config:
-                self.save_checkpoint()
+            # only a training run has state worth rescuing (a failing test / validate run must not overwrite
+            # checkpoint.pth.tar with the weights it loaded and a fresh optimizer); the save is rank-local -- no barrier: the
+            # other ranks are inside the gradient all-reduce or a mean_over_ranks, and the re-raise lets the launcher tear
+            # them down -- and goes to checkpoint.rank<r>.pth.tar, never over the collective checkpoint
+            if self.config.mode in ("train", "train_postprocess", "debug") and getattr(self, "optimizer", None) is not None \
+                    and "checkpoint_dir" in self.config:
+                try:
+                    self.save_checkpoint(collective=False)
+                except Exception as e:                         # the original error is the one to report
+                    self.logger.error("emergency checkpoint failed: %s", e)
             raise
 
     def _epoch_loop(self, train_one, validate):

@@ -26,13 +26,18 @@ class LiftingBasedDWTAgent(BaseAgent):
         self.clrch = config.clrch
         self.lr = config.learning_rate
         self.model = LiftingBasedDWTNetWrapper(config).to(self.device)
-        self.seed_noise_stream()
         self.postprocessflag = config.get("postprocess", "none")
-        self.optimizer = configure_optimizers(self.model, self.lr)
         self.postprocess = None
+        self._bucket_postprocess = None
         if config.mode == "train_postprocess":                                   # :26-41
+            # built BEFORE the per-rank noise stream is seeded: every rank initialises the same replica from the config seed
+            # (and the broadcast makes that independent of how many random numbers the codec's constructor drew)
             from ..graphs.layers.post_processing_networks import make_postprocess
             self.postprocess = make_postprocess(config).to(self.device)
+            parallel.broadcast_parameters(self.postprocess)
+        self.seed_noise_stream()
+        self.optimizer = configure_optimizers(self.model, self.lr)
+        if self.postprocess is not None:
             self.optimizer_postprocess = optim.Adam(self.postprocess.parameters(), lr=0.0001)
             self.scheduler_postprocess = optim.lr_scheduler.ReduceLROnPlateau(
                 self.optimizer_postprocess, factor=0.5, patience=5, threshold=0.0001, threshold_mode="rel", cooldown=0,
@@ -135,16 +140,29 @@ class LiftingBasedDWTAgent(BaseAgent):
             return self.valid_loss.forward3(xs, xhat.contiguous(), si_xe, si_xo)
         return self.train_loss.forward3_train(xs, xhat.contiguous(), si_xe, si_xo)
 
+    def _postprocess_zero_grad(self):
+        """Data-parallel like train_step: the post-processing net's gradients live in one flat bucket."""
+        if self._bucket_postprocess is None:
+            self._bucket_postprocess = parallel.FlatGradBucket(self.postprocess.parameters())
+        self._bucket_postprocess.zero_()
+
+    def _postprocess_backward_and_step(self, mse):
+        """backward of the MSE (:141), ONE all-reduce (mean over ranks) of the bucket, Adam: the replicas of the
+        post-processing net stay identical (rank 0's is the one that is checkpointed and every rank's metrics steer
+        scheduler_postprocess through mean_over_ranks)."""
+        (mse / self.grad_acc_iters).float().backward()
+        self._bucket_postprocess.all_reduce_mean()
+        self.optimizer_postprocess.step()
+
     def train_one_epoch_postprocess(self):
         """agents/liftingDWT_agent.py:113-153: the codec is frozen (eval), only the post-processing net trains, on the MSE."""
         self.model.eval()
         self.postprocess.train()
         for x in self.data_loader.train_loader:
             x = x.to(self.device)
-            self.optimizer_postprocess.zero_grad()
+            self._postprocess_zero_grad()
             loss, mse, r1, r2 = self._postprocess_batch(x, True)
-            (mse / self.grad_acc_iters).float().backward()                      # :141
-            self.optimizer_postprocess.step()
+            self._postprocess_backward_and_step(mse)
             self.current_iteration += 1
             vals = (loss.item(), mse.item(), r1.item(), r2.item())
             self.train_logger(*vals)

@@ -525,10 +525,27 @@ extern "C" int64_t lldwt_cdf97_ws_bytes(int64_t Z, int64_t H, int64_t W) {
     return (int64_t)sizeof(float) * (Z * H * (W / 2) * 2 + Z * (H / 2) * (W / 2) * 2);
 }
 
+static int g_short_levels_periodic = 0;
+extern "C" int lldwt_set_cdf97_short_levels(int periodic) {
+    g_short_levels_periodic = periodic ? 1 : 0;
+    return LLDWT_OK;
+}
+
 static int cdf_args(const char* who, int64_t Z, int64_t H, int64_t W, int levels, void* ws, int64_t ws_bytes) {
     LLDWT_REQUIRE(Z > 0 && Z <= 65535 && levels > 0 && levels < 16, "%s: bad Z/levels", who);
     LLDWT_REQUIRE(H > 0 && W > 0 && H % (1 << levels) == 0 && W % (1 << levels) == 0,
                   "%s: H=%ld W=%ld must be divisible by 2^levels", who, (long)H, (long)W);
+    // level inputs shorter than the 10-tap filter (2, 4, 6, 8 samples): the reference's pytorch_wavelets afb1d folds the linear
+    // convolution back ONCE (restated from its source in the test infrastructure; the library is absent, so that form is itself unpinned), these
+    // kernels wrap every tap (the periodic transform, = PyWavelets).  The two differ there, so such a call fails unless the
+    // caller opted into the periodic form (lldwt_set_cdf97_short_levels(1))
+    if (!g_short_levels_periodic) {
+        const int64_t smallest = (H < W ? H : W) >> (levels - 1);
+        LLDWT_REQUIRE(smallest >= 10, "%s: the level-%d input is %ld samples, shorter than the 10-tap CDF 9/7 filter: the "
+                      "reference (pytorch_wavelets, single fold) and the exact periodic transform computed here differ on it; "
+                      "use fewer levels / a larger image, or call lldwt_set_cdf97_short_levels(1) to accept the periodic form",
+                      who, levels - 1, (long)smallest);
+    }
     LLDWT_REQUIRE(ws, "%s: null workspace", who);
     LLDWT_REQUIRE(Z * cdiv(H / 2, CT) * cdiv(W / 2, CT) < (1ll << 31), "%s: too many tiles for one grid", who);
     if (ws_bytes < lldwt_cdf97_ws_bytes(Z, H, W)) {

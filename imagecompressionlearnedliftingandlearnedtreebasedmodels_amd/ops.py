@@ -170,6 +170,13 @@ def lifting_inverse(ll, yh, taps, packed, Cc, K, res_weight, linear=False, scale
     return x
 
 
+def set_cdf97_short_levels(periodic):
+    """Policy for CDF 9/7 level inputs shorter than the 10-tap filter (lldwt_set_cdf97_short_levels): False (default) =
+    such a call raises LLDWTError (the reference's single-fold form and the exact periodic transform differ there),
+    True = compute the periodic form (= PyWavelets)."""
+    check(_lib.load().lldwt_set_cdf97_short_levels(1 if periodic else 0), "lldwt_set_cdf97_short_levels")
+
+
 def cdf97_forward(x, levels, adj=False):
     """x: (Z..., H, W) as (P,B,C,H,W) -> (ll, [yh_i (P,B,C*3? no: (P,B*C,3,h,w))]).  Channels are folded into batch."""
     lib = _lib.load()

@@ -96,6 +96,10 @@ def mean_over_ranks(values, device="cpu"):
     return (t / dist.get_world_size()).tolist()
 
 
+def rank():
+    return dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", 0))
+
+
 def is_rank0():
     return (not dist.is_initialized()) or dist.get_rank() == 0
 

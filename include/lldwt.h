@@ -457,6 +457,12 @@ int lldwt_axpby(const float* a, const float* b, float* out, int64_t n, float alp
 /* ---------------------------------------------------------------------------------------------------------
  * Fixed CDF 9/7 (bior4.4) DWT, periodization (DWTPytorchWaveletsLayer, lifting_dwt_nets.py:228-231,250,274).
  * Same tensor conventions as lldwt_lifting_forward/inverse.                                                */
+/* Level inputs SHORTER than the 10-tap filter (2, 4, 6 or 8 samples, e.g. a 64 x 64 image at 4 levels).  The reference's
+ * pytorch_wavelets afb1d / sfb1d fold the linear convolution back once there; these kernels compute the exact periodic
+ * transform (= PyWavelets 'periodization', perfect reconstruction).  The two forms differ on such levels and agree from
+ * 10 samples up (every BASELINE config: smallest level input 32).  periodic = 0 (default): lldwt_cdf97_* return
+ * LLDWT_EINVAL for such a call instead of silently differing from the reference; 1: compute the periodic form.        */
+int lldwt_set_cdf97_short_levels(int periodic);
 int64_t lldwt_cdf97_ws_bytes(int64_t Z, int64_t H, int64_t W);
 int lldwt_cdf97_forward(const float* x, float* ll, float* const* yh, int64_t Z, int64_t H, int64_t W, int levels,
                         void* ws, int64_t ws_bytes, void* stream);

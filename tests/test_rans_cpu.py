@@ -66,6 +66,57 @@ def test_encode_bytes_equal_the_oracle_and_round_trip():
     assert 8 * len(stream) <= bits * 1.001 + 64 + esc * 60
 
 
+def test_different_tables_per_call_share_a_stream_and_decoder_cache_is_safe():
+    """ADVICE r2.  compressai resolves each buffered symbol with the tables passed IN ITS call: two calls with different
+    tables must give one stream that decodes chunk by chunk with the matching tables (bytes = the oracle coder run on the
+    stacked tables).  The decoder's converted-table cache must not outlive set_stream, must not confuse a new list with a
+    freed one of the same id, and must see an in-place edit of a list."""
+    ta, tb = _tables(5, ncdf=4), _tables(6, ncdf=3)
+    g = np.random.default_rng(9)
+
+    def draw(t, n):
+        idx = g.integers(0, len(t[0]), n).astype(np.int32)
+        sym = np.array([int(g.integers(t[2][i], t[2][i] + t[1][i] - 2)) for i in idx], dtype=np.int32)
+        return sym, idx
+    sa, ia = draw(ta, 400)
+    sb, ib = draw(tb, 300)
+    enc = ans.BufferedRansEncoder()
+    enc.encode_with_indexes(sa, ia, *ta)
+    enc.encode_with_indexes(sb, ib, *tb)
+    enc.encode_with_indexes(sa[:50], ia[:50], *ta)                 # the first tables again: no third copy
+    stream = enc.flush()
+    stacked = (ta[0] + tb[0], ta[1] + tb[1], ta[2] + tb[2])
+    ref = orans.encode(sa.tolist() + sb.tolist() + sa[:50].tolist(),
+                       ia.tolist() + (ib + len(ta[0])).tolist() + ia[:50].tolist(), *stacked)
+    assert stream == ref
+    dec = ans.RansDecoder()
+    dec.set_stream(stream)
+    assert dec.decode_stream(ia.tolist(), *ta) == sa.tolist()
+    assert dec.decode_stream(ib.tolist(), *tb) == sb.tolist()      # fresh lists: converted again, not the cached first tables
+    assert dec.decode_stream(ia[:50].tolist(), *ta) == sa[:50].tolist()
+    with pytest.raises(Exception):
+        enc.encode_with_indexes(sa, ia + 100, *ta)                 # an index outside this call's tables
+    # numpy tables are cached by identity; a list edited in place between calls is seen
+    na = tuple(np.asarray(x, dtype=np.int32) if not isinstance(x[0], list) else None for x in ta)
+    width = max(len(r) for r in ta[0])
+    m = np.zeros((len(ta[0]), width), dtype=np.int32)
+    for i, r in enumerate(ta[0]):
+        m[i, :len(r)] = r
+    e2 = ans.RansEncoder()
+    st2 = e2.encode_with_indexes(sa, ia, m, na[1], na[2])
+    assert st2 == orans.encode(sa.tolist(), ia.tolist(), *ta)
+    d2 = ans.RansDecoder()
+    d2.set_stream(st2)
+    assert d2.decode_stream(ia[:100], m, na[1], na[2]) == sa[:100].tolist()
+    assert d2._tab_key is not None and d2._tab_key[0] is m
+    assert d2.decode_stream(ia[100:], m, na[1], na[2]) == sa[100:].tolist()
+    d2.set_stream(st2)
+    assert d2._tab_key is None                                     # a new stream starts without cached tables
+    cd = [list(r) for r in ta[0]]
+    assert d2.decode_stream(ia[:10].tolist(), cd, ta[1], ta[2]) == sa[:10].tolist()
+    assert d2._tab_key is None                                     # lists are never cached
+
+
 def test_empty_and_corrupt_streams():
     cdfs, sizes, offs = _tables(4)
     e = ans.BufferedRansEncoder()

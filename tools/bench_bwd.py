@@ -3,7 +3,7 @@
 weight-gradient GEMMs and backward-data convs of the lifting P-blocks, the tree context conv and the cgp 1x1 stack.
 Prints one JSON object: per case ms and useful TFLOP/s (2*MACs of the layer, not the padded MFMA work).
 
-    python tools_bench_bwd.py [--iters 10] [--only lift]
+    python tools/bench_bwd.py [--iters 10] [--only lift]
 """
 import argparse
 import json
@@ -12,8 +12,9 @@ import sys
 
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from tools_bench_kernels import timeit  # noqa: E402
+from bench_kernels import timeit  # noqa: E402
 
 
 def main():

@@ -2,7 +2,7 @@
 """Micro-benchmark of the HBM-bound kernels of the path (north_star's HBM-roofline target applies to these):
 fixed CDF 9/7 4-level DWT, Gaussian / factorized rate kernels, colour transform.  Prints one JSON object.
 
-    python tools_bench_kernels.py [--batch 8 --size 512 --iters 20]
+    python tools/bench_kernels.py [--batch 8 --size 512 --iters 20]
 """
 import argparse
 import json
@@ -11,6 +11,7 @@ import sys
 
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK = 8000.0
 
