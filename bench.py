@@ -36,14 +36,18 @@ CONFIGS = {
             note="configs[0] is the reference's CPU plumbing case (liftingDWT.json); the product has no CPU path, so the "
                  "same model runs on the GPU here (HBM / launch bound)"),
     1: dict(netType="LiftingBasedNeuralWaveletv4", entropy_layer="factorized", levels=3, batch=16, H=256, W=256, strips=0,
-            note="configs[1] names bf16 storage; this line is the fp32 path (bf16 storage is reported separately)"),
+            precision="bf16",
+            note="configs[1] names bf16: the matrix kernels run ONE bf16 MFMA product per MAC (LLDWT_PRECISION=bf16; fp32 accumulate, "
+                 "fp32 tensors in HBM; tolerance class 1e-2, tests/test_gpu_precision.py); --precision f16x3 gives the fp32-accurate line"),
     2: dict(netType="LiftingBasedNeuralWaveletv4", entropy_layer="conditioned2ZTsepSubbands", levels=4, batch=8, H=512,
             W=512, strips=0, note="the configuration the metric is quoted on"),
     3: dict(netType="LiftingBasedNeuralWaveletv4", entropy_layer="onlyEZWT", levels=4, batch=4, H=1024, W=1024, strips=0,
             note="configs[3]: batch 32 over 8 ranks = 4 images of 1024x1024 per GPU; the training leg is the DP step"),
     4: dict(netType="LiftingBasedNeuralWaveletv4", entropy_layer="onlyEZWT", levels=4, batch=1, H=2160, W=3840, strips=8,
-            note="configs[4]: one 3840x2160 frame per GPU cut into 8 independent 480x2160 strips (tiling.split_strips); "
-                 "fp32 storage (fp16 storage is reported separately)"),
+            precision="fp16",
+            note="configs[4]: one 3840x2160 frame per GPU cut into 8 independent 480x2160 strips (tiling.split_strips); names fp16: the "
+                 "matrix kernels run ONE fp16 MFMA product per MAC (LLDWT_PRECISION=fp16; fp32 accumulate, fp32 tensors in HBM; "
+                 "tolerance class 1e-2, tests/test_gpu_precision.py); --precision f16x3 gives the fp32-accurate line"),
 }
 
 
@@ -93,6 +97,9 @@ def parse_args():
     ap.add_argument("--train-steps", type=int, default=2,
                     help="extra (not part of `value`): time this many full training steps (fwd + hand-written bwd + "
                          "gradient all-reduce + Adam) on the same workload; 0 disables")
+    ap.add_argument("--precision", default="", choices=["", "f16x3", "fp16", "bf16"],
+                    help="arithmetic of the eval path's matrix kernels; default: what the BASELINE config names (configs[1] bf16, "
+                         "configs[4] fp16, otherwise f16x3 = three fp16 products per fp32 MAC, fp32-level accuracy)")
     ap.add_argument("--plc-mode", default="", help="override LLDWT_PLC_MODE (f16x3 | f32) for the dominant conv")
     ap.add_argument("--storage", default="", help="override LLDWT_STORAGE (fp32 | fp16): storage type of the tree-context tensor "
                                                   "(BASELINE configs[4] names fp16; its own tolerance class, never the headline)")
@@ -147,6 +154,9 @@ def resolve_workload(a):
     if a.entropy:
         c["entropy_layer"] = a.entropy
         explicit.append("entropy")
+    c["precision_run"] = a.precision or c.get("precision", "f16x3")
+    if a.precision and a.precision != c.get("precision", "f16x3"):
+        explicit.append("precision")
     c["overrides"] = explicit
     return c
 
@@ -162,9 +172,10 @@ def workload_string(c, a):
     else:
         shape = "%dx3x%dx%d per GPU" % (c["batch"], c["H"], c["W"])
     st = os.environ.get("LLDWT_STORAGE", "fp32")
+    prec = c.get("precision_run", "f16x3")
     s = "BASELINE configs[%d]%s: %s + SubbandAutoEncoder + %s, %s, %s, eval" % (
         a.config, " with overrides (%s)" % ",".join(c["overrides"]) if c["overrides"] else "", tr, c["entropy_layer"], shape,
-        "fp32" if st == "fp32" else "fp32 with fp16 STORAGE of the tree-context tensor")
+        ("fp32 tensors, %s matrix arithmetic" % prec) if st == "fp32" else "fp32 with fp16 STORAGE of the tree-context tensor")
     return s
 
 
@@ -348,6 +359,8 @@ def main():
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops, tiling
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models.LiftingBasedDWT_net import rate_planes
     c = resolve_workload(a)
+    ops.set_precision(c["precision_run"])                    # eval path only; the training leg always runs f16x3 / fp32
+    nprod_mode = 3.0 if c["precision_run"] == "f16x3" else 1.0
     log("building model: %s" % workload_string(c, a))
     net, sd, cfg = build_model(c, dev)
     nets = net.nets()
@@ -484,29 +497,29 @@ def main():
         if _L.load().lldwt_get_lift_mode() == 1:
             # fused split-fp16 lifting step (k_lift_fused_f16): three fp16 MFMA products per fp32 MAC, bounded by the
             # dense fp16 MFMA peak (halo recomputation NOT counted as work)
-            roof["arithmetic"] = "f16x3"
+            roof["arithmetic"] = c["precision_run"]
             roof["kernel"] = ("learned lifting forward, %d levels: k_lift_fused_f16 (one persistent launch per lifting step, "
-                              "split-fp16 MFMA) inside one lldwt_lifting_forward call" % c["levels"])
+                              "%s MFMA) inside one lldwt_lifting_forward call" % (c["levels"], c["precision_run"]))
             roof["fp32_equivalent_tflops"] = achieved
             roof["frac_of_fp32_mfma_peak"] = achieved / F32_MFMA_PEAK_TFLOPS
             roof["peak"] = F16_MFMA_PEAK_TFLOPS
-            roof["achieved"] = 3.0 * achieved
-            roof["frac"] = 3.0 * achieved / F16_MFMA_PEAK_TFLOPS
+            roof["achieved"] = nprod_mode * achieved
+            roof["frac"] = nprod_mode * achieved / F16_MFMA_PEAK_TFLOPS
             lpf = 8 * c["levels"]             # kernel launches per forward call (4 row + 4 paired column steps per level)
             roof["launches_per_forward"] = lpf
             roof["launches"] = lpf * n_launch
             roof["avg_launch_ms"] = dom_ms / roof["launches"]
-            roof["algorithmic_flop_per_launch"] = 3.0 * dom["work"] / roof["launches"]
-            roof["peak_note"] = ("peak = dense fp16 MFMA (2.5 PFLOP/s); achieved = 3 fp16 products per fp32 MAC x the "
+            roof["algorithmic_flop_per_launch"] = nprod_mode * dom["work"] / roof["launches"]
+            roof["peak_note"] = ("peak = dense fp16 / bf16 MFMA (2.5 PFLOP/s); achieved = %d MFMA product(s) per MAC x the "
                                  "transform's algorithmic MACs (SURVEY 8d) / HIP-event time of the whole forward call "
-                                 "(avg_launch_ms = that time / the call's kernel launches)")
+                                 "(avg_launch_ms = that time / the call's kernel launches)" % int(nprod_mode))
     if has_plc:
         mode = ops.plc_mode()
         roof["arithmetic"] = mode
         if mode == "f16x3" and ops.plc_fuse() and ops.storage_dtype() != "fp16":
             roof["kernel"] = ("tree-context pair conv 3->243 (on the fly) + conv 243->243 3x3 in one launch, k_conv3_f16x3<2> "
                               "(lldwt_plc_fused; the largest share of the step's FLOPs)")
-        nprod = 2.0 if ops.storage_dtype() == "fp16" else 3.0
+        nprod = 2.0 if ops.storage_dtype() == "fp16" else nprod_mode
         if ops.storage_dtype() == "fp16":
             roof["storage"] = "fp16 (tree-context tensor stored as fp16; 2 MFMA products per MAC; tolerance class 1e-2)"
         if mode == "f16x3":
@@ -520,9 +533,10 @@ def main():
             roof["achieved"] = nprod * achieved
             roof["frac"] = nprod * achieved / F16_MFMA_PEAK_TFLOPS
             roof["algorithmic_flop_per_launch"] = nprod * dom["work"] / n_launch
-            roof["peak_note"] = ("peak = dense fp16 MFMA (2.5 PFLOP/s); achieved = 3 fp16 products per fp32 MAC x the conv's "
+            roof["arithmetic"] = c["precision_run"] if ops.storage_dtype() != "fp16" else "f16x2 (fp16 storage)"
+            roof["peak_note"] = ("peak = dense fp16 / bf16 MFMA (2.5 PFLOP/s); achieved = %g MFMA product(s) per MAC x the conv's "
                                  "algorithmic MACs / HIP-event time; fp32_equivalent_tflops / frac_of_fp32_mfma_peak compare "
-                                 "the same launches with the fp32 MFMA roof (157.3 TF) of the reference arithmetic")
+                                 "the same launches with the fp32 MFMA roof (157.3 TF) of the reference arithmetic" % nprod)
         else:
             roof["peak_note"] = "peak = dense fp32-input MFMA (157.3 TFLOP/s); exact fp32 arithmetic (LLDWT_PLC_MODE=f32)"
     # what executes: every tensor in HBM is fp32; the matrix work of the eval path runs as three fp16 MFMA products per fp32 MAC
@@ -530,7 +544,12 @@ def main():
     from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import _lib as _L0
     f16_lift = lifting and _L0.load().lldwt_get_lift_mode() == 1
     f16_plc = has_plc and ops.plc_mode() == "f16x3"
-    dtype = "f32 storage, f16x3 arithmetic (3 fp16 MFMA products per fp32 MAC, fp32 accumulate)" if (f16_lift or f16_plc) else "f32"
+    if not (f16_lift or f16_plc):
+        dtype = "f32"
+    elif c["precision_run"] == "f16x3":
+        dtype = "f32 storage, f16x3 arithmetic (3 fp16 MFMA products per fp32 MAC, fp32 accumulate)"
+    else:
+        dtype = "%s (one %s MFMA product per MAC, fp32 accumulate; fp32 storage)" % (c["precision_run"], c["precision_run"])
     if roof.get("fp32_equivalent_tflops") is not None and roof["unit"] == "TFLOP/s":
         roof["frac_algorithmic"] = roof["fp32_equivalent_tflops"] / roof["peak"]     # the conv's own MACs only, same roof
     out = {
@@ -555,9 +574,10 @@ def main():
                 c["levels"], "persistent k_lift_fused_f16 launches (the L / H column passes of a level share a launch), split-fp16" if f16l else "fp32 MFMA launches"),
             "ms_per_step": ms2 / len(dom2["events"]), "calls": len(dom2["events"]),
             "fp32_equivalent_tflops": tf2, "frac_of_fp32_mfma_peak": tf2 / F32_MFMA_PEAK_TFLOPS,
-            "achieved": (3.0 if f16l else 1.0) * tf2, "peak": F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS,
-            "frac": (3.0 if f16l else 1.0) * tf2 / (F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS),
-            "note": "algorithmic MACs of the transform (SURVEY 8d), halo recomputation not counted; 3 fp16 products per MAC"}
+            "achieved": (nprod_mode if f16l else 1.0) * tf2, "peak": F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS,
+            "frac": (nprod_mode if f16l else 1.0) * tf2 / (F16_MFMA_PEAK_TFLOPS if f16l else F32_MFMA_PEAK_TFLOPS),
+            "note": "algorithmic MACs of the transform (SURVEY 8d), halo recomputation not counted; %d MFMA product(s) per MAC (%s)"
+                    % (int(nprod_mode), c["precision_run"])}
         lift_roof["frac_algorithmic"] = tf2 / lift_roof["peak"]
         # kernel launches of one forward call: per level 4 row-pass steps + 4 column steps (the L and H column passes share
         # a launch); the fp32 path takes 3 launches for each of the 12 steps of a level.  HIP events bracket the whole call.
@@ -565,7 +585,7 @@ def main():
         lift_roof["launches_per_forward"] = lpf
         lift_roof["launches"] = lpf * len(dom2["events"])
         lift_roof["avg_launch_ms"] = ms2 / lift_roof["launches"]
-        lift_roof["algorithmic_flop_per_launch"] = (3.0 if f16l else 1.0) * dom2["work"] / lift_roof["launches"]
+        lift_roof["algorithmic_flop_per_launch"] = (nprod_mode if f16l else 1.0) * dom2["work"] / lift_roof["launches"]
         lift_roof["traffic"], lift_roof["traffic_source"] = None, None
         try:
             with open(tpath) as f:
@@ -586,6 +606,7 @@ def main():
             out["roofline"], out["roofline_second"] = lift_roof, roof
         else:
             out["roofline_second"] = lift_roof
+    ops.set_precision("f16x3")
     if a.train_steps > 0:
         try:
             out["train"] = train_leg(a, c, dev, rank, world_seen, x)

@@ -54,6 +54,8 @@ SIGNATURES = {
     "lldwt_pblock_packed_floats": (_i64, [_i, _i]),
     "lldwt_set_lift_mode": (_i, [_i]),
     "lldwt_set_diagnostics": (_i, [_i, _p, _i64, _i]),
+    "lldwt_set_precision": (_i, [_i]),
+    "lldwt_get_precision": (_i, []),
     "lldwt_set_cdf97_short_levels": (_i, [_i]),
     "lldwt_get_lift_mode": (_i, []),
     "lldwt_pack_pblock": (_i, [_p] * 9 + [_i, _i, _i, _p]),
@@ -163,7 +165,16 @@ def load():
     if mode not in ("f16x3", "f32"):
         raise LLDWTError("LLDWT_LIFT_MODE must be 'f16x3' or 'f32' (got %r)" % mode)
     lib.lldwt_set_lift_mode(1 if mode == "f16x3" else 0)
+    prec = os.environ.get("LLDWT_PRECISION", "f16x3")
+    if prec not in PRECISIONS:
+        raise LLDWTError("LLDWT_PRECISION must be one of %s (got %r)" % (sorted(PRECISIONS), prec))
+    lib.lldwt_set_precision(PRECISIONS[prec])
     return lib
+
+
+# arithmetic of the eval path's matrix kernels (lldwt_set_precision): three fp16 MFMA products per fp32 MAC (default, fp32-level
+# accuracy), or ONE product on fp16 / bf16 operands (BASELINE configs[4] / configs[1]; tolerance class 1e-2)
+PRECISIONS = {"f16x3": 0, "fp16": 1, "bf16": 2}
 
 
 def check(rc, what):

@@ -24,6 +24,7 @@
 // Output: params (planes, batch, 2*groups, h, w) = (sigma, mu) interleaved per subband, consumed by lldwt_gauss_rate.
 #include "common.h"
 #include "split_f16.h"
+#include "lifting_f16.h"      // split_precision()
 
 namespace lldwt {
 
@@ -40,7 +41,8 @@ constexpr int NM1 = 2;                 // layer 1 (64 >= 54)
 constexpr int NSTEP = NM0 * (NK0 + 2 * NM1) + 2 * NM1 + 2;     // 60 + 4 + 2 = 66 weight steps
 constexpr int STEP_BYTES = 2048;       // hi fragment + lo fragment
 constexpr int HDR_FLOATS = 64 + 192 + 64 + 32 + 32;            // scalars | b0 | b1 | b2 | b3
-constexpr int GROUP_BYTES = HDR_FLOATS * 4 + (NSTEP + 3) * STEP_BYTES;   // + 3 steps of padding for the prefetch ring
+constexpr int BF_OFF = HDR_FLOATS * 4 + (NSTEP + 3) * STEP_BYTES;        // + 3 steps of padding for the prefetch ring
+constexpr int GROUP_BYTES = BF_OFF + (NSTEP + 3) * (STEP_BYTES / 2);     // then a bf16 copy of the scaled weights (one-product bf16 mode)
 constexpr int NB = 1;                  // pixel blocks of 32 per wave.  One block and two waves per SIMD (232 VGPRs): the other wave
                                        // computes while this one waits for its 48 input loads (two blocks in one wave at one wave
                                        // per SIMD share the weight stream, but nothing hides the input latency: 12 % slower)
@@ -135,6 +137,7 @@ __global__ void k_cgp16_pack(const float* __restrict__ w0, const float* __restri
         const _Float16 hi = (_Float16)v;
         fr[step * 1024 + lane * 8 + j] = hi;
         fr[step * 1024 + 512 + lane * 8 + j] = (_Float16)(v - (float)hi);
+        reinterpret_cast<__bf16*>(dst + BF_OFF)[step * 512 + lane * 8 + j] = (__bf16)v;
     }
 }
 
@@ -165,6 +168,7 @@ __device__ __forceinline__ void load_bias_scaled(const float* bias_lds, int h, f
 #pragma unroll
     for (int q = 0; q < 16; ++q) bsc[q] = bias_lds[drow(q, h)] * snext;
 }
+template <int PREC>
 __device__ __forceinline__ void next_frags(const floatx16& acc, float k, const float (&bsc)[16], half8 (&bh)[2], half8 (&bl)[2]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -174,11 +178,15 @@ __device__ __forceinline__ void next_frags(const floatx16& acc, float k, const f
             const float t = __builtin_fmaf(acc[8 * s + j], k, bsc[8 * s + j]);
             v[j] = fmaxf(t, 0.01f * t);
         }
-        split8v(v, bh[s], bl[s]);
+        if constexpr (PREC == 0) split8v(v, bh[s], bl[s]);
+        else bh[s] = cvt8<PREC>(v);
     }
 }
 
+// PREC (lldwt_set_precision): 0 = three MFMA products per MAC (split fp16), 1 / 2 = one product on fp16 / bf16 operands
+template <int PREC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cgp16(Cgp16Args a) {
+    constexpr int SB = PREC == 2 ? STEP_BYTES / 2 : STEP_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h5 = lane >> 5, pl = lane & 31;
     const int64_t z = blockIdx.z;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();                                             // the only barrier: before any wave can leave
     if (col >= a.cols) return;                                   // whole wave
     const float* bias0 = sbias, * bias1 = sbias + 192, * bias2 = sbias + 256, * bias3 = sbias + 288;
-    const uint8_t* wst = grp + HDR_FLOATS * 4 + lane * 16;
+    const uint8_t* wst = grp + (PREC == 2 ? BF_OFF : HDR_FLOATS * 4) + lane * 16;
     CGP_STAMP(0)
     CGP_STAMP(6)
 
@@ -260,28 +268,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = xin[nb][k][j] * s_in;
-            split8v(v, b0h[nb][k], b0l[nb][k]);
+            if constexpr (PREC == 0) split8v(v, b0h[nb][k], b0l[nb][k]);
+            else b0h[nb][k] = cvt8<PREC>(v);
         }
 
     // ---- weight stream: ring of 4 steps
     half8 ah[4], al[4];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        ah[i] = *reinterpret_cast<const half8*>(wst + i * STEP_BYTES);
-        al[i] = *reinterpret_cast<const half8*>(wst + i * STEP_BYTES + 1024);
+        ah[i] = *reinterpret_cast<const half8*>(wst + i * SB);
+        if constexpr (PREC == 0) al[i] = *reinterpret_cast<const half8*>(wst + i * SB + 1024);
     }
     int step = 0;
 #define CGP16_NEXT()                                                                                  \
     {                                                                                                 \
-        ah[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * STEP_BYTES);          \
-        al[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * STEP_BYTES + 1024);   \
+        ah[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * SB);                  \
+        if constexpr (PREC == 0) al[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * SB + 1024); \
         __builtin_amdgcn_sched_barrier(0);   /* the scheduler otherwise sinks these loads down to their use (3 steps later) */ \
     }
 #define CGP16_MMA(ACC, BH, BL)                                                                        \
     {                                                                                                 \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[step & 3], BH, ACC, 0, 0, 0);                 \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[step & 3], BL, ACC, 0, 0, 0);                 \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[step & 3], BH, ACC, 0, 0, 0);                 \
+        if constexpr (PREC == 0) {                                                                    \
+            ACC = mma32<0>(al[step & 3], BH, ACC);                                                    \
+            ACC = mma32<0>(ah[step & 3], BL, ACC);                                                    \
+        }                                                                                             \
+        ACC = mma32<PREC>(ah[step & 3], BH, ACC);                                                     \
     }
 
     floatx16 acc1[NB][NM1];
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float bsc[16];
             load_bias_scaled(bias0 + 32 * m0, h5, s1, bsc);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) next_frags(acc0[nb], inv0 * s1, bsc, b1h[nb], b1l[nb]);
+            for (int nb = 0; nb < NB; ++nb) next_frags<PREC>(acc0[nb], inv0 * s1, bsc, b1h[nb], b1l[nb]);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float bsc[16];
             load_bias_scaled(bias1 + 32 * m1, h5, s2, bsc);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) next_frags(acc1[nb][m1], inv1 * s2, bsc, b2h[nb], b2l[nb]);
+            for (int nb = 0; nb < NB; ++nb) next_frags<PREC>(acc1[nb][m1], inv1 * s2, bsc, b2h[nb], b2l[nb]);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float bsc[16];
             load_bias_scaled(bias2, h5, s3, bsc);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) next_frags(acc2[nb], inv2 * s3, bsc, b3h[nb], b3l[nb]);
+            for (int nb = 0; nb < NB; ++nb) next_frags<PREC>(acc2[nb], inv2 * s3, bsc, b3h[nb], b3l[nb]);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -436,6 +447,9 @@ extern "C" int lldwt_cgp16_params(const float* plc, const float* xq, const void*
         a.stamps = (g_cgp_stamps && g_cgp_stamps_bytes >= need) ? g_cgp_stamps : nullptr;
     }
     dim3 grid((unsigned)cdiv(a.cols, 4), (unsigned)groups, (unsigned)(planes * batch));
-    hipLaunchKernelGGL(k_cgp16, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const int prec = split_precision();
+    if (prec == 1) hipLaunchKernelGGL(k_cgp16<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (prec == 2) hipLaunchKernelGGL(k_cgp16<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_cgp16<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("cgp16_params");
 }

@@ -23,13 +23,13 @@
 //      straight from L2 into registers (1 KB coalesced per instruction, no LDS), two k-steps ahead.
 #include "common.h"
 #include "split_f16.h"
+#include "lifting_f16.h"      // split_precision(): the one-product fp16 / bf16 modes of the fused pair (lldwt_set_precision)
 #include <type_traits>
 
 namespace lldwt {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-
 constexpr int F3_CK = 32;                       // input channels per chunk
 constexpr int F3_TH = 8, F3_TW = 32;            // output pixels per workgroup
 constexpr int F3_IH = F3_TH + 2, F3_IW = F3_TW + 2, F3_NPX = F3_IH * F3_IW;   // 10 x 34 = 340 staged pixels
@@ -50,13 +50,19 @@ constexpr int F1_NBLK = (F3_NPX + 31) / 32;     // 11 pixel blocks of 32 cover t
 constexpr int F1_COL = 12 * 4 * 1024;           // the split im2col of the parent patch, [block][k-step][hi|lo][lane][8 x fp16]
 constexpr int F1_PP = 3 * 6 * 18;               // parent values under a tile (see the kernel)
 constexpr int F1_LDS = F3_LDS + F1_COL + 1536;  // + the parent patch: 159,552 B
-static inline int64_t f1_plane_bytes(int cmid) { return F1_HDR + (int64_t)cdiv(cmid, F3_CK) * F1_CHUNK_BYTES; }
+// behind the (hi, lo) fp16 fragments: a bf16 copy of the scaled weights, half a step's bytes per step (one-product bf16 mode)
+static inline int64_t f1_bf_off(int cmid) { return F1_HDR + (int64_t)cdiv(cmid, F3_CK) * F1_CHUNK_BYTES; }
+static inline int64_t f1_plane_bytes(int cmid) { return f1_bf_off(cmid) + (int64_t)cdiv(cmid, F3_CK) * (F1_CHUNK_BYTES / 2); }
 
 static inline int f3_nch(int cin) { return (int)cdiv(cin, F3_CK); }
 static inline int f3_nocb(int cout) { return (int)cdiv(cout, F3_OCB); }
-static inline int64_t f3_plane_bytes(int cin, int cout) {
+static inline __host__ __device__ int64_t f3_bf_off_n(int nocb, int nch) {
     // + 5 steps of padding: the kernel prefetches weight fragments 5 steps ahead without a bounds branch
-    return F3_HDR + (int64_t)f3_nocb(cout) * 4 * f3_nch(cin) * F3_CHUNK_BYTES + 5 * F3_STEP_BYTES;
+    return F3_HDR + (int64_t)nocb * 4 * nch * F3_CHUNK_BYTES + 5 * F3_STEP_BYTES;
+}
+static inline int64_t f3_plane_bytes(int cin, int cout) {
+    // the (hi, lo) fp16 steps, then a bf16 copy at half the bytes per step (same 5 steps of padding)
+    return f3_bf_off_n(f3_nocb(cout), f3_nch(cin)) + (int64_t)f3_nocb(cout) * 4 * f3_nch(cin) * (F3_CHUNK_BYTES / 2) + 5 * (F3_STEP_BYTES / 2);
 }
 
 __device__ __forceinline__ float pow2_scale_for(float amax) {
@@ -130,6 +136,7 @@ __global__ void k_f3_pack(const float* __restrict__ w, uint8_t* __restrict__ pac
         const int64_t step = ((((int64_t)(ocb * 4 + wv) * nch + chunk) * 9 + tap) * 2 + ks);
         out[step * 1024 + lane * 8 + j] = hi;                                   // 1024 halves = 2048 B per step
         out[step * 1024 + 512 + lane * 8 + j] = lo;
+        reinterpret_cast<__bf16*>(pp + f3_bf_off_n(nocb, nch))[step * 512 + lane * 8 + j] = (__bf16)v;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = sw;
 }
@@ -181,6 +188,7 @@ __global__ void k_f1_pack(const float* __restrict__ w1, const float* __restrict_
         const _Float16 hi = (_Float16)v;
         fr[(chunk * 2 + ks) * 1024 + lane * 8 + j] = hi;
         fr[(chunk * 2 + ks) * 1024 + 512 + lane * 8 + j] = (_Float16)(v - (float)hi);
+        reinterpret_cast<__bf16*>(pp + F1_HDR + (int64_t)nch * F1_CHUNK_BYTES)[(chunk * 2 + ks) * 512 + lane * 8 + j] = (__bf16)v;
     }
 }
 
@@ -214,9 +222,13 @@ struct F3Args {
 //               tile and kept in registers) and written straight into the LDS image that the second conv reads: no first
 //               conv launch, no 243-channel tensor in HBM (1.5 GB written + 2 GB read per level-0 launch), no global
 //               staging loads, no |x|-max pass (the activation scale comes from a per-workgroup bound).
-template <int MODE>
+// PREC (FUSED only; lldwt_set_precision): 0 = three products per MAC as above; 1 / 2 = ONE product on fp16 / bf16 operands -- the
+//               lo images and lo fragments are neither written nor read, a third of the MFMAs.
+template <int MODE, int PREC = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv3_f16x3(F3Args a) {
     constexpr bool IN16 = MODE == 1, FUSED = MODE == 2;
+    static_assert(PREC == 0 || FUSED, "the one-product modes exist for the fused pair (eval path)");
+    constexpr int SB = PREC == 2 ? F3_STEP_BYTES / 2 : F3_STEP_BYTES;      // bytes per weight step in the section being read
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t z = blockIdx.z;
@@ -310,7 +322,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[n][q] = 0.f;
 
-    const uint8_t* wbase = pp + F3_HDR + ((int64_t)(ocb * 4 + wave) * a.nch) * F3_CHUNK_BYTES + lane * 16;
+    const uint8_t* wbase = pp + (PREC == 2 ? f3_bf_off_n((a.cout + F3_OCB - 1) / F3_OCB, a.nch) : (int64_t)F3_HDR) +
+                           ((int64_t)(ocb * 4 + wave) * a.nch) * (18 * SB) + lane * 16;
     const int boff = (lane & 31) * F3_PITCH + (lane >> 5) * 16;     // B fragment: pixel column lane&31, k half lane>>5
 
     // ---- FUSED: the im2col of the parent patch for this wave's pixel blocks (wave, wave + 4, wave + 8), once per tile
@@ -381,10 +394,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const int i1 = (q1 / 9) * 108 + ro[(q1 % 9) / 3] + co[q1 % 3];
                     v8[j] = PP[hh ? i1 : i0] * s_p;
                 }
-                half8 ch_, cl_;
-                split8v(v8, ch_, cl_);
-                *reinterpret_cast<half8*>(col1 + (((wave + 4 * b) * 2 + ks) * 2 + 0) * 1024) = ch_;
-                *reinterpret_cast<half8*>(col1 + (((wave + 4 * b) * 2 + ks) * 2 + 1) * 1024) = cl_;
+                if constexpr (PREC == 0) {
+                    half8 ch_, cl_;
+                    split8v(v8, ch_, cl_);
+                    *reinterpret_cast<half8*>(col1 + (((wave + 4 * b) * 2 + ks) * 2 + 0) * 1024) = ch_;
+                    *reinterpret_cast<half8*>(col1 + (((wave + 4 * b) * 2 + ks) * 2 + 1) * 1024) = cl_;
+                } else {
+                    *reinterpret_cast<half8*>(col1 + (((wave + 4 * b) * 2 + ks) * 2 + 0) * 1024) = cvt8<PREC>(v8);
+                }
             }
         }
     }
@@ -396,10 +413,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                 // vmcnt(0) wait there, which drains the whole weight ring (vmcnt retires in order)
 #define F3_FUSED_LOAD(C1)                                                                                             \
     {                                                                                                                 \
-        const uint8_t* w1_ = pk1 + F1_HDR + (int64_t)((C1) / F3_CK) * F1_CHUNK_BYTES + lane * 16;                     \
+        const uint8_t* w1_ = pk1 + F1_HDR + (PREC == 2 ? (int64_t)a.nch * F1_CHUNK_BYTES : (int64_t)0) +                \
+                             (int64_t)((C1) / F3_CK) * (2 * SB) + lane * 16;                                          \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
-            w1h[ks] = *reinterpret_cast<const half8*>(w1_ + ks * F3_STEP_BYTES);                                      \
-            w1l[ks] = *reinterpret_cast<const half8*>(w1_ + ks * F3_STEP_BYTES + 1024);                               \
+            w1h[ks] = *reinterpret_cast<const half8*>(w1_ + ks * SB);                                                 \
+            if constexpr (PREC == 0) w1l[ks] = *reinterpret_cast<const half8*>(w1_ + ks * SB + 1024);                 \
         }                                                                                                             \
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                              \
             b1r[gq] = *reinterpret_cast<const floatx4*>(bias1 + (C1) + 8 * gq + 4 * (lane >> 5));                     \
@@ -412,10 +430,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         _Pragma("unroll") for (int q = 0; q < 16; ++q) t_[q] = 0.f;                                                   \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
             const half8 ch_ = *reinterpret_cast<const half8*>(col1 + (((wave + 4 * (B)) * 2 + ks) * 2 + 0) * 1024);  \
-            const half8 cl_ = *reinterpret_cast<const half8*>(col1 + (((wave + 4 * (B)) * 2 + ks) * 2 + 1) * 1024);  \
-            t_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[ks], ch_, t_, 0, 0, 0);                                   \
-            t_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ks], cl_, t_, 0, 0, 0);                                   \
-            t_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ks], ch_, t_, 0, 0, 0);                                   \
+            if constexpr (PREC == 0) {                                                                                \
+                const half8 cl_ = *reinterpret_cast<const half8*>(col1 + (((wave + 4 * (B)) * 2 + ks) * 2 + 1) * 1024); \
+                t_ = mma32<0>(w1l[ks], ch_, t_);                                                                      \
+                t_ = mma32<0>(w1h[ks], cl_, t_);                                                                      \
+            }                                                                                                         \
+            t_ = mma32<PREC>(w1h[ks], ch_, t_);                                                                       \
         }                                                                                                             \
         typedef _Float16 half4_ __attribute__((ext_vector_type(4)));                                                  \
         const bool livep_ = p1[B] >= 0;                                                                               \
@@ -428,10 +448,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const float v_ = __builtin_fmaf(t_[4 * gq + i], inv1sx, b1v[gq][i]);   /* sx (2^k) folded in */       \
                 v4_[i] = pin1[B] ? fmaxf(v_, 0.01f * v_) : 0.f;                                                       \
             }                                                                                                         \
-            half4_ hi_, lo_;                                                                                          \
-            split4v(v4_, hi_, lo_);                                                                                   \
-            *reinterpret_cast<half4_*>(d0_ + gq * gstep_) = hi_;                                                      \
-            *reinterpret_cast<half4_*>(d0_ + gq * gstep_ + lo_off_) = lo_;                                            \
+            if constexpr (PREC == 0) {                                                                                \
+                half4_ hi_, lo_;                                                                                      \
+                split4v(v4_, hi_, lo_);                                                                               \
+                *reinterpret_cast<half4_*>(d0_ + gq * gstep_) = hi_;                                                  \
+                *reinterpret_cast<half4_*>(d0_ + gq * gstep_ + lo_off_) = lo_;                                        \
+            } else {                                                                                                  \
+                typedef float f4_ __attribute__((ext_vector_type(4)));                                                \
+                typedef __bf16 b4_ __attribute__((ext_vector_type(4)));                                               \
+                const f4_ x_ = {v4_[0], v4_[1], v4_[2], v4_[3]};                                                      \
+                if constexpr (PREC == 2) *reinterpret_cast<b4_*>(d0_ + gq * gstep_) = __builtin_convertvector(x_, b4_); \
+                else *reinterpret_cast<half4_*>(d0_ + gq * gstep_) = __builtin_convertvector(x_, half4_);             \
+            }                                                                                                         \
         }                                                                                                             \
     }
 
@@ -463,14 +491,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     half8 ah[6], al[6];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        ah[i] = *reinterpret_cast<const half8*>(wbase + i * F3_STEP_BYTES);
-        al[i] = *reinterpret_cast<const half8*>(wbase + i * F3_STEP_BYTES + 1024);
+        ah[i] = *reinterpret_cast<const half8*>(wbase + i * SB);
+        if constexpr (PREC == 0) al[i] = *reinterpret_cast<const half8*>(wbase + i * SB + 1024);
     }
     F3_STAMP(1)
     for (int chunk = 0; chunk < a.nch; ++chunk) {
         if (chunk < 8) F3_STAMP(2 + chunk)
         const int buf = chunk & 1;
-        const uint8_t* wp = wbase + (int64_t)chunk * F3_CHUNK_BYTES;
+        const uint8_t* wp = wbase + (int64_t)chunk * (18 * SB);
         const uint8_t* bb = lds + buf * F3_BUF + boff;
         uint8_t* sdst = lds + (buf ^ 1) * F3_BUF;
         const int c1 = (chunk + 1 < a.nch ? chunk + 1 : chunk) * F3_CK;     // chunk being staged (last: itself, unused)
@@ -483,7 +511,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                            \
                 const int off = ((hf_ * 4 + n + dy_) * F3_IW + dx_) * F3_PITCH + ks_ * 32;             \
                 bh[SET][n] = *reinterpret_cast<const half8*>(bb + off);                                \
-                if constexpr (!IN16) bl[SET][n] = *reinterpret_cast<const half8*>(bb + F3_PART + off); \
+                if constexpr (!IN16 && PREC == 0) bl[SET][n] = *reinterpret_cast<const half8*>(bb + F3_PART + off); \
             }                                                                                          \
         }
         F3_BLOAD(0, 0)
@@ -491,8 +519,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int u = 0; u < 36; ++u) {
             const int st = u >> 1, hf = u & 1;
             if (hf == 0) {                                      // weight fragments of step st+5 (may belong to the next chunk)
-                ah[(st + 5) % 6] = *reinterpret_cast<const half8*>(wp + (st + 5) * F3_STEP_BYTES);
-                al[(st + 5) % 6] = *reinterpret_cast<const half8*>(wp + (st + 5) * F3_STEP_BYTES + 1024);
+                ah[(st + 5) % 6] = *reinterpret_cast<const half8*>(wp + (st + 5) * SB);
+                if constexpr (PREC == 0) al[(st + 5) % 6] = *reinterpret_cast<const half8*>(wp + (st + 5) * SB + 1024);
             }
             if (u + 1 < 36) F3_BLOAD(u + 1, (u + 1) & 1)
             if constexpr (FUSED) {
@@ -507,18 +535,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const half8 A_h = ah[st % 6], A_l = al[st % 6];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_l, bh[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
-                if constexpr (!IN16)
-                    acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, bl[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
-                acc[hf * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_h, bh[u & 1][n], acc[hf * 4 + n], 0, 0, 0);
+                if constexpr (PREC == 0) {
+                    acc[hf * 4 + n] = mma32<0>(A_l, bh[u & 1][n], acc[hf * 4 + n]);
+                    if constexpr (!IN16) acc[hf * 4 + n] = mma32<0>(A_h, bl[u & 1][n], acc[hf * 4 + n]);
+                }
+                acc[hf * 4 + n] = mma32<PREC>(A_h, bh[u & 1][n], acc[hf * 4 + n]);
             }
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // one global load
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // a few vector ALU instructions
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // one LDS write
+            for (int i = 0; i < (PREC == 0 ? 12 : 4); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        // one global load
+                __builtin_amdgcn_sched_group_barrier(0x002, PREC == 0 ? 4 : 10, 0);       // a few vector ALU instructions
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        // one LDS write
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -722,13 +751,18 @@ extern "C" int lldwt_plc_fused(const float* parent, float* y, const void* packed
     }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv3_f16x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv3_f16x3<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv3_f16x3<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv3_f16x3<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS) != hipSuccess) {
             set_error("plc_fused: cannot reserve %d bytes of LDS", F1_LDS);
             return LLDWT_EHIP;
         }
         attr_set = true;
     }
     dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)f3_nocb(cout), (unsigned)(planes * batch));
-    hipLaunchKernelGGL(k_conv3_f16x3<2>, grid, dim3(256), F1_LDS, (hipStream_t)stream, a);
+    const int prec = split_precision();
+    if (prec == 1) hipLaunchKernelGGL((k_conv3_f16x3<2, 1>), grid, dim3(256), F1_LDS, (hipStream_t)stream, a);
+    else if (prec == 2) hipLaunchKernelGGL((k_conv3_f16x3<2, 2>), grid, dim3(256), F1_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_conv3_f16x3<2, 0>), grid, dim3(256), F1_LDS, (hipStream_t)stream, a);
     return check_launch("plc_fused");
 }

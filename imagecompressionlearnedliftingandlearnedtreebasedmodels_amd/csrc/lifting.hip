@@ -1479,6 +1479,13 @@ using namespace lldwt;
 
 extern "C" int64_t lldwt_pblock_packed_floats(int C, int K) { return pack_off(C, K).total; }
 
+extern "C" int lldwt_set_precision(int prec) {
+    LLDWT_REQUIRE(prec >= 0 && prec <= 2, "set_precision: %d (0 = f16x3, 1 = fp16, 2 = bf16)", prec);
+    split_set_precision(prec);
+    return LLDWT_OK;
+}
+extern "C" int lldwt_get_precision(void) { return split_precision(); }
+
 extern "C" int lldwt_set_diagnostics(int kind, void* stamps, int64_t nbytes, int flags) {
     LLDWT_REQUIRE(kind >= 0 && kind <= 2, "set_diagnostics: kind %d (0 = fused lifting step, 1 = tree-pair conv, 2 = cgp chain)", kind);
     LLDWT_REQUIRE(nbytes >= 0 && (stamps != nullptr || nbytes == 0), "set_diagnostics: bad buffer");

@@ -20,7 +20,10 @@ constexpr int LF_H_CC = LF_H_C4 + LF_KS4 * LF_FRAG;           // composite fragm
 constexpr int LF_H_END = LF_H_CC + LF_KSC * LF_FRAG;          // 35 * 1024 halves
 // floats after the fragments: [0..3] s_w1..s_w4, [4] s_wc, [16..31] sum over taps of w4[oc], [32..112] Wr[81] = w4 o w1
 constexpr int LF_TAIL_FLOATS = 128;
-constexpr int LF_ORIENT_FLOATS = LF_H_END / 2 + LF_TAIL_FLOATS;
+// behind the tail, in HALVES from the section start: a bf16 copy of the scaled weights, 512 per k-step (the one-product bf16 mode)
+constexpr int LF_H_BF = LF_H_END + 2 * LF_TAIL_FLOATS;
+constexpr int LF_NSTEP = LF_H_END / LF_FRAG;                  // 35 k-steps
+constexpr int LF_ORIENT_FLOATS = (LF_H_BF + LF_NSTEP * 512) / 2;
 constexpr int LF_FLOATS = 2 * LF_ORIENT_FLOATS;               // both orientations
 
 static inline __host__ __device__ int lift_f16_floats(int C, int K) { return (C == LF_C && K == LF_K) ? LF_FLOATS : 0; }
@@ -40,6 +43,10 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
                   hipStream_t st);
 // the same step for TWO independent view sets of the same geometry and parameters in one launch (v2 may be null): images
 // 0 .. Z-1 use v, images Z .. 2Z-1 use *v2
+// arithmetic of the split-fp16 kernel families (lldwt_set_precision): 0 = f16x3 (three products per MAC, fp32-level accuracy),
+// 1 = fp16, 2 = bf16 (one product per MAC).  Defined in lifting_f16.hip, read at launch by conv_f16x3.hip and cgp_f16x3.hip too
+int split_precision();
+void split_set_precision(int p);
 int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int64_t batch, int64_t h, int64_t w,
                    const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical,
                    float sign, float rw, hipStream_t st);

@@ -34,8 +34,46 @@ namespace lldwt {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
+
+// Arithmetic of the 16-channel convolutions (lldwt_set_precision).  PREC 0: split fp16, three MFMA products per fp32 MAC (hi hi +
+// hi lo + lo hi; fp32-level accuracy, the default and what every fp32 parity bar is checked with).  PREC 1 / 2: ONE product per
+// MAC on fp16 / bf16 operands (BASELINE configs[4] "fp16", configs[1] "bf16"; their own tolerance class): the lo images, lo
+// weight fragments and two thirds of the MFMAs are not touched at all.  16-byte fragments travel as half8 whatever they hold.
+template <int PREC>
+__device__ __forceinline__ floatx4 mma1(const half8& a, const half8& b, const floatx4& acc) {
+    if constexpr (PREC == 2)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
+template <int PREC>
+__device__ __forceinline__ floatx4 mma3(const half8& ah, const half8& al, const half8& bh, const half8& bl, floatx4 acc) {
+    if constexpr (PREC == 0) {
+        acc = mma1<0>(al, bh, acc);
+        acc = mma1<0>(ah, bl, acc);
+    }
+    return mma1<PREC>(ah, bh, acc);
+}
+// weight fragments of global k-step `step` (conv1 | conv2 | conv3 | conv4 | composed): hi and lo fp16 in the f16 section, a bf16
+// copy of the (scaled) weights behind the section's tail
+template <int PREC>
+__device__ __forceinline__ void ldA(const _Float16* __restrict__ frag, int step, int lane, half8& h, half8& l) {
+    if constexpr (PREC == 2) {
+        h = *reinterpret_cast<const half8*>(frag + LF_H_BF + step * 512 + lane * 8);
+    } else {
+        h = *reinterpret_cast<const half8*>(frag + step * LF_FRAG + lane * 8);
+        if constexpr (PREC == 0) l = *reinterpret_cast<const half8*>(frag + step * LF_FRAG + 512 + lane * 8);
+    }
+}
+// fp32 -> the 2-byte operand type of PREC (bits): fp16 hi, or bf16
+template <int PREC>
+__device__ __forceinline__ unsigned short to16(float v) {
+    if constexpr (PREC == 2) return __builtin_bit_cast(unsigned short, (__bf16)v);
+    else return __builtin_bit_cast(unsigned short, (_Float16)v);
+}
 
 constexpr int TH = 16, TW = 32, NTH = 512, NWAVE = 8;
 constexpr int SH = TH + 16, SW = TW + 16, NS = SH * SW;              // 32 x 48 skip patch (fp32)
@@ -76,8 +114,7 @@ static_assert(DPIECE_BYTES + T3V_PER * LF_C * 4 <= (N1 - KEEP1 * R1W) * 16, "D q
 static_assert(10 * NTH * 4 <= 4 * T2HALF && 2 * T2HALF == (N2 - KEEP2 * R2W) * 16, "a staging quarter fits half of the dying rows of a T2 array");
 static_assert(4 * T3V_PER >= 4 * R3W + 4 * (TH + 4), "the strip buffer holds every tile's border strips");
 constexpr int LDS_W4L = LDS_TOTAL;                                    // conv4's fp32 weights [tap][channel] (border tiles)
-constexpr int LDS_CORR = LDS_W4L + LF_KK * LF_C * 4;                  // per output pixel: sum of the conv4 taps that fall outside the image
-constexpr int LDS_TOTAL2 = LDS_CORR + TH * TW * 4;                    // 163 008 B
+constexpr int LDS_TOTAL2 = LDS_W4L + LF_KK * LF_C * 4;                // 160 960 B
 static_assert(LDS_TOTAL2 <= 160 * 1024, "one workgroup per CU");
 constexpr float ACT_SCALE = 16384.f;                                  // tanh outputs: |t| <= 1 -> |t * 2^14| < fp16 max
 
@@ -197,6 +234,7 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
         const _Float16 lo = (_Float16)(v - (float)hi);
         hp[(step * 2 + 0) * 512 + lane * 8 + j] = hi;
         hp[(step * 2 + 1) * 512 + lane * 8 + j] = lo;
+        reinterpret_cast<__bf16*>(hp + LF_H_BF)[step * 512 + lane * 8 + j] = (__bf16)v;
     }
     float* tail = dst + LF_H_END / 2;
     if (tid < 4) tail[tid] = sw[tid];
@@ -238,7 +276,7 @@ struct LfArgs {
             (i) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
 
 // 13 k-steps of one 16-pixel tile: B fragments from a T-image (input region width WIN, NIN pixels), A fragments in registers
-template <int WIN, int NIN>
+template <int WIN, int NIN, int PREC = 0>
 __device__ __forceinline__ floatx4 conv16_tile(const uint8_t* __restrict__ img, int basein, bool hi_tap,
                                                const half8 (&ah)[LF_KS], const half8 (&al)[LF_KS]) {
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -250,37 +288,31 @@ __device__ __forceinline__ floatx4 conv16_tile(const uint8_t* __restrict__ img, 
         const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16, offb = ((tb / LF_K) * WIN + tb % LF_K) * 16;
         const int off = basein + (hi_tap ? offb : offa);
         const half8 bh = *reinterpret_cast<const half8*>(img + off);
-        const half8 bl = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + off);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc, 0, 0, 0);
+        half8 bl;
+        if constexpr (PREC == 0) bl = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + off);
+        acc = mma3<PREC>(ah[ks], al[ks], bh, bl, acc);
     }
     return acc;
 }
 
 // the same with the A fragments streamed from memory (L2) k-step by k-step: for the few strip tiles of a border tile, where
 // holding all 26 fragments in registers is not worth their 104 VGPRs
-template <int WIN, int NIN>
+template <int WIN, int NIN, int PREC>
 __device__ __forceinline__ floatx4 conv16_tile_stream(const uint8_t* __restrict__ img, int basein, bool hi_tap,
-                                                      const _Float16* __restrict__ afrag /* + lane * 8 */) {
+                                                      const _Float16* __restrict__ frag, int step0, int lane) {
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
     half8 ah[2], al[2];
-    ah[0] = *reinterpret_cast<const half8*>(afrag);
-    al[0] = *reinterpret_cast<const half8*>(afrag + 512);
+    ldA<PREC>(frag, step0, lane, ah[0], al[0]);
 #pragma unroll
     for (int ks = 0; ks < LF_KS; ++ks) {
-        if (ks + 1 < LF_KS) {
-            ah[(ks + 1) & 1] = *reinterpret_cast<const half8*>(afrag + ((ks + 1) * 2 + 0) * 512);
-            al[(ks + 1) & 1] = *reinterpret_cast<const half8*>(afrag + ((ks + 1) * 2 + 1) * 512);
-        }
+        if (ks + 1 < LF_KS) ldA<PREC>(frag, step0 + ks + 1, lane, ah[(ks + 1) & 1], al[(ks + 1) & 1]);
         const int ta = 2 * ks, tb = (2 * ks + 1) < LF_KK ? 2 * ks + 1 : LF_KK - 1;
         const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16, offb = ((tb / LF_K) * WIN + tb % LF_K) * 16;
         const int off = basein + (hi_tap ? offb : offa);
         const half8 bh = *reinterpret_cast<const half8*>(img + off);
-        const half8 bl = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + off);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks & 1], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks & 1], bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks & 1], bh, acc, 0, 0, 0);
+        half8 bl;
+        if constexpr (PREC == 0) bl = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + off);
+        acc = mma3<PREC>(ah[ks & 1], al[ks & 1], bh, bl, acc);
     }
     return acc;
 }
@@ -289,7 +321,7 @@ __device__ __forceinline__ floatx4 conv16_tile_stream(const uint8_t* __restrict_
 // read from LDS into a second register set BEFORE the 6 MFMAs of k-step ks (the sched_group_barrier sequence pins that
 // order and leaves room for 2 vector instructions of a neighbouring epilogue after every MFMA), so the matrix pipe never
 // waits for an LDS round trip.
-template <int WIN, int NIN, class Piece>
+template <int WIN, int NIN, int PREC, class Piece>
 __device__ __forceinline__ void conv16_tile2(const uint8_t* __restrict__ img, int base0, int base1, bool hi_tap,
                                              const half8 (&ah)[LF_KS], const half8 (&al)[LF_KS], floatx4& acc0, floatx4& acc1,
                                              Piece&& piece) {
@@ -307,9 +339,11 @@ __device__ __forceinline__ void conv16_tile2(const uint8_t* __restrict__ img, in
         const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16;
         const int sel = ks == LF_KS - 1 ? 2 : (ta % LF_K == LF_K - 1 ? 1 : 0);
         bh0[set] = *reinterpret_cast<const half8*>(q0[sel] + offa);
-        bl0[set] = *reinterpret_cast<const half8*>(q0[sel] + 2 * NIN * 16 + offa);
         bh1[set] = *reinterpret_cast<const half8*>(q1[sel] + offa);
-        bl1[set] = *reinterpret_cast<const half8*>(q1[sel] + 2 * NIN * 16 + offa);
+        if constexpr (PREC == 0) {
+            bl0[set] = *reinterpret_cast<const half8*>(q0[sel] + 2 * NIN * 16 + offa);
+            bl1[set] = *reinterpret_cast<const half8*>(q1[sel] + 2 * NIN * 16 + offa);
+        }
     };
     load(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -317,22 +351,34 @@ __device__ __forceinline__ void conv16_tile2(const uint8_t* __restrict__ img, in
     for (int ks = 0; ks < LF_KS; ++ks) {
         const int c = ks & 1;
         if (ks + 1 < LF_KS) load(ks + 1, c ^ 1);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh0[c], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh1[c], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl0[c], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl1[c], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh0[c], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh1[c], acc1, 0, 0, 0);
+        if constexpr (PREC == 0) {
+            acc0 = mma1<0>(al[ks], bh0[c], acc0);
+            acc1 = mma1<0>(al[ks], bh1[c], acc1);
+            acc0 = mma1<0>(ah[ks], bl0[c], acc0);
+            acc1 = mma1<0>(ah[ks], bl1[c], acc1);
+        }
+        acc0 = mma1<PREC>(ah[ks], bh0[c], acc0);
+        acc1 = mma1<PREC>(ah[ks], bh1[c], acc1);
         piece(ks);       // a slice of the PREVIOUS pair's epilogue (vector ALU, LDS stores): runs in the shadow of the MFMAs
         // this k-step is a scheduling region of its own (fenced): its 4 LDS reads can only be the NEXT step's, one after
         // each of the first four MFMAs; the epilogue slice is spread between the MFMAs (two waves of a SIMD otherwise fall
         // into lockstep -- both in their MFMA stretch, then both in their vector stretch -- and the matrix pipe idles)
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+        } else {               // one product: 2 MFMAs and 2 LDS reads per k-step, the same epilogue slice between them
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -340,7 +386,7 @@ __device__ __forceinline__ void conv16_tile2(const uint8_t* __restrict__ img, in
 
 // one tile, same pipeline (a continuing tile has 5 conv2 tiles per wave: two pairs and this one).  A single accumulation chain
 // of this MFMA needs no second accumulator for throughput (MI355X guide); the slice of the previous pair's epilogue rides here
-template <int WIN, int NIN, class Piece>
+template <int WIN, int NIN, int PREC, class Piece>
 __device__ __forceinline__ void conv16_tile1(const uint8_t* __restrict__ img, int base0, bool hi_tap, const half8 (&ah)[LF_KS],
                                              const half8 (&al)[LF_KS], floatx4& acc0, Piece&& piece) {
     acc0 = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -352,7 +398,7 @@ __device__ __forceinline__ void conv16_tile1(const uint8_t* __restrict__ img, in
         const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16;
         const int sel = ks == LF_KS - 1 ? 2 : (ta % LF_K == LF_K - 1 ? 1 : 0);
         bh0[set] = *reinterpret_cast<const half8*>(q0[sel] + offa);
-        bl0[set] = *reinterpret_cast<const half8*>(q0[sel] + 2 * NIN * 16 + offa);
+        if constexpr (PREC == 0) bl0[set] = *reinterpret_cast<const half8*>(q0[sel] + 2 * NIN * 16 + offa);
     };
     load(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -360,16 +406,16 @@ __device__ __forceinline__ void conv16_tile1(const uint8_t* __restrict__ img, in
     for (int ks = 0; ks < LF_KS; ++ks) {
         const int c = ks & 1;
         if (ks + 1 < LF_KS) load(ks + 1, c ^ 1);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh0[c], acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl0[c], acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh0[c], acc0, 0, 0, 0);
+        acc0 = mma3<PREC>(ah[ks], al[ks], bh0[c], bl0[c], acc0);
         piece(ks);
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            if (i == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            for (int i = 0; i < 3; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if (i == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -389,6 +435,7 @@ __device__ __forceinline__ void interleave_hint() {
 
 // conv1 of one 16-pixel tile: this lane's 8 k values = 4 aligned fp16 pairs of the scaled skip patch (see the header), 3 MFMAs.
 // sbase = element index of the tile pixel's top-left tap in the patch; kgoff = {kg * SW, 4 * SW + 2 * min(kg, 2)} (elements)
+template <int PREC = 0>
 __device__ __forceinline__ floatx4 conv1_tile(const uint8_t* __restrict__ s16, int sbase, int kgoff0, int kgoff1,
                                               const half8& a1h, const half8& a1l) {
     typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
@@ -401,26 +448,39 @@ __device__ __forceinline__ floatx4 conv1_tile(const uint8_t* __restrict__ s16, i
     uh[1] = *reinterpret_cast<const unsigned*>(r0 + 4);
     uh[2] = *reinterpret_cast<const unsigned*>(r0 + 8);
     uh[3] = *reinterpret_cast<const unsigned*>(r1);
-    ul[0] = *reinterpret_cast<const unsigned*>(r0 + NS16 * 2);
-    ul[1] = *reinterpret_cast<const unsigned*>(r0 + NS16 * 2 + 4);
-    ul[2] = *reinterpret_cast<const unsigned*>(r0 + NS16 * 2 + 8);
-    ul[3] = *reinterpret_cast<const unsigned*>(r1 + NS16 * 2);
+    if constexpr (PREC == 0) {
+        ul[0] = *reinterpret_cast<const unsigned*>(r0 + NS16 * 2);
+        ul[1] = *reinterpret_cast<const unsigned*>(r0 + NS16 * 2 + 4);
+        ul[2] = *reinterpret_cast<const unsigned*>(r0 + NS16 * 2 + 8);
+        ul[3] = *reinterpret_cast<const unsigned*>(r1 + NS16 * 2);
+    }
     const half8 bh = __builtin_bit_cast(half8, uh), bl = __builtin_bit_cast(half8, ul);
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bh, acc, 0, 0, 0);
-    return acc;
+    return mma3<PREC>(a1h, a1l, bh, bl, acc);
 }
 
-// store 4 consecutive channels (oc0 .. oc0+3) of pixel p into a T-image of N pixels
-template <int N>
+// store 4 consecutive channels (oc0 .. oc0+3) of pixel p into a T-image of N pixels (one-product modes: the hi image only,
+// as fp16 or bf16)
+template <int N, int PREC = 0>
 __device__ __forceinline__ void timg_store(uint8_t* __restrict__ img, int p, int oc0, const float (&v)[4]) {
-    half4 hi, lo;
-    split4(v, hi, lo);
     uint8_t* d = img + (oc0 >> 3) * (N * 16) + p * 16 + (oc0 & 7) * 2;
-    *reinterpret_cast<half4*>(d) = hi;
-    *reinterpret_cast<half4*>(d + 2 * N * 16) = lo;
+    if constexpr (PREC == 0) {
+        half4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<half4*>(d) = hi;
+        *reinterpret_cast<half4*>(d + 2 * N * 16) = lo;
+    } else if constexpr (PREC == 1) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 a = __builtin_convertvector((f2){v[0], v[1]}, h2), b = __builtin_convertvector((f2){v[2], v[3]}, h2);
+        *reinterpret_cast<half4*>(d) = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+    } else {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        const b2 a = __builtin_convertvector((f2){v[0], v[1]}, b2), b = __builtin_convertvector((f2){v[2], v[3]}, b2);
+        *reinterpret_cast<b4*>(d) = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+    }
 }
 
 // raw operands of one tile's skip patch (this thread's three patch elements: centre and the two filter neighbours) and its
@@ -433,8 +493,11 @@ struct LfPre {
 // PERSISTENT: one workgroup per CU (155 KB of LDS) walks over tiles t = blockIdx.x, + gridDim.x, ...  The position of a
 // tile inside its image is rotated by the image index, so that a workgroup does not meet the (slower) border tiles of
 // every image.
-template <bool SEQ>      // SEQ: the sequential evaluation of conv3 / conv4 for every tile (LLDWT_LF_DBG bit 16), the check of the composed path
+// SEQ: the sequential evaluation of conv3 / conv4 for every tile (debug flag 16), the check of the composed path.
+// PREC: 0 = f16x3, 1 = fp16, 2 = bf16 (see mma3)
+template <bool SEQ, int PREC>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lift_fused_f16(LfArgs a) {
+    static_assert(!SEQ || PREC == 0, "the sequential check path exists for the fp32-accurate arithmetic only");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* S = reinterpret_cast<float*>(lds + LDS_S);
     float* RED = reinterpret_cast<float*>(lds + LDS_RED);
@@ -551,7 +614,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // disjoint, the destinations are dead since the barrier that ended the tile above; P1 / P2 read them two barriers later)
     if (cont) {
         typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
-        constexpr int MV1 = 4 * KEEP1 * R1W, MV2 = 4 * KEEP2 * R2W;                   // 16-byte pieces: 2112, 1280
+        constexpr int NARR = PREC == 0 ? 4 : 2;                                       // one product: the two hi arrays only
+        constexpr int MV1 = NARR * KEEP1 * R1W, MV2 = NARR * KEEP2 * R2W;             // 16-byte pieces: 2112, 1280
 #pragma unroll
         for (int k = 0; k < (MV1 + NTH - 1) / NTH; ++k) {
             const int c = tid + k * NTH, arr = c / (KEEP1 * R1W), px = c - arr * (KEEP1 * R1W);
@@ -612,13 +676,20 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int k = 0; k < NS / NTH; ++k) {
             const int i = tid + k * NTH;
             const float v = sv[k] * s_skip;
-            const _Float16 hi = (_Float16)v;
-            const _Float16 lo = (_Float16)(v - (float)hi);
-            h0[i] = hi;
-            h0[NS16 + i] = lo;
-            if (i > 0) {
-                h0[2 * NS16 + i - 1] = hi;
-                h0[3 * NS16 + i - 1] = lo;
+            if constexpr (PREC == 0) {
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                h0[i] = hi;
+                h0[NS16 + i] = lo;
+                if (i > 0) {
+                    h0[2 * NS16 + i - 1] = hi;
+                    h0[3 * NS16 + i - 1] = lo;
+                }
+            } else {                                        // one product: the hi image only, fp16 or bf16 bits
+                const unsigned short hb = to16<PREC>(v);
+                unsigned short* u0 = reinterpret_cast<unsigned short*>(h0);
+                u0[i] = hb;
+                if (i > 0) u0[2 * NS16 + i - 1] = hb;
             }
         }
         if (tid < 4 * 49) {                                                   // tails: finite values against zero weights
@@ -631,8 +702,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // conv1 operands: element offsets of this lane group's pairs inside the patch (conv1_tile)
     const uint8_t* s16 = lds + LDS_S16;
     const int kgoff0 = kg * SW, kgoff1 = 4 * SW + 2 * (kg < 2 ? kg : 2);
-    const half8 a1h = *reinterpret_cast<const half8*>(frag + LF_H_C1 + lane * 8);
-    const half8 a1l = *reinterpret_cast<const half8*>(frag + LF_H_C1 + 512 + lane * 8);
+    half8 a1h, a1l;
+    ldA<PREC>(frag, LF_H_C1 / LF_FRAG, lane, a1h, a1l);
     float b1v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) b1v[q] = bias[a.b1 + oc0 + q];
@@ -658,7 +729,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int tile = wave + (2 * it + t) * NWAVE;
                 const int p = (tb1 + (tile < nt1 ? tile : nt1 - 1)) * 16 + pl;
                 const int r = p / R1W, c = p - r * R1W;
-                acc[t] = conv1_tile(s16, r * SW + c, kgoff0, kgoff1, a1h, a1l);
+                acc[t] = conv1_tile<PREC>(s16, r * SW + c, kgoff0, kgoff1, a1h, a1l);
                 const int gy = y0 - 6 + r, gx = x0 - 6 + c;
                 msk[t] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? ACT_SCALE : 0.f;
                 pq[t] = p;
@@ -668,7 +739,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = tanh_scaled(acc[t][q], inv1c, b1c[q]) * msk[t];
-                timg_store<N1>(lds + LDS_T1, pq[t], oc0, v);
+                timg_store<N1, PREC>(lds + LDS_T1, pq[t], oc0, v);
             }
         }
     }
@@ -680,10 +751,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
         half8 ah[LF_KS], al[LF_KS];
 #pragma unroll
-        for (int ks = 0; ks < LF_KS; ++ks) {
-            ah[ks] = *reinterpret_cast<const half8*>(frag + LF_H_C2 + (ks * 2 + 0) * 512 + lane * 8);
-            al[ks] = *reinterpret_cast<const half8*>(frag + LF_H_C2 + (ks * 2 + 1) * 512 + lane * 8);
-        }
+        for (int ks = 0; ks < LF_KS; ++ks) ldA<PREC>(frag, LF_H_C2 / LF_FRAG + ks, lane, ah[ks], al[ks]);
         float bv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = bias[a.b2 + oc0 + q];
@@ -724,13 +792,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             } else if (ks < 10) {
                 const int t = ks - 8;
                 const float v[4] = {ev[4 * t], ev[4 * t + 1], ev[4 * t + 2], ev[4 * t + 3]};
-                timg_store<N2>(lds + LDS_T2, pp[t], oc0, v);
+                timg_store<N2, PREC>(lds + LDS_T2, pp[t], oc0, v);
             }
         };
         if (!(a.dbg & 2)) {
             {
                 const int b0 = tile_base(wave, pp[0]), b1 = tile_base(wave + NWAVE, pp[1]);
-                conv16_tile2<R1W, N1>(lds + LDS_T1, b0, b1, hi_tap, ah, al, pc[0], pc[1], [](int) {});
+                conv16_tile2<R1W, N1, PREC>(lds + LDS_T1, b0, b1, hi_tap, ah, al, pc[0], pc[1], [](int) {});
                 pin[0] = in_image(pp[0]);
                 pin[1] = in_image(pp[1]);
             }
@@ -739,7 +807,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 floatx4 n0, n1;
                 int q0, q1;
                 const int b0 = tile_base(wave + 16 * it, q0), b1 = tile_base(wave + 16 * it + NWAVE, q1);
-                conv16_tile2<R1W, N1>(lds + LDS_T1, b0, b1, hi_tap, ah, al, n0, n1, slice);
+                conv16_tile2<R1W, N1, PREC>(lds + LDS_T1, b0, b1, hi_tap, ah, al, n0, n1, slice);
                 pc[0] = n0; pc[1] = n1; pp[0] = q0; pp[1] = q1;
                 pin[0] = in_image(q0);
                 pin[1] = in_image(q1);
@@ -748,12 +816,12 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 floatx4 n0;
                 int q0;
                 const int b0 = tile_base(wave + 4 * NWAVE, q0);
-                conv16_tile1<R1W, N1>(lds + LDS_T1, b0, hi_tap, ah, al, n0, slice);
+                conv16_tile1<R1W, N1, PREC>(lds + LDS_T1, b0, hi_tap, ah, al, n0, slice);
                 const float pin0 = in_image(q0);
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = tanh_scaled(n0[q], inv2c, bvc[q]) * pin0;
-                timg_store<N2>(lds + LDS_T2, q0, oc0, v);
+                timg_store<N2, PREC>(lds + LDS_T2, q0, oc0, v);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 10; ++ks) slice(ks);
@@ -804,14 +872,12 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             return reinterpret_cast<float*>(lds + LDS_T1 + k * T1A + DPIECE_BYTES) + (j - k * T3V_PER) * LF_C;
         };
         float* W4L = reinterpret_cast<float*>(lds + LDS_W4L);   // conv4's fp32 weights as [tap][channel]
-        float* CORR = reinterpret_cast<float*>(lds + LDS_CORR);
         const bool more = next_item < a.nitems;
         LfPre nxt;
         if (!interior) {                                        // before the composite loop: what it needs from P1 dies here
             if (tid < LF_C * LF_KK) W4L[(tid % LF_KK) * LF_C + tid / LF_KK] = bias[a.w4 + tid];
-            CORR[tid] = 0.f;
-            const half8 c1h = *reinterpret_cast<const half8*>(frag + LF_H_C1 + lane * 8);
-            const half8 c1l = *reinterpret_cast<const half8*>(frag + LF_H_C1 + 512 + lane * 8);
+            half8 c1h, c1l;
+            ldA<PREC>(frag, LF_H_C1 / LF_FRAG, lane, c1h, c1l);
             float bv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) bv[q] = bias[a.b3 + oc0 + q] + bias[a.b1 + oc0 + q];
@@ -828,9 +894,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     r = q - ic * (TH + 4);
                     c = ic == 0 ? Cl0 : ic == 1 ? Cl1 : ic == 2 ? Cl2 : Cl3;
                 }
-                const floatx4 acc = conv16_tile_stream<R2W, N2>(lds + LDS_T2, (r * R2W + c) * 16 + halfsel * (N2 * 16), hi_tap,
-                                                                frag + LF_H_C3 + lane * 8);
-                const floatx4 accr = conv1_tile(s16, (r + 4) * SW + c + 4, kgoff0, kgoff1, c1h, c1l);
+                const floatx4 acc = conv16_tile_stream<R2W, N2, PREC>(lds + LDS_T2, (r * R2W + c) * 16 + halfsel * (N2 * 16), hi_tap,
+                                                                      frag, LF_H_C3 / LF_FRAG, lane);
+                const floatx4 accr = conv1_tile<PREC>(s16, (r + 4) * SW + c + 4, kgoff0, kgoff1, c1h, c1l);
                 floatx4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = acc[q] * inv3 + accr[q] * inv1 + bv[q];
@@ -841,10 +907,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             half8 ah[LF_KSC], al[LF_KSC];
 #pragma unroll
-            for (int ks = 0; ks < LF_KSC; ++ks) {
-                ah[ks] = *reinterpret_cast<const half8*>(frag + LF_H_CC + (ks * 2 + 0) * 512 + lane * 8);
-                al[ks] = *reinterpret_cast<const half8*>(frag + LF_H_CC + (ks * 2 + 1) * 512 + lane * 8);
-            }
+            for (int ks = 0; ks < LF_KSC; ++ks) ldA<PREC>(frag, LF_H_CC / LF_FRAG + ks, lane, ah[ks], al[ks]);
             // operands of the NEXT tile of this workgroup: issued here, in flight during the composite loop (~2 us of matrix
             // work, an HBM round trip under load), staged in LDS at the tile's end (issued behind the loop they were waited for
             // at full latency).  AFTER the weight fragments: vmcnt retires in order, so a wait for a younger L2 hit would
@@ -870,10 +933,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int dya = 2 * ks, dyb = 2 * ks + 1 < 9 ? 2 * ks + 1 : 8;            // dy 9 does not exist: weight 0
                     const int off = basein + (hi_tap ? dyb : dya) * (R2W * 16);
                     const half8 bh = *reinterpret_cast<const half8*>(img + off);
-                    const half8 bl = *reinterpret_cast<const half8*>(img + 2 * N2 * 16 + off);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc, 0, 0, 0);
+                    half8 bl;
+                    if constexpr (PREC == 0) bl = *reinterpret_cast<const half8*>(img + 2 * N2 * 16 + off);
+                    acc = mma3<PREC>(ah[ks], al[ks], bh, bl, acc);
                 }
                 // rows = dx: lanes kg 0 hold dx 0-3, kg 1 dx 4-7, kg 2 dx 8 (register 0)
                 float* dq = Dp(p);
@@ -882,51 +944,16 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int j = 17 * it; j < 17 * it + 17 && j < 81; ++j) rs += tail[32 + j] * Sc[(j / 9) * SW + j % 9];
 #pragma unroll
-                for (int i = 0; i < 15; ++i) {
+                for (int i = 0; i < (PREC == 0 ? 15 : 5); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, PREC == 0 ? 2 : 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, PREC == 0 ? 2 : 5, 0);
                 }
             }
         }
         LF_STAMP(7)
         __syncthreads();
         LF_STAMP(8)
-        if (!interior) {
-            // SCATTER of the correction: strip position (r, c) and conv4 tap (dy, dx) -> output pixel (r - dy, c - dx) of this tile,
-            // u = sum_oc w4[oc][tap] * t3v[position][oc] added to that pixel's CORR (LDS float add); dense over (position, tap)
-            // items, no per-pixel gather.  A column-strip position whose row is also outside the image belongs to the row strip.
-            for (int i = tid; i < nF * LF_KK; i += NTH) {
-                const int pos = i / LF_KK, tap = i - pos * LF_KK;
-                const int dy = tap / LF_K, dx = tap - dy * LF_K;
-                int r, c;
-                bool dup = false;
-                if (pos < nR * R3W) {
-                    const int ir = pos / R3W;
-                    c = pos - ir * R3W;
-                    r = ir == 0 ? Rl0 : ir == 1 ? Rl1 : ir == 2 ? Rl2 : Rl3;
-                } else {
-                    const int q = pos - nR * R3W, ic = q / (TH + 4);
-                    r = q - ic * (TH + 4);
-                    c = ic == 0 ? Cl0 : ic == 1 ? Cl1 : ic == 2 ? Cl2 : Cl3;
-                    const int gyy = y0 - 2 + r;
-                    dup = gyy < 0 || gyy >= h;
-                }
-                const int oy = r - dy, ox = c - dx;
-                if (!dup && oy >= 0 && oy < TH && ox >= 0 && ox < TW) {
-                    const floatx4* tv = reinterpret_cast<const floatx4*>(T3Vp(pos));
-                    const floatx4* wv = reinterpret_cast<const floatx4*>(W4L + tap * LF_C);
-                    float u = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const floatx4 t = tv[q], ww = wv[q];
-                        u += t[0] * ww[0] + t[1] * ww[1] + t[2] * ww[2] + t[3] * ww[3];
-                    }
-                    __hip_atomic_fetch_add(CORR + oy * TW + ox, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-            __syncthreads();
-        }
         {
             const int oy = tid / TW, ox = tid - oy * TW;
             const int gy = y0 + oy, gx = x0 + ox;
@@ -941,7 +968,35 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int oc = 0; oc < LF_C; ++oc) cst += (bias[a.b3 + oc] + bias[a.b1 + oc]) * tail[16 + oc];
             net += rs + cst;
             const bool valid = gy < h && gx < w;
-            if (!interior) net -= CORR[tid];    // the conv4 taps of this pixel that land outside the image
+            if (!interior && (gy < 2 || gy >= h - 2 || gx < 2 || gx >= w - 2)) {
+                // the conv4 taps of this pixel that land outside the image: sum_oc w4[oc][tap] * t3v[position][oc], straight from the
+                // strips' t3v (a fixed summation order: results do not depend on scheduling).  Only pixels within two of an image
+                // edge come here; a position outside in both directions belongs to the row strip.
+                float corr = 0.f;
+                for (int dy = 0; dy < LF_K; ++dy) {
+                    const int r = oy + dy, gyy = gy - 2 + dy;
+                    const bool rowout = gyy < 0 || gyy >= h;
+                    const int ir = r == Rl0 ? 0 : r == Rl1 ? 1 : r == Rl2 ? 2 : 3;
+                    for (int dx = 0; dx < LF_K; ++dx) {
+                        const int c = ox + dx, gxx = gx - 2 + dx;
+                        const bool colout = gxx < 0 || gxx >= w;
+                        if (rowout || colout) {
+                            const int ic = c == Cl0 ? 0 : c == Cl1 ? 1 : c == Cl2 ? 2 : 3;
+                            const int j = rowout ? ir * R3W + c : nR * R3W + ic * (TH + 4) + r;
+                            const floatx4* tv = reinterpret_cast<const floatx4*>(T3Vp(j));
+                            const floatx4* wv = reinterpret_cast<const floatx4*>(W4L + (dy * LF_K + dx) * LF_C);
+                            float u = 0.f;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const floatx4 t = tv[q], ww = wv[q];
+                                u += t[0] * ww[0] + t[1] * ww[1] + t[2] * ww[2] + t[3] * ww[3];
+                            }
+                            corr += u;
+                        }
+                    }
+                }
+                net -= corr;
+            }
             const float skip = S[(oy + 8) * SW + ox + 8];
             const float din = din_pre;
             if (valid)
@@ -960,10 +1015,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
         half8 ah[LF_KS], al[LF_KS];
 #pragma unroll
-        for (int ks = 0; ks < LF_KS; ++ks) {
-            ah[ks] = *reinterpret_cast<const half8*>(frag + LF_H_C3 + (ks * 2 + 0) * 512 + lane * 8);
-            al[ks] = *reinterpret_cast<const half8*>(frag + LF_H_C3 + (ks * 2 + 1) * 512 + lane * 8);
-        }
+        for (int ks = 0; ks < LF_KS; ++ks) ldA<0>(frag, LF_H_C3 / LF_FRAG + ks, lane, ah[ks], al[ks]);
         float bv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = bias[a.b3 + oc0 + q] + b1v[q];
@@ -1021,10 +1073,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
         half8 ah[LF_KS4], al[LF_KS4];
 #pragma unroll
-        for (int ks = 0; ks < LF_KS4; ++ks) {
-            ah[ks] = *reinterpret_cast<const half8*>(frag + LF_H_C4 + (ks * 2 + 0) * 512 + lane * 8);
-            al[ks] = *reinterpret_cast<const half8*>(frag + LF_H_C4 + (ks * 2 + 1) * 512 + lane * 8);
-        }
+        for (int ks = 0; ks < LF_KS4; ++ks) ldA<0>(frag, LF_H_C4 / LF_FRAG + ks, lane, ah[ks], al[ks]);
         float* D = reinterpret_cast<float*>(lds + LDS_D);
         const uint8_t* img = lds + LDS_T3;
         for (int tile = wave; tile < ((a.dbg & 8) ? 0 : NTD); tile += NWAVE) {
@@ -1038,9 +1087,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int off = basein + (hi_tap ? dyb : dya) * (R3W * 16);
                 const half8 bh = *reinterpret_cast<const half8*>(img + off);
                 const half8 bl = *reinterpret_cast<const half8*>(img + 2 * N3 * 16 + off);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc, 0, 0, 0);
+                acc = mma3<0>(ah[ks], al[ks], bh, bl, acc);
             }
             // D rows = dx: lanes kg == 0 hold dx 0..3, lanes kg == 1 hold dx 4 in register 0
             if (kg == 0) *reinterpret_cast<floatx4*>(D + p * 8) = acc;
@@ -1085,6 +1132,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 static int g_lf_dbg = [] { const char* e = getenv("LLDWT_LF_DBG"); return e ? atoi(e) : 0; }();
 static unsigned long long* g_lf_stamps = nullptr;
 static int64_t g_lf_stamps_bytes = 0;
+static int g_precision = 0;
+int split_precision() { return g_precision; }
+void split_set_precision(int p) { g_precision = p; }
 void lift_f16_set_debug(int dbg) { g_lf_dbg = dbg; }
 void lift_f16_set_stamps(void* p, int64_t nbytes) { g_lf_stamps = reinterpret_cast<unsigned long long*>(p); g_lf_stamps_bytes = p ? nbytes : 0; }
 
@@ -1105,8 +1155,10 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
                    float sign, float rw, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_lift_fused_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_lift_fused_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_lift_fused_f16<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_lift_fused_f16<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_lift_fused_f16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_lift_fused_f16<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess) {
             set_error("lift_f16_step: cannot reserve %d bytes of LDS", LDS_TOTAL2);
             return LLDWT_EHIP;
         }
@@ -1181,8 +1233,11 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
     a.nseg = (int)cdiv(a.tiles_y, a.rl);
     a.nitems = (int)(Zl * a.tiles_x * a.nseg);
     const unsigned grid = (unsigned)(a.nitems < ncu ? a.nitems : ncu);      // one resident workgroup per CU
-    if (seq) hipLaunchKernelGGL(k_lift_fused_f16<true>, dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
-    else hipLaunchKernelGGL(k_lift_fused_f16<false>, dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
+    const int prec = seq ? 0 : g_precision;
+    if (seq) hipLaunchKernelGGL((k_lift_fused_f16<true, 0>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
+    else if (prec == 1) hipLaunchKernelGGL((k_lift_fused_f16<false, 1>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
+    else if (prec == 2) hipLaunchKernelGGL((k_lift_fused_f16<false, 2>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
+    else hipLaunchKernelGGL((k_lift_fused_f16<false, 0>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
     return check_launch("lift_f16_step");
 }
 

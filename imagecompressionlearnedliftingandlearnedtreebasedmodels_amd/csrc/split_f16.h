@@ -43,4 +43,25 @@ __device__ __forceinline__ void split8v(const float (&v)[8], h8_t& hi, h8_t& lo)
     lo = __builtin_shufflevector(b, d, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// ---- the one-product modes (lldwt_set_precision 1 = fp16, 2 = bf16): 16-byte fragments travel as h8_t whatever they hold
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef float f16_t __attribute__((ext_vector_type(16)));
+
+// one MFMA product of the 32x32x16 shape on fp16 (PREC 0, 1) or bf16 (PREC 2) operands
+template <int PREC>
+__device__ __forceinline__ f16_t mma32(const h8_t& a, const h8_t& b, const f16_t& acc) {
+    if constexpr (PREC == 2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+// 8 fp32 values -> 8 fp16 (PREC 1) or bf16 (PREC 2) operands, round to nearest
+template <int PREC>
+__device__ __forceinline__ h8_t cvt8(const float (&v)[8]) {
+    typedef float f8 __attribute__((ext_vector_type(8)));
+    const f8 x = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    if constexpr (PREC == 2) return __builtin_bit_cast(h8_t, __builtin_convertvector(x, bf8_t));
+    else return __builtin_convertvector(x, h8_t);
+}
+
 }  // namespace lldwt

@@ -28,6 +28,21 @@ def plc_mode():
     return m
 
 
+def set_precision(name):
+    """Arithmetic of the eval path's matrix kernels (fused lifting step, tree-context pair, cgp chain): 'f16x3' (default: three
+    fp16 MFMA products per fp32 MAC, fp32-level accuracy), 'fp16' or 'bf16' (ONE product per MAC on operands rounded to that
+    type, fp32 accumulate; BASELINE configs[4] / configs[1], tolerance class 1e-2 -- never the headline).  Also settable with
+    the environment variable LLDWT_PRECISION before the library is loaded.  Training is not affected."""
+    if name not in _lib.PRECISIONS:
+        raise _lib.LLDWTError("precision must be one of %s (got %r)" % (sorted(_lib.PRECISIONS), name))
+    check(_lib.load().lldwt_set_precision(_lib.PRECISIONS[name]), "lldwt_set_precision")
+
+
+def get_precision():
+    code = _lib.load().lldwt_get_precision()
+    return [k for k, v in _lib.PRECISIONS.items() if v == code][0]
+
+
 _diag_keep = {}
 
 

@@ -79,6 +79,15 @@ int64_t lldwt_pblock_packed_floats(int C, int K);
  * launch per step with the 16 -> 16 convolutions on the fp16 matrix cores, split-fp16 operands, intermediates in LDS
  * (csrc/lifting_f16.hip); 0 = the three fp32-MFMA launches (exact fp32 products; also what training uses).       */
 int lldwt_set_lift_mode(int mode);
+/* Arithmetic of the split-fp16 kernel families on the EVAL path (fused lifting step, tree-context pair, cgp chain):
+ *   0 (default) = f16x3: every fp32 MAC is three fp16 MFMA products (hi hi + hi lo + lo hi), fp32 accumulate: fp32-level
+ *                 accuracy; every parity bar against the fp32 reference is stated for this mode;
+ *   1 = fp16, 2 = bf16: ONE MFMA product per MAC on operands rounded to fp16 / bf16 (fp32 accumulate, fp32 tensors in HBM,
+ *                 biases / activations / rate arithmetic in fp32).  BASELINE configs[4] ("fp16") and configs[1] ("bf16");
+ *                 their own tolerance class (<= 1e-2 relative on coefficients and summed bits), never the headline.
+ * The reference itself is fp32-only (graphs/layers/wavelet_inverse_v2.py:49-51).  Training always runs f16x3 / fp32.   */
+int lldwt_set_precision(int prec);
+int lldwt_get_precision(void);
 /* Diagnostics hook of the three split-fp16 kernel families (tools/lift_stamps.py, plc_stamps.py, cgp_stamps.py; the
  * product never calls it).  kind 0 = fused lifting step, 1 = tree-pair conv, 2 = cgp chain.  stamps / nbytes: a device
  * buffer the kernels of that kind write s_memtime stamps into (null = off); a launch whose stamps would not fit in
