@@ -150,6 +150,16 @@ struct Cgp16Args {
     int ntaps;
     int tap_dy[25], tap_dx[25];
     int cols;              // 64-pixel columns per image
+    // ---- wavefront mode (real entropy coding, lldwt_cgp16_wavefront_step): the pixels of ONE anti-diagonal step t = x + slope * y
+    // instead of a whole image; xq is the (Z, groups, h, w) tensor of values decoded so far (0 where not yet coded)
+    int wf_t, wf_slope, wf_y0, wf_n;      // step, slope (K/2 + 1), first row of the step, pixels of the step
+    const float* wf_y;                    // encoder: the coefficients (Z, groups, h, w); decoder: null
+    float* wf_yhat;                       // encoder: == xq, receives symbol + mu at the step's pixels
+    const float* wf_table;                // the scale table's first 63 entries (CDF index = number of entries < max(sigma, 0.11))
+    int* wf_idx;                          // (Z, ntot, groups) CDF indexes in wavefront order; this step starts at wf_off
+    int* wf_sym;                          // encoder: symbols, same layout
+    float* wf_mu;                         // decoder: (Z, groups, wf_n) means of this step
+    int64_t wf_ntot, wf_off;
     unsigned long long* stamps;   // diagnostics only (lldwt_set_diagnostics kind 2): [z][group][column][8] s_memtime stamps
 };
 #define CGP_STAMP(i)                                                                                                    \
@@ -184,7 +194,9 @@ __device__ __forceinline__ void next_frags(const floatx16& acc, float k, const f
 }
 
 // PREC (lldwt_set_precision): 0 = three MFMA products per MAC (split fp16), 1 / 2 = one product on fp16 / bf16 operands
-template <int PREC>
+// WF: one wavefront step of the real entropy coder (see Cgp16Args): the pixel list is the step's anti-diagonal and the epilogue
+// turns (sigma, mu) into CDF index + symbol + dequantised value (LiftingBasedDWT_net.py:458-506: compress_ar's per-pixel work)
+template <int PREC, bool WF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cgp16(Cgp16Args a) {
     constexpr int SB = PREC == 2 ? STEP_BYTES / 2 : STEP_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -214,11 +226,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float amax = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int64_t p = (int64_t)col * (32 * NB) + nb * 32 + pl;
-        valid[nb] = p < hw;
-        const int pc = (int)(valid[nb] ? p : hw - 1);
+        int pc, y, x;
+        if constexpr (WF) {
+            const int i = col * (32 * NB) + nb * 32 + pl;
+            valid[nb] = i < a.wf_n;
+            y = a.wf_y0 + (valid[nb] ? i : 0);
+            x = a.wf_t - a.wf_slope * y;
+            pc = y * a.w + x;
+        } else {
+            const int64_t p = (int64_t)col * (32 * NB) + nb * 32 + pl;
+            valid[nb] = p < hw;
+            pc = (int)(valid[nb] ? p : hw - 1);
+            y = pc / a.w;
+            x = pc - y * a.w;
+        }
         pix[nb] = pc;
-        const int y = pc / a.w, x = pc - y * a.w;
 #pragma unroll
         for (int k = 0; k < NK0; ++k) {
 #pragma unroll
@@ -385,7 +407,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef CGP16_MMA
     CGP_STAMP(4)
     // ---- rows 0 (sigma) and 1 (mu) of the last tile: registers 0, 1 of the lanes with h == 0
-    if (h5 == 0) {
+    if constexpr (WF) {
+        if (h5 == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                if (valid[nb]) {
+                    const float sigma = acc3[nb][0] * inv3 + bias3[0], mu = acc3[nb][1] * inv3 + bias3[1];
+                    const float sb = fmaxf(sigma, 0.11f);                         // GaussianConditional's scale bound (:32-33)
+                    int idx = 0;
+                    for (int k = 0; k < 63; ++k) idx += a.wf_table[k] < sb ? 1 : 0;   // build_indexes
+                    const int i = col * (32 * NB) + nb * 32 + pl;
+                    const int64_t o = (z * a.wf_ntot + a.wf_off + i) * a.groups + g;
+                    a.wf_idx[o] = idx;
+                    if (a.wf_y) {                                                 // encoder: symbol = round(y - mu), value = symbol + mu
+                        const int64_t e = (z * a.groups + g) * hw + pix[nb];
+                        const int sym = (int)rintf(a.wf_y[e] - mu);
+                        a.wf_sym[o] = sym;
+                        a.wf_yhat[e] = (float)sym + mu;
+                    } else {
+                        a.wf_mu[(z * a.groups + g) * a.wf_n + i] = mu;
+                    }
+                }
+        }
+    } else if (h5 == 0) {
         float* out = a.params + (z * 2 * a.groups + 2 * g) * hw;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -448,8 +492,76 @@ extern "C" int lldwt_cgp16_params(const float* plc, const float* xq, const void*
     }
     dim3 grid((unsigned)cdiv(a.cols, 4), (unsigned)groups, (unsigned)(planes * batch));
     const int prec = split_precision();
-    if (prec == 1) hipLaunchKernelGGL(k_cgp16<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (prec == 2) hipLaunchKernelGGL(k_cgp16<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_cgp16<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (prec == 1) hipLaunchKernelGGL((k_cgp16<1, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (prec == 2) hipLaunchKernelGGL((k_cgp16<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_cgp16<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("cgp16_params");
+}
+
+// the decoder's second half of a wavefront step: yhat[pixel] = symbol + mu
+__global__ void k_wf_apply(const int* __restrict__ sym, const float* __restrict__ mu, float* __restrict__ yhat, int groups, int h,
+                           int w, int t, int slope, int y0, int n, int64_t ntot, int64_t off) {
+    const int64_t z = blockIdx.z;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int y = y0 + i, x = t - slope * y;
+    yhat[(z * groups + g) * (int64_t)h * w + (int64_t)y * w + x] = (float)sym[(z * ntot + off + i) * groups + g] + mu[(z * groups + g) * n + i];
+}
+
+// pixels of wavefront step t: rows y0 .. y0 + n - 1 with x = t - slope * y inside [0, w)
+static inline void wf_range(int t, int slope, int h, int w, int& y0, int& n) {
+    int lo = t - (w - 1);
+    lo = lo <= 0 ? 0 : (lo + slope - 1) / slope;
+    int hi = t / slope;
+    if (hi > h - 1) hi = h - 1;
+    y0 = lo;
+    n = hi >= lo ? hi - lo + 1 : 0;
+}
+
+extern "C" int lldwt_cgp16_wavefront_step(const float* plc, float* yhat, const float* y, const void* packed, const float* table63,
+                                          int* idx, int* sym, float* mu, int64_t planes, int64_t batch, int64_t h, int64_t w_,
+                                          int groups, int K, uint32_t tap_mask, int t, int64_t ntot, int64_t off, void* stream) {
+    LLDWT_REQUIRE(plc && yhat && packed && table63 && idx && (y ? sym != nullptr : mu != nullptr), "cgp16_wavefront_step: null pointer");
+    LLDWT_REQUIRE(planes > 0 && batch > 0 && h > 0 && w_ > 0 && groups > 0 && (K == 3 || K == 5), "cgp16_wavefront_step: bad arguments");
+    LLDWT_REQUIRE(planes * batch <= 65535 && groups <= 65535, "cgp16_wavefront_step: grid too large");
+    LLDWT_REQUIRE((int64_t)CPLC * h * w_ < ((int64_t)1 << 31), "cgp16_wavefront_step: image too large for 32-bit offsets");
+    const int slope = K / 2 + 1;
+    LLDWT_REQUIRE(t >= 0 && t <= (int)(w_ - 1 + slope * (h - 1)), "cgp16_wavefront_step: step %d outside 0 .. %ld", t, (long)(w_ - 1 + slope * (h - 1)));
+    Cgp16Args a;
+    a.plc = plc; a.xq = yhat; a.params = nullptr; a.packed = reinterpret_cast<const uint8_t*>(packed);
+    a.batch = (int)batch; a.groups = groups; a.h = (int)h; a.w = (int)w_; a.K = K;
+    int n = 0;
+    for (int q = 0; q < K * K; ++q)
+        if ((tap_mask >> q) & 1u) {
+            LLDWT_REQUIRE(n < 25, "cgp16_wavefront_step: too many taps");
+            a.tap_dy[n] = q / K;
+            a.tap_dx[n] = q % K;
+            ++n;
+        }
+    LLDWT_REQUIRE(n == C0 - CPLC, "cgp16_wavefront_step: %d live taps, the folded first layer expects %d", n, C0 - CPLC);
+    a.ntaps = n;
+    a.wf_t = t; a.wf_slope = slope;
+    wf_range(t, slope, (int)h, (int)w_, a.wf_y0, a.wf_n);
+    if (a.wf_n == 0) return LLDWT_OK;
+    LLDWT_REQUIRE(off >= 0 && off + a.wf_n <= ntot, "cgp16_wavefront_step: step does not fit the output (off %ld + %d > %ld)", (long)off, a.wf_n, (long)ntot);
+    a.wf_y = y; a.wf_yhat = yhat; a.wf_table = table63; a.wf_idx = idx; a.wf_sym = sym; a.wf_mu = mu; a.wf_ntot = ntot; a.wf_off = off;
+    a.cols = (int)cdiv(a.wf_n, 32 * NB);
+    a.stamps = nullptr;
+    dim3 grid((unsigned)cdiv(a.cols, 4), (unsigned)groups, (unsigned)(planes * batch));
+    // always the fp32-accurate arithmetic: encoder and decoder must agree bit for bit whatever the precision mode of the process
+    hipLaunchKernelGGL((k_cgp16<0, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("cgp16_wavefront_step");
+}
+
+extern "C" int lldwt_wavefront_apply(const int* sym, const float* mu, float* yhat, int64_t planes, int64_t batch, int64_t h,
+                                     int64_t w_, int groups, int K, int t, int64_t ntot, int64_t off, void* stream) {
+    LLDWT_REQUIRE(sym && mu && yhat && planes > 0 && batch > 0 && h > 0 && w_ > 0 && groups > 0 && (K == 3 || K == 5), "wavefront_apply: bad arguments");
+    const int slope = K / 2 + 1;
+    int y0, n;
+    wf_range(t, slope, (int)h, (int)w_, y0, n);
+    if (n == 0) return LLDWT_OK;
+    LLDWT_REQUIRE(off >= 0 && off + n <= ntot, "wavefront_apply: step does not fit");
+    dim3 grid((unsigned)cdiv(n, 64), (unsigned)groups, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_wf_apply, grid, dim3(64), 0, (hipStream_t)stream, sym, mu, yhat, groups, (int)h, (int)w_, t, slope, y0, n, ntot, off);
+    return check_launch("wavefront_apply");
 }

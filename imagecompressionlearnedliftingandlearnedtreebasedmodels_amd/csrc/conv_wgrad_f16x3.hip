@@ -252,6 +252,234 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+
+// ================================================================================================================
+// k_wgrad16_f16x3 -- backward-weights of the 16 -> 16 5x5 convs of a P/U block (conv2 and conv3 of P_block_v2.py:40-55; their
+// inputs t1 / t2 are tanh outputs, |x| <= 1) on the fp16 matrix cores with split-fp16 operands.  Replaces k_wgrad16<5> (fp32
+// MFMA 16x16x4: 24 ms of the headline training step at 38 TFLOP/s).
+//
+//   dW[oc][ic][ty][tx] += alpha * sum over images and pixels of dY[oc][y][x] * X[ic][y + ty - 2][x + tx - 2]    (zero padded)
+//
+// GEMM view per tap: M = 16 oc, N = 16 ic, K = pixels; v_mfma_f32_16x16x32_f16 with A = dY (16 oc x 32 pixels of one row) and
+// B = X shifted by the tap (32 pixels x 16 ic).  Both fragments are "8 consecutive pixels of one channel", so both operands
+// live in LDS channel-major as fp16 rows.  The horizontal tap moves the start of a B fragment by tx elements = 2 tx bytes, and a
+// 16-byte LDS read must be aligned: instead of one pre-shifted copy of the patch per tx (five copies: the split + store of the
+// patch would cost more than the MFMAs), every lane reads the ALIGNED 16-element window that holds all five shifts of its
+// fragment (two ds_read_b128 per row and part, shared by the five tx) and extracts a shift in registers -- even shifts are
+// whole dwords, odd shifts four v_alignbit_b32.
+// Workgroup = 4 waves; K chunk = 8 rows x 32 pixels; wave w owns rows w and w + 4 of the chunk for all 25 taps (100 accumulator
+// registers; 150 MFMAs per chunk and wave against 44 fragment reads).  No register prefetch (the accumulators leave no room
+// for it): load -> split -> LDS store of the next chunk happen between two barriers, and the OTHER workgroup resident on the
+// CU (two at 255 registers per lane) runs its MFMAs meanwhile.  K is also split over workgroups (one resident round); the partial 16 x 16 x 25
+// tiles of the four waves are summed in LDS and added to dW with one coalesced float atomic per element.
+// Scales: X has a fixed 2^14 (tanh outputs); dY one power of two per plane from its |max| (lldwt_absmax_slots).
+constexpr int G_CR = 8, G_CW = 32;                          // chunk: 8 rows x 32 pixels
+constexpr int G_AP = G_CR * G_CW * 2 + 16;                  // dY bytes per oc: 528 (132 dwords = 4 mod 64: conflict-free b128)
+constexpr int G_APART = 16 * G_AP;                          // 8 448 B (hi or lo)
+constexpr int G_XR = G_CR + 4, G_BR = 80;                   // 12 patch rows; 40 elements per row: columns x0-2 .. x0+37
+constexpr int G_BC = G_XR * G_BR + 16;                      // bytes per ic: 976 (244 dwords = 52 mod 64: conflict-free b128)
+constexpr int G_BPART = 16 * G_BC;                          // 15 616 B (hi or lo)
+constexpr int G_LDS_A = 0, G_LDS_B = 2 * G_APART, G_LDS_DUMP = G_LDS_B + 2 * G_BPART;
+constexpr int G_LDS_TOTAL = G_LDS_DUMP + 64;                // 48 192 B
+constexpr int G_NA4 = 16 * G_CR * G_CW / 4 / 256;           // dY float4s per thread and chunk: 4
+constexpr int G_XSEG = 11;                                  // aligned float4 segments per patch row: columns x0-4 .. x0+39
+constexpr int G_NX4 = (16 * G_XR * G_XSEG + 255) / 256;     // 9 (the last round: 64 threads)
+static_assert(16 * 16 * 25 * 4 <= G_LDS_DUMP, "the epilogue's dW tile fits the staging images");
+
+struct Wg16Args {
+    const float* x;       // (planes, batch, 16, h, w), |x| <= 1
+    const float* dy;      // (planes, batch, 16, h, w)
+    float* dw;            // (planes, 16, 16, 5, 5)
+    float* db;            // (planes, 16) or null
+    const float* sy;      // (planes, 64) max-|dy| slots
+    int batch, h, w, slices, chunks_x, chunks_y;
+    float alpha;
+    int8_t tap_of[25];    // tap (ty * 5 + tx) -> position inside a dW[oc][ic] block (row passes store (kh, kw) swapped)
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgrad16_f16x3(Wg16Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int plane = blockIdx.z, slice = blockIdx.x;
+    const int h = a.h, w = a.w;
+    const int64_t hw = (int64_t)h * w;
+    const int nchunk_img = a.chunks_x * a.chunks_y;
+    const int nchunk = a.batch * nchunk_img;
+    float ay = a.sy[plane * 64 + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ay = fmaxf(ay, __shfl_xor(ay, o, 64));
+    const float sY = pow2_scale_for(ay);
+    constexpr float sX = 16384.f;
+
+    floatx4 acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const float* xp = a.x + (int64_t)plane * a.batch * 16 * hw;
+    const float* yp = a.dy + (int64_t)plane * a.batch * 16 * hw;
+    floatx4 ra[G_NA4], rx[G_NX4];
+    float dbs[G_NA4];
+#pragma unroll
+    for (int j = 0; j < G_NA4; ++j) dbs[j] = 0.f;
+
+    // dY: float4 f = tid + 256 j -> oc = f / 64, row = (f % 64) / 8, x4 = 4 (f % 8)
+    // x : float4 f = tid + 256 j -> ic = f / 132, row = (f % 132) / 11 (image row y0 - 2 + row), segment s = f % 11 (columns x0-4+4s ..)
+    auto issue = [&](int chunk) {
+        const int img = chunk / nchunk_img, rem = chunk - img * nchunk_img;
+        const int cy = rem / a.chunks_x, cx = rem - cy * a.chunks_x;
+        const int y0 = cy * G_CR, x0 = cx * G_CW;
+#pragma unroll
+        for (int j = 0; j < G_NA4; ++j) {
+            const int f = tid + 256 * j;
+            const int oc = f >> 6, row = (f >> 3) & 7, x4 = (f & 7) * 4;
+            const int gy = min(y0 + row, h - 1), gx = min(x0 + x4, w - 4);
+            ra[j] = *reinterpret_cast<const floatx4*>(yp + ((int64_t)img * 16 + oc) * hw + (int64_t)gy * w + gx);
+        }
+#pragma unroll
+        for (int j = 0; j < G_NX4; ++j) {
+            const int f = min(tid + 256 * j, 16 * G_XR * G_XSEG - 1);
+            const int ic = f / (G_XR * G_XSEG), r2 = f - ic * (G_XR * G_XSEG), row = r2 / G_XSEG, s = r2 - row * G_XSEG;
+            const int gy = min(max(y0 - 2 + row, 0), h - 1), gx = min(max(x0 - 4 + 4 * s, 0), w - 4);
+            rx[j] = *reinterpret_cast<const floatx4*>(xp + ((int64_t)img * 16 + ic) * hw + (int64_t)gy * w + gx);
+        }
+    };
+    auto stage = [&](int chunk) {
+        const int img = chunk / nchunk_img, rem = chunk - img * nchunk_img;
+        const int cy = rem / a.chunks_x, cx = rem - cy * a.chunks_x;
+        const int y0 = cy * G_CR, x0 = cx * G_CW;
+        (void)img;
+#pragma unroll
+        for (int j = 0; j < G_NA4; ++j) {
+            const int f = tid + 256 * j;
+            const int oc = f >> 6, row = (f >> 3) & 7, x4 = (f & 7) * 4;
+            const bool ok = y0 + row < h && x0 + x4 < w;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ok ? ra[j][i] : 0.f;
+            dbs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= sY;
+            half4 hi, lo;
+            split4v(v, hi, lo);
+            uint8_t* d = lds + G_LDS_A + oc * G_AP + (row * G_CW + x4) * 2;
+            *reinterpret_cast<half4*>(d) = hi;
+            *reinterpret_cast<half4*>(d + G_APART) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < G_NX4; ++j) {
+            const int f = tid + 256 * j;
+            const bool live = f < 16 * G_XR * G_XSEG;
+            const int fc = live ? f : 0;
+            const int ic = fc / (G_XR * G_XSEG), r2 = fc - ic * (G_XR * G_XSEG), row = r2 / G_XSEG, s = r2 - row * G_XSEG;
+            const int gy = y0 - 2 + row, gx = x0 - 4 + 4 * s;
+            const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;       // w % 4 == 0: a segment is inside or outside as a whole
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ok ? rx[j][i] * sX : 0.f;
+            half4 hi, lo;
+            split4v(v, hi, lo);
+            // element e of a patch row holds column x0 - 2 + e: this segment's columns are elements 4s-2 .. 4s+1 = two aligned
+            // fp16 pairs; pairs that fall outside the 48 slots (s == 0: elements -2, -1) and dead tasks go to a dump slot
+            uint8_t* rowp = lds + G_LDS_B + ic * G_BC + row * G_BR;
+            uint8_t* dump = lds + G_LDS_DUMP;
+            const int e0 = 4 * s - 2;
+            const bool k0 = live && e0 >= 0, k1 = live && e0 + 2 < 40;
+            uint8_t* d0 = k0 ? rowp + e0 * 2 : dump;
+            uint8_t* d1 = k1 ? rowp + (e0 + 2) * 2 : dump + 8;
+            *reinterpret_cast<half2*>(d0) = half2{hi[0], hi[1]};
+            *reinterpret_cast<half2*>(d0 + (k0 ? G_BPART : 4)) = half2{lo[0], lo[1]};
+            *reinterpret_cast<half2*>(d1) = half2{hi[2], hi[3]};
+            *reinterpret_cast<half2*>(d1 + (k1 ? G_BPART : 4)) = half2{lo[2], lo[3]};
+        }
+    };
+
+    const int kg = lane >> 4, l15 = lane & 15;
+    const uint8_t* abase = lds + G_LDS_A + l15 * G_AP + kg * 16;
+    const uint8_t* bbase = lds + G_LDS_B + l15 * G_BC + kg * 16;
+    int chunk = slice;
+    if (chunk < nchunk) {
+        issue(chunk);
+        stage(chunk);
+    }
+    __syncthreads();
+    while (chunk < nchunk) {
+        const int next = chunk + a.slices;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = wave + 4 * rr;                                  // chunk row of this k-step
+            const half8 ah = *reinterpret_cast<const half8*>(abase + r * G_CW * 2);
+            const half8 al = *reinterpret_cast<const half8*>(abase + r * G_CW * 2 + G_APART);
+#pragma unroll
+            for (int ty = 0; ty < 5; ++ty) {
+                const uint8_t* bp = bbase + (r + ty) * G_BR;
+                uintx4 wh[2], wl[2];
+                wh[0] = *reinterpret_cast<const uintx4*>(bp);
+                wh[1] = *reinterpret_cast<const uintx4*>(bp + 16);
+                wl[0] = *reinterpret_cast<const uintx4*>(bp + G_BPART);
+                wl[1] = *reinterpret_cast<const uintx4*>(bp + G_BPART + 16);
+                const unsigned dh[8] = {wh[0][0], wh[0][1], wh[0][2], wh[0][3], wh[1][0], wh[1][1], wh[1][2], wh[1][3]};
+                const unsigned dl[8] = {wl[0][0], wl[0][1], wl[0][2], wl[0][3], wl[1][0], wl[1][1], wl[1][2], wl[1][3]};
+#pragma unroll
+                for (int tx = 0; tx < 5; ++tx) {
+                    uintx4 fh, fl;
+                    if (tx % 2 == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { fh[i] = dh[tx / 2 + i]; fl[i] = dl[tx / 2 + i]; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            fh[i] = __builtin_amdgcn_alignbit(dh[tx / 2 + i + 1], dh[tx / 2 + i], 16);
+                            fl[i] = __builtin_amdgcn_alignbit(dl[tx / 2 + i + 1], dl[tx / 2 + i], 16);
+                        }
+                    }
+                    const half8 bh = __builtin_bit_cast(half8, fh), bl = __builtin_bit_cast(half8, fl);
+                    const int t = ty * 5 + tx;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                              // every wave is done reading this chunk's images
+        if (next < nchunk) {
+            issue(next);
+            stage(next);
+        }
+        __syncthreads();
+        chunk = next;
+    }
+
+    // ---- epilogue: the four waves' partial tiles summed in LDS in dW order, then one coalesced atomic per element (every
+    // workgroup of a plane adds to the same 6 400 addresses: scattered lanes would touch 64 cache lines per instruction)
+    float* tile = reinterpret_cast<float*>(lds);
+    for (int i = tid; i < 16 * 16 * 25; i += 256) tile[i] = 0.f;
+    __syncthreads();
+    if (slice < nchunk) {
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            const int tap = a.tap_of[t];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)               // D row = oc = 4 kg + q, col = ic = lane & 15
+                __hip_atomic_fetch_add(tile + ((4 * kg + q) * 16 + l15) * 25 + tap, acc[t][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    if (slice >= nchunk) return;
+    const float inv = a.alpha * (1.f / sX) * (1.f / sY);
+    float* dwp = a.dw + (int64_t)plane * 16 * 16 * 25;
+    for (int i = tid; i < 16 * 16 * 25; i += 256) atomicAdd(dwp + i, tile[i] * inv);
+    if (a.db) {
+#pragma unroll
+        for (int j = 0; j < G_NA4; ++j) {
+            float s_ = dbs[j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o, 64);   // the 64 threads (one wave) that stage one oc
+            const int oc = (tid + 256 * j) >> 6;
+            if (lane == 0) atomicAdd(a.db + (int64_t)plane * 16 + oc, s_ * a.alpha);
+        }
+    }
+}
+
 }  // namespace
 }  // namespace lldwt
 using namespace lldwt;
@@ -303,4 +531,51 @@ extern "C" int lldwt_conv3x3_wgrad_f16x3(const float* x, const float* dy, float*
     dim3 grid((unsigned)(slices * ncol), 1, (unsigned)planes);
     hipLaunchKernelGGL(k_wgrad3_f16x3, grid, dim3(256), LDS_TOTAL, st, a);
     return check_launch("conv3x3_wgrad_f16x3");
+}
+
+
+// 16 -> 16 5x5 weight gradient of a P/U block on the fp16 matrix cores (see k_wgrad16_f16x3).  x must be bounded by 1 in magnitude
+// (the tanh outputs t1 / t2); slots_ws: planes * 64 floats.  tap_of: 25 entries, tap (ty*5+tx) -> position inside dW[oc][ic].
+namespace lldwt {
+int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int64_t planes, int64_t batch,
+                  int64_t h, int64_t w_, float alpha, const int8_t* tap_of, hipStream_t st) {
+    LLDWT_REQUIRE(x && dy && dw && slots_ws && tap_of, "wgrad16_f16x3: null pointer");
+    LLDWT_REQUIRE(planes > 0 && planes <= 65535 && batch > 0 && h > 0 && w_ >= 4 && w_ % 4 == 0, "wgrad16_f16x3: bad dims");
+    LLDWT_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dy) & 15) == 0, "wgrad16_f16x3: x and dy must be 16-byte aligned");
+    int r = lldwt_absmax_slots(dy, planes, batch * 16 * h * w_, slots_ws, st);
+    if (r) return r;
+    Wg16Args a;
+    a.x = x; a.dy = dy; a.dw = dw; a.db = dbias; a.sy = slots_ws;
+    a.batch = (int)batch; a.h = (int)h; a.w = (int)w_; a.alpha = alpha;
+    a.chunks_x = (int)cdiv(w_, G_CW);
+    a.chunks_y = (int)cdiv(h, G_CR);
+    for (int t = 0; t < 25; ++t) a.tap_of[t] = tap_of[t];
+    const int64_t nchunk = batch * a.chunks_x * a.chunks_y;
+    static bool attr = false;
+    static int per_cu = 2;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k_wgrad16_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_TOTAL) != hipSuccess) {
+            set_error("wgrad16_f16x3: cannot reserve %d bytes of LDS", G_LDS_TOTAL);
+            return LLDWT_EHIP;
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_wgrad16_f16x3, 256, G_LDS_TOTAL) != hipSuccess || per_cu < 1)
+            per_cu = 2;
+        attr = true;
+    }
+    // one resident round over all planes (equal-time workgroups), at least 2 chunks per workgroup
+    int64_t slices = (int64_t)lldwt_num_cus() * per_cu / planes;
+    if (slices > nchunk / 2) slices = nchunk / 2;
+    if (slices < 1) slices = 1;
+    a.slices = (int)slices;
+    dim3 grid((unsigned)slices, 1, (unsigned)planes);
+    hipLaunchKernelGGL(k_wgrad16_f16x3, grid, dim3(256), G_LDS_TOTAL, st, a);
+    return check_launch("wgrad16_f16x3");
+}
+}  // namespace lldwt
+
+extern "C" int lldwt_wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int64_t planes,
+                                   int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw, void* stream) {
+    int8_t tap_of[25];
+    for (int t = 0; t < 25; ++t) tap_of[t] = (int8_t)(swap_hw ? (t % 5) * 5 + t / 5 : t);
+    return lldwt::wgrad16_f16x3(x, dy, dw, dbias, slots_ws, planes, batch, h, w_, alpha, tap_of, (hipStream_t)stream);
 }

@@ -9,6 +9,7 @@
 // pass uses the (kh,kw)-transposed weights instead of transposing the data.
 #include "common.h"
 #include "lifting_f16.h"
+#include <string.h>
 
 namespace lldwt {
 
@@ -1579,7 +1580,8 @@ extern "C" int lldwt_lift_bwd_fin(const float* g, const float* dsk, const float*
 }
 
 extern "C" int64_t lldwt_lift_step_bwd_ws_bytes(int64_t Z, int64_t h, int64_t w, int C) {
-    return (int64_t)sizeof(float) * Z * h * w * (2 + 3 * (int64_t)C);     // g | dsk | dt3 | dpre2 | dr
+    // g | dsk | dt3 | dpre2 | dr | 64 |dY|-max slots per plane (split-fp16 weight gradient of the 16 -> 16 convs)
+    return (int64_t)sizeof(float) * (Z * h * w * (2 + 3 * (int64_t)C) + 64 * Z);
 }
 
 template <int K>
@@ -1606,6 +1608,13 @@ static int launch_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, float* g, 
                        vertical);
     return check_launch("lift_step_bwd");
 }
+
+namespace lldwt {
+int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int64_t planes, int64_t batch,
+                  int64_t h, int64_t w_, float alpha, const int8_t* tap_of, hipStream_t st);
+}
+// LLDWT_WGRAD16=f32 keeps the fp32-MFMA weight gradient of the 16 -> 16 lifting convs (k_wgrad16<5>); default: split-fp16
+static const int g_wgrad16_f16 = [] { const char* e = getenv("LLDWT_WGRAD16"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
 
 extern "C" int lldwt_lift_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_src, const float* saved_step,
                                    int64_t planes, int64_t batch, int64_t h, int64_t w, const float* taps, float* dtaps,
@@ -1654,8 +1663,20 @@ extern "C" int lldwt_lift_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, ll
     desc(C, 1);
     if ((r = lldwt_conv2d_wgrad_ex(t3, g, dw4, db4, &d, planes, batch, h, w, alpha, swap, stream))) return r;
     desc(C, C);
-    if ((r = lldwt_conv2d_wgrad_ex(t2, dt3, dw3, db3, &d, planes, batch, h, w, alpha, swap, stream))) return r;
-    if ((r = lldwt_conv2d_wgrad_ex(t1, dpre2, dw2, db2, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    if (K == 5 && !linear && g_wgrad16_f16 && w % 4 == 0 && batch * h * w >= 500000) {
+        // conv3 / conv2: their inputs t2 / t1 are tanh outputs (|x| <= 1): split-fp16 on the fp16 matrix cores (conv_wgrad_f16x3.hip).
+        // Only where it wins (measured, 3 planes x 8 images: 360 vs 513 us at 256 x 512, 231 vs 272 at 256 x 256, but 173 vs 146 at
+        // 128 x 256 and 146 vs 70 at 128 x 128: below ~0.5 Mpixel per plane the per-plane |dY|-max pass and the 6 400 float atomics
+        // of every workgroup weigh more than the matrix work saved)
+        int8_t tap_of[25];
+        for (int t = 0; t < 25; ++t) tap_of[t] = (int8_t)(swap ? (t % 5) * 5 + t / 5 : t);
+        float* slots = dr + n * C;
+        if ((r = wgrad16_f16x3(t2, dt3, dw3, db3, slots, planes, batch, h, w, alpha, tap_of, st))) return r;
+        if ((r = wgrad16_f16x3(t1, dpre2, dw2, db2, slots, planes, batch, h, w, alpha, tap_of, st))) return r;
+    } else {
+        if ((r = lldwt_conv2d_wgrad_ex(t2, dt3, dw3, db3, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+        if ((r = lldwt_conv2d_wgrad_ex(t1, dpre2, dw2, db2, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    }
     desc(1, C);
     if ((r = lldwt_conv2d_wgrad_ex(skip, dr, dw1, db1, &d, planes, batch, h, w, alpha, swap, stream))) return r;
     return lldwt_lift_bwd_fin(g, dsk, srcv, g_src, Z, batch, h, w, taps, dtaps, vertical, sign, res_weight, stream);

@@ -246,3 +246,17 @@ extern "C" int lldwt_rans_decode(void* dec, const int32_t* indexes, int64_t n, c
     }
     return LLDWT_OK;
 }
+
+// One call for a whole wavefront step: stream k (of nstreams decoders) pops n symbols for the indexes at indexes + k * stride,
+// into symbols + k * stride.  The same tables for every stream.  (A Python loop over the streams of a step cost more than the
+// decoding itself: ~10 us of call overhead per stream and step.)
+extern "C" int lldwt_rans_decode_multi(void* const* decs, int64_t nstreams, const int32_t* indexes, int64_t n, int64_t stride,
+                                       const int32_t* cdfs, int32_t ncdf, int32_t cdf_stride, const int32_t* cdf_sizes,
+                                       const int32_t* offsets, int32_t* symbols) {
+    LLDWT_REQUIRE(decs && nstreams >= 0 && stride >= n, "rans_decode_multi: bad arguments");
+    for (int64_t k = 0; k < nstreams; ++k) {
+        const int r = lldwt_rans_decode(decs[k], indexes + k * stride, n, cdfs, ncdf, cdf_stride, cdf_sizes, offsets, symbols + k * stride);
+        if (r) return r;
+    }
+    return LLDWT_OK;
+}

@@ -403,9 +403,9 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
         convs = [[s[n] for s in cg] for n in (0, 2, 4, 6)]
         for m in cs:
             m.apply_mask_()
-        packed, dims, _ = cached(cg[0], ("cgp_ctx",), [p for layer in convs for m in layer for p in (m.weight, m.bias)] +
-                                 [p for m in cs for p in (m.weight, m.bias)], lambda: _fold_csc_into_cgp(convs, cs, so))
-        return plc, packed, dims, cs[0].kernel_size[0], cs[0].tap_bits()
+        packed, dims, packed16 = cached(cg[0], ("cgp_ctx",), [p for layer in convs for m in layer for p in (m.weight, m.bias)] +
+                                        [p for m in cs for p in (m.weight, m.bias)], lambda: _fold_csc_into_cgp(convs, cs, so))
+        return plc, (packed, packed16), dims, cs[0].kernel_size[0], cs[0].tap_bits()
 
     @staticmethod
     def compress_planes(layers, out_xe, out_xo_list):
@@ -423,7 +423,11 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
             for i in range(L - 2, -1, -1):
                 x = out_xo_list[i]
                 plc, packed, dims, K, bits = DWTConditioned2EntropyLayerZTsepSubbands._tree_context(layers, i, q, x.shape[2])
-                s, q = ec.code_tree_level([l.ent_out_xo_list[i] for l in layers], plc, packed, dims, K, bits, x, x.shape, tabs)
+                em_i = [l.ent_out_xo_list[i] for l in layers]
+                if packed[1] is not None:       # the reference's cgp widths: one fused launch per wavefront step
+                    s, q = ec.code_tree_level(em_i, plc, packed[1], K, bits, x, x.shape, tabs)
+                else:
+                    s, q = ec.code_tree_level_generic(em_i, plc, packed[0], dims, K, bits, x, x.shape, tabs)
                 s_list.append(s)
                 q_list.append(q)
         s_list.reverse()
@@ -445,8 +449,12 @@ class DWTConditioned2EntropyLayerZTsepSubbands(_EntropyLayerBase):
             q_list = [q]
             for i in range(L - 2, -1, -1):
                 plc, packed, dims, K, bits = DWTConditioned2EntropyLayerZTsepSubbands._tree_context(layers, i, q, shapes_xo[i][2])
-                _, q = ec.code_tree_level([l.ent_out_xo_list[i] for l in layers], plc, packed, dims, K, bits, None, shapes_xo[i],
-                                          tabs, strings_xo_list[i])
+                em_i = [l.ent_out_xo_list[i] for l in layers]
+                if packed[1] is not None:
+                    _, q = ec.code_tree_level(em_i, plc, packed[1], K, bits, None, shapes_xo[i], tabs, strings_xo_list[i])
+                else:
+                    _, q = ec.code_tree_level_generic(em_i, plc, packed[0], dims, K, bits, None, shapes_xo[i], tabs,
+                                                      strings_xo_list[i])
                 q_list.append(q)
         q_list.reverse()
         return xe, q_list

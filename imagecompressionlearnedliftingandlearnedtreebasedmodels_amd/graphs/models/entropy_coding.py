@@ -71,6 +71,7 @@ class _Sink:
     def __init__(self, P, B, tables, strings=None):
         self.P, self.B, self.t = P, B, tables
         self.decoding = strings is not None
+        self._handles = None
         if self.decoding:
             self.dec = [[RansDecoder() for _ in range(B)] for _ in range(P)]
             for p in range(P):
@@ -86,13 +87,22 @@ class _Sink:
             self.idx.append(idx)
             self.sym.append(sym)
             return sym
-        ih = idx.cpu().numpy()
+        import ctypes as C
+        from ... import _lib
+        ih = np.ascontiguousarray(idx.cpu().numpy(), dtype=np.int32)
         out = np.empty(ih.shape, dtype=np.int32)
-        for p in range(self.P):
-            for b in range(self.B):
-                out[p, b] = self.dec[p][b].decode_stream(ih[p, b].reshape(-1), self.t.cdf, self.t.sizes, self.t.offsets,
-                                                         as_numpy=True).reshape(ih.shape[2:])
+        if self._handles is None:
+            self._handles = (C.c_void_p * (self.P * self.B))(*[self.dec[p][b]._h for p in range(self.P) for b in range(self.B)])
+        per = int(ih.shape[2] * ih.shape[3])
+        pv = lambda a_: a_.ctypes.data_as(C.c_void_p)
+        ops.check(_lib.load().lldwt_rans_decode_multi(self._handles, self.P * self.B, pv(ih), per, per, pv(self.t.cdf),
+                                                      self.t.cdf.shape[0], self.t.cdf.shape[1], pv(self.t.sizes),
+                                                      pv(self.t.offsets), pv(out)), "rans_decode_multi")
         return torch.from_numpy(out).to(idx.device)
+
+    def note(self, idx_host, sym_host):
+        """Decoder of code_tree_level: called with every step's (indexes, symbols) as host int32 arrays once they are decoded.
+        A hook for diagnostics (the code-length test replaces it); does nothing."""
 
     def flush(self):
         """Encoder: -> strings[p][b]."""
@@ -147,10 +157,80 @@ def code_crop_stack(seq_stack, emodels, seqs, y, shape, tables, strings=None):
     return (None if sink.decoding else sink.flush()), out
 
 
-def code_tree_level(emodels, plc, cgp_packed, cgp_dims, K, tap_bits, y, shape, tables, strings=None):
+def _step_offsets(H, W, slope):
+    """starts[t] = number of pixels in the wavefront steps before t (pixels of step t: rows ascending)."""
+    h = np.repeat(np.arange(H), W)
+    w = np.tile(np.arange(W), H)
+    t = np.sort(w + slope * h)
+    return np.searchsorted(t, np.arange(W + slope * (H - 1) + 1)).tolist()
+
+
+def code_tree_level(emodels, plc, packed16, K, tap_bits, y, shape, tables, strings=None):
+    """A level with tree context + masked KxK context + cgp (:402-417 / :440-454 with kernel size 5).  plc: (P,B,G*81,H,W)
+    tree-context features of the (decoded) parent; packed16: the cgp stack with the masked conv folded into its first layer,
+    packed for the register-chain kernel (_fold_csc_into_cgp).
+
+    ONE launch per wavefront step (lldwt_cgp16_wavefront_step): the step's pixels are enumerated in the kernel, the causal
+    taps are gathered from the decoded-so-far tensor, the cgp chain runs on the matrix cores and the epilogue produces CDF
+    index, symbol and dequantised value -- no per-step tensor ops on the host side.  Encoder: the launches are queued back to
+    back (no synchronisation until the streams are written).  Decoder: per step one launch, the step's indexes down to the
+    host (pinned buffer), ONE C call that pops the step's symbols from every (plane, image) stream, the symbols up, one
+    small launch that writes symbol + mu."""
+    import ctypes as C
+    from ... import _lib
+    lib = _lib.load()
+    P, B, G, H, W = shape
+    dev = plc.device
+    slope = K // 2 + 1
+    starts = _step_offsets(H, W, slope)
+    nsteps, ntot = len(starts) - 1, H * W
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    table63 = emodels[0].scale_table.to(dev).float()[:63].contiguous()
+    yhat = torch.zeros(P, B, G, H, W, device=dev, dtype=torch.float32)
+    sink = _Sink(P, B, tables, strings)
+    ptr = lambda t_: C.c_void_p(t_.data_ptr())
+    if not sink.decoding:
+        yc = y.contiguous()
+        idx_all = torch.empty(P, B, ntot, G, device=dev, dtype=torch.int32)
+        sym_all = torch.empty(P, B, ntot, G, device=dev, dtype=torch.int32)
+        for t in range(nsteps):
+            ops.check(lib.lldwt_cgp16_wavefront_step(ptr(plc), ptr(yhat), ptr(yc), ptr(packed16), ptr(table63), ptr(idx_all),
+                                                     ptr(sym_all), None, P, B, H, W, G, K, int(tap_bits), t, ntot, starts[t], st),
+                      "cgp16_wavefront_step")
+        sink.idx, sink.sym = [idx_all], [sym_all]
+        return sink.flush(), yhat
+    nmax = max(starts[t + 1] - starts[t] for t in range(nsteps))
+    Z = P * B
+    idx_d = torch.empty(Z * nmax * G, device=dev, dtype=torch.int32)
+    sym_d = torch.empty(Z * nmax * G, device=dev, dtype=torch.int32)
+    mu_d = torch.empty(Z * G * nmax, device=dev, dtype=torch.float32)
+    idx_h = torch.empty(Z * nmax * G, dtype=torch.int32).pin_memory()
+    sym_h = torch.empty(Z * nmax * G, dtype=torch.int32).pin_memory()
+    handles = (C.c_void_p * Z)(*[sink.dec[p][b]._h for p in range(P) for b in range(B)])
+    cdf, sizes, offs = tables.cdf, tables.sizes, tables.offsets
+    pv = lambda a_: a_.ctypes.data_as(C.c_void_p)
+    for t in range(nsteps):
+        n = starts[t + 1] - starts[t]
+        if n == 0:
+            continue
+        cnt = Z * n * G
+        ops.check(lib.lldwt_cgp16_wavefront_step(ptr(plc), ptr(yhat), None, ptr(packed16), ptr(table63), ptr(idx_d), None, ptr(mu_d),
+                                                 P, B, H, W, G, K, int(tap_bits), t, n, 0, st), "cgp16_wavefront_step")
+        idx_h[:cnt].copy_(idx_d[:cnt], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        ops.check(lib.lldwt_rans_decode_multi(handles, Z, C.c_void_p(idx_h.data_ptr()), n * G, n * G, pv(cdf), cdf.shape[0],
+                                              cdf.shape[1], pv(sizes), pv(offs), C.c_void_p(sym_h.data_ptr())), "rans_decode_multi")
+        sink.note(idx_h[:cnt].numpy(), sym_h[:cnt].numpy())
+        sym_d[:cnt].copy_(sym_h[:cnt], non_blocking=True)
+        ops.check(lib.lldwt_wavefront_apply(ptr(sym_d), ptr(mu_d), ptr(yhat), P, B, H, W, G, K, t, n, 0, st), "wavefront_apply")
+    return None, yhat
+
+
+def code_tree_level_generic(emodels, plc, cgp_packed, cgp_dims, K, tap_bits, y, shape, tables, strings=None):
     """A level with tree context + masked KxK context + cgp (:402-417 / :440-454 with kernel size 5).  plc: (P,B,G*81,H,W)
     tree-context features of the (decoded) parent; cgp_packed/dims: the cgp stack with the masked conv folded into its
-    first layer (_fold_csc_into_cgp)."""
+    first layer (_fold_csc_into_cgp).  The host-stepped schedule (a handful of tensor ops and launches per step) for cgp widths
+    other than the reference's 93 -> 162 -> 54 -> 18 -> 2, which the fused step kernel of code_tree_level is built for."""
     P, B, G, H, W = shape
     dev = plc.device
     R = K // 2

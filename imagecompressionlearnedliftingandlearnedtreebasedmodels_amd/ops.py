@@ -477,6 +477,22 @@ def conv2d_wgrad(x, dy, wshape, K, groups=1, upsample2=False, tap_mask=None, wan
     return dw, db
 
 
+def wgrad16_f16x3(x, dy, dw=None, db=None, alpha=1.0, swap_hw=False):
+    """Backward-weights of a 16 -> 16 5x5 conv whose input is bounded by 1 (tanh outputs) on the fp16 matrix cores, split-fp16
+    operands (lldwt_wgrad16_f16x3).  x, dy (P,B,16,h,w) -> (dw (P,16,16,5,5), db (P,16)), accumulated into dw / db if given."""
+    P, B, Cc, h, wd = x.shape
+    if Cc != 16 or dy.shape != x.shape:
+        raise _lib.LLDWTError("wgrad16_f16x3: shapes %r %r" % (tuple(x.shape), tuple(dy.shape)))
+    if dw is None:
+        dw = torch.zeros(P, 16, 16, 5, 5, device=x.device, dtype=torch.float32)
+    if db is None:
+        db = torch.zeros(P, 16, device=x.device, dtype=torch.float32)
+    slots = workspace(P * 64 * 4, x.device)
+    check(_lib.load().lldwt_wgrad16_f16x3(_chk(x, "x"), _chk(dy, "dy"), _chk(dw), _chk(db), C.c_void_p(slots.data_ptr()), P, B, h, wd,
+                                          float(alpha), int(bool(swap_hw)), _stream()), "wgrad16_f16x3")
+    return dw, db
+
+
 def conv3x3_wgrad_f16x3(x, dy, wshape, want_bias=True, alpha=1.0):
     """Backward-weights of a dense 3x3 conv on the fp16 matrix cores, split-fp16 operands (lldwt_conv3x3_wgrad_f16x3).
     x (P,B,cin,h,w), dy (P,B,cout,h,w) -> (dw (P,cout,cin,3,3), dbias (P,cout) or None)."""

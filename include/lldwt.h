@@ -287,6 +287,15 @@ int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, float* dbi
  * path of the 243 -> 243 tree-context conv (LiftingBasedDWT_net.py:271-272); lldwt_conv2d_wgrad covers every other shape. */
 int lldwt_conv3x3_wgrad_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int cin, int cout,
                               int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, void* stream);
+/* Backward-weights of the 16 -> 16 5x5 convs of a P/U block (conv2 / conv3 of graphs/layers/P_block_v2.py:40-55; autograd of
+ * agents/liftingDWT_agent.py:97) on the fp16 matrix cores, split-fp16 operands (fp32-level accuracy):
+ *   dw[p][oc][ic][ty][tx] += alpha * sum_{b,y,x} dy[p][b][oc][y][x] * x[p][b][ic][y+ty-2][x+tx-2],  dbias += alpha * sum dy.
+ * x (planes, batch, 16, h, w) must be bounded by 1 in magnitude (the tanh outputs t1 / t2: its split uses the fixed scale
+ * 2^14); dy any magnitude (one power-of-two scale per plane from its |max|).  w % 4 == 0, 16-byte aligned tensors.
+ * slots_ws: planes * 64 floats of scratch.  swap_hw != 0: the (kh, kw) axes of dw are stored swapped (row passes).
+ * lldwt_lift_step_bwd uses it for K == 5 tanh blocks; LLDWT_WGRAD16=f32 keeps the fp32-MFMA kernel of lldwt_conv2d_wgrad. */
+int lldwt_wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int64_t planes,
+                        int64_t batch, int64_t h, int64_t w, float alpha, int swap_hw, void* stream);
 /* dx = dy * act'(y) elementwise (y = forward output); act as in lldwt_conv_desc. */
 int lldwt_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, void* stream);
 /* backward of the nearest-neighbour 2x upsampling: out (Z,C,h/2,w/2) = sum over each 2x2 block of g (Z,C,h,w). */
@@ -365,6 +374,20 @@ int lldwt_cgp16_pack(const float* w0, const float* b0, const float* w1, const fl
                      int groups, void* stream);
 int lldwt_cgp16_params(const float* plc, const float* xq, const void* packed, float* params, int64_t planes, int64_t batch,
                        int64_t h, int64_t w_, int groups, int K, uint32_t tap_mask, void* stream);
+/* Real entropy coding of a level with tree context + masked KxK context + cgp (the reference walks its pixels in raster
+ * order with a CNN call on a crop each, graphs/models/LiftingBasedDWT_net.py:402-417,440-454,458-556): ONE anti-diagonal
+ * wavefront step t = x + (K/2 + 1) * y, all planes / images / subbands / pixels of the step in one launch of the cgp
+ * register chain (fp32-accurate f16x3 arithmetic whatever lldwt_set_precision says: encoder and decoder must agree bit for
+ * bit).  yhat (Z, groups, h, w): the values decoded so far, 0 elsewhere (the masked taps only reach coded positions).
+ * table63: the first 63 entries of the Gaussian scale table; CDF index = number of entries < max(sigma, 0.11).
+ * idx / sym (Z, ntot, groups) int32 in wavefront order, this step's pixels at positions off .. off + n - 1 (rows ascending).
+ *   encoder (y != null): sym = round(y - mu), yhat[pixel] = sym + mu, idx written.
+ *   decoder (y == null): idx written, mu (Z, groups, n) kept for lldwt_wavefront_apply once the host has decoded sym.    */
+int lldwt_cgp16_wavefront_step(const float* plc, float* yhat, const float* y, const void* packed, const float* table63,
+                               int* idx, int* sym, float* mu, int64_t planes, int64_t batch, int64_t h, int64_t w,
+                               int groups, int K, uint32_t tap_mask, int t, int64_t ntot, int64_t off, void* stream);
+int lldwt_wavefront_apply(const int* sym, const float* mu, float* yhat, int64_t planes, int64_t batch, int64_t h, int64_t w,
+                          int groups, int K, int t, int64_t ntot, int64_t off, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Real entropy coding (reference: compress_ar / decompress_ar, LiftingBasedDWT_net.py:458-556, on
@@ -386,6 +409,11 @@ int64_t lldwt_rans_encode(const int32_t* symbols, const int32_t* indexes, int64_
 void* lldwt_rans_decoder_new(const uint8_t* stream, int64_t nbytes);
 int lldwt_rans_decode(void* dec, const int32_t* indexes, int64_t n, const int32_t* cdfs, int32_t ncdf, int32_t cdf_stride,
                       const int32_t* cdf_sizes, const int32_t* offsets, int32_t* symbols);
+/* The same for nstreams decoders in one call (one wavefront step of every (plane, image) stream): stream k reads its n
+ * indexes at indexes + k * stride and writes symbols + k * stride; one table set for all. */
+int lldwt_rans_decode_multi(void* const* decs, int64_t nstreams, const int32_t* indexes, int64_t n, int64_t stride,
+                            const int32_t* cdfs, int32_t ncdf, int32_t cdf_stride, const int32_t* cdf_sizes,
+                            const int32_t* offsets, int32_t* symbols);
 void lldwt_rans_decoder_free(void* dec);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -141,11 +141,19 @@ def test_round_trip_and_code_length_64(gain, outlier):
         ideal += b
         escapes += e
         return out
+    def spy_note(self, idx_host, sym_host):                  # the tree levels: one fused launch per step, decoded in one C call
+        nonlocal ideal, escapes
+        b, e = ec.ideal_bits(sym_host.reshape(-1).copy(), idx_host.reshape(-1).copy(), self.t)
+        ideal += b
+        escapes += e
+    orig_note = ec._Sink.note
     ec._Sink.step = spy
+    ec._Sink.note = spy_note
     try:
         Layer.decompress_planes(em, s_xe, s_xo, xe.shape, [t.shape for t in xo])
     finally:
         ec._Sink.step = orig_step
+        ec._Sink.note = orig_note
     assert 8 * total_bytes >= ideal
     if outlier:
         assert escapes >= 1
