@@ -268,7 +268,16 @@ struct LfArgs {
     int tiles_x, tiles_y;
     int rl, nseg;                 // run length (tiles a workgroup walks down before it moves to another column) and runs per column
     int nitems;                   // runs of the launch: Z * tiles_x * nseg
+    int nborder;                  // the runs of the image's first / last column strip come first in the item order: items 0 .. nborder-1
+    int qslot;                    // which of the work-queue counters this launch uses
 };
+// Work queue of the runs.  A workgroup starts with run blockIdx.x and takes every further one from an atomic counter, so the
+// workgroups that drew border columns (their tiles cost ~25 % more) simply take fewer runs; the border runs come first in the
+// item order (longest processing time first).  A static deal left the CUs 13 % idle at the level-0 shape (in-kernel stamps).
+// [slot][0] = runs handed out beyond the first round, [slot][1] = workgroups that are done; the last one to finish zeroes both,
+// so a slot is clean again when its launch ends (zero-initialised at module load; a launch takes the next of 64 slots, so
+// launches on different streams do not share one).
+__device__ int g_lf_queue[64][2];
 // in-kernel clock stamps of a diagnostic run (tools/lift_stamps.py); a null pointer (always, outside that tool) skips them
 #define LF_STAMP(i)                                                                                                     \
     if (a.stamps && lane == 0)                                                                                          \
@@ -301,18 +310,22 @@ template <int WIN, int NIN, int PREC>
 __device__ __forceinline__ floatx4 conv16_tile_stream(const uint8_t* __restrict__ img, int basein, bool hi_tap,
                                                       const _Float16* __restrict__ frag, int step0, int lane) {
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-    half8 ah[2], al[2];
-    ldA<PREC>(frag, step0, lane, ah[0], al[0]);
+    // ring of 4: three k-steps of weight fragments in flight (one step ahead exposed an L2 round trip per k-step: 13 of them made
+    // the strips of a border tile cost 3.4k cycles for 126 MFMAs)
+    half8 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ldA<PREC>(frag, step0 + i, lane, ah[i], al[i]);
 #pragma unroll
     for (int ks = 0; ks < LF_KS; ++ks) {
-        if (ks + 1 < LF_KS) ldA<PREC>(frag, step0 + ks + 1, lane, ah[(ks + 1) & 1], al[(ks + 1) & 1]);
+        if (ks + 3 < LF_KS) ldA<PREC>(frag, step0 + ks + 3, lane, ah[(ks + 3) & 3], al[(ks + 3) & 3]);
+        __builtin_amdgcn_sched_barrier(0);               // the loads stay three steps ahead of their use
         const int ta = 2 * ks, tb = (2 * ks + 1) < LF_KK ? 2 * ks + 1 : LF_KK - 1;
         const int offa = ((ta / LF_K) * WIN + ta % LF_K) * 16, offb = ((tb / LF_K) * WIN + tb % LF_K) * 16;
         const int off = basein + (hi_tap ? offb : offa);
         const half8 bh = *reinterpret_cast<const half8*>(img + off);
         half8 bl;
         if constexpr (PREC == 0) bl = *reinterpret_cast<const half8*>(img + 2 * NIN * 16 + off);
-        acc = mma3<PREC>(ah[ks & 1], al[ks & 1], bh, bl, acc);
+        acc = mma3<PREC>(ah[ks & 3], al[ks & 3], bh, bl, acc);
     }
     return acc;
 }
@@ -516,13 +529,23 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return r;
     };
     // work item = a RUN: rl vertically consecutive tiles of one column strip of one image (the last run of a column may be
-    // shorter).  The position of a run inside its image is rotated by the image index, so that a workgroup does not meet the
-    // (slower) border columns of every image.
-    const int ipi = a.tiles_x * a.nseg;                        // runs per image
+    // shorter).  Item order: the runs of the first / last column strip of every image (border tiles), then the others.
+    const int bcols = a.tiles_x >= 2 ? 2 : 1;
     auto decode = [&](int item, int j, int64_t& z, int& y0, int& x0, int& seglen) {
-        const int zi = item / ipi;
-        const int pos = (item - zi * ipi + zi * 37) % ipi;
-        const int sx = pos / a.nseg, seg = pos - sx * a.nseg;
+        int zi, sx, seg;
+        if (item < a.nborder) {
+            const int per = bcols * a.nseg;
+            zi = item / per;
+            const int r = item - zi * per, c = r / a.nseg;
+            seg = r - c * a.nseg;
+            sx = c ? a.tiles_x - 1 : 0;
+        } else {
+            const int per = (a.tiles_x - bcols) * a.nseg, it2 = item - a.nborder;
+            zi = it2 / per;
+            const int r = it2 - zi * per, c = r / a.nseg;
+            seg = r - c * a.nseg;
+            sx = 1 + c;
+        }
         z = zi;
         y0 = (seg * a.rl + j) * TH;
         x0 = sx * TW;
@@ -592,7 +615,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     decode(item_i, run_j, z, y0, x0, seglen);
     const bool cont = !SEQ && run_j > 0;                       // the tile above handed down its last T1 / T2 rows
     const bool hand_down = !SEQ && run_j + 1 < seglen;
-    const int next_item = hand_down ? item_i : item_i + (int)gridDim.x, next_j = hand_down ? run_j + 1 : 0;
+    int next_item = item_i;
+    const int next_j = hand_down ? run_j + 1 : 0;
+    int* QN = reinterpret_cast<int*>(lds + LDS_RED) + 16;       // the run this workgroup takes next (broadcast through LDS)
+    if (!hand_down && tid == 0) *QN = (int)gridDim.x + atomicAdd(&g_lf_queue[a.qslot][0], 1);
     const int64_t stamp_tile = (z * a.tiles_y + y0 / TH) * a.tiles_x + x0 / TW;
     int64_t zv;
     const LiftF16Views vout = view_of_z(z, zv);
@@ -662,6 +688,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     LF_STAMP(1)
     __syncthreads();
     LF_STAMP(2)
+    if (!hand_down) next_item = *QN;
     float s_skip;
     {
         float m = RED[0];
@@ -954,6 +981,64 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         LF_STAMP(7)
         __syncthreads();
         LF_STAMP(8)
+        // ---- border tiles: CORR[a] = sum over the conv4 taps of affected pixel a that land outside the image of
+        // sum_oc w4[oc][tap] * t3v[position][oc].  Affected pixels (within two of an image edge): the tile's affected rows RA in
+        // full, then the affected columns CA of the other rows.  Half a wave per pixel, one lane per tap (25 of 32 lanes), the 32
+        // partial sums reduced by a fixed shuffle tree: every lane takes part, and the summation order does not depend on scheduling.
+        int nRA = 0, nCA = 0, RA0 = 0, RA1 = 0, RA2 = 0, RA3 = 0, CA0 = 0, CA1 = 0, CA2 = 0, CA3 = 0, rlo = 0;
+        float* CORR = reinterpret_cast<float*>(lds + LDS_T2);   // rows 0..7 of T2 array 0 are dead after the composite loop (5 120 B)
+        if (!interior) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                       // image rows / columns 0, 1, h-2, h-1 (w-2, w-1) that lie in this tile
+                const int gyk = k < 2 ? k : h - 4 + k, gxk = k < 2 ? k : w - 4 + k;
+                const int r = gyk - y0, c = gxk - x0;
+                const bool newr = r >= 0 && r < TH && !(nRA > 0 && r == RA0) && !(nRA > 1 && r == RA1) && !(nRA > 2 && r == RA2);
+                const bool newc = c >= 0 && c < TW && !(nCA > 0 && c == CA0) && !(nCA > 1 && c == CA1) && !(nCA > 2 && c == CA2);
+                if (newr) { if (nRA == 0) RA0 = r; else if (nRA == 1) RA1 = r; else if (nRA == 2) RA2 = r; else RA3 = r; ++nRA; }
+                if (newc) { if (nCA == 0) CA0 = c; else if (nCA == 1) CA1 = c; else if (nCA == 2) CA2 = c; else CA3 = c; ++nCA; }
+            }
+            // the rows not in RA are one contiguous range (RA = the tile's first and / or last rows)
+            rlo = 0;
+            while (rlo < TH && ((nRA > 0 && rlo == RA0) || (nRA > 1 && rlo == RA1) || (nRA > 2 && rlo == RA2) || (nRA > 3 && rlo == RA3))) ++rlo;
+            const int nA = nRA * TW + (TH - nRA) * nCA;
+            const int half = lane >> 5, tap = lane & 31;
+            const int dy = tap / LF_K, dx = tap - dy * LF_K;
+            for (int a0 = wave * 2; a0 < nA; a0 += 2 * NWAVE) {
+                const int ai = a0 + half;
+                float u = 0.f;
+                if (ai < nA && tap < LF_KK) {
+                    int oy, ox;
+                    if (ai < nRA * TW) {
+                        const int ir = ai / TW;
+                        ox = ai - ir * TW;
+                        oy = ir == 0 ? RA0 : ir == 1 ? RA1 : ir == 2 ? RA2 : RA3;
+                    } else {
+                        const int b = ai - nRA * TW, q = b / nCA, ic = b - q * nCA;
+                        oy = rlo + q;
+                        ox = ic == 0 ? CA0 : ic == 1 ? CA1 : ic == 2 ? CA2 : CA3;
+                    }
+                    const int r = oy + dy, c = ox + dx;                  // t3-region coordinates of this tap's position
+                    const int gyy = y0 + oy - 2 + dy, gxx = x0 + ox - 2 + dx;
+                    const bool rowout = gyy < 0 || gyy >= h, colout = gxx < 0 || gxx >= w;
+                    if (rowout || colout) {
+                        const int ir = r == Rl0 ? 0 : r == Rl1 ? 1 : r == Rl2 ? 2 : 3;
+                        const int ic = c == Cl0 ? 0 : c == Cl1 ? 1 : c == Cl2 ? 2 : 3;
+                        const int j = rowout ? ir * R3W + c : nR * R3W + ic * (TH + 4) + r;
+                        const floatx4* tv = reinterpret_cast<const floatx4*>(T3Vp(j));
+                        const floatx4* wv = reinterpret_cast<const floatx4*>(W4L + tap * LF_C);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const floatx4 t = tv[q], ww = wv[q];
+                            u += t[0] * ww[0] + t[1] * ww[1] + t[2] * ww[2] + t[3] * ww[3];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) u += __shfl_xor(u, o, 64);      // inside each half of the wave
+                if (tap == 0 && ai < nA) CORR[ai] = u;
+            }
+            __syncthreads();
+        }
         {
             const int oy = tid / TW, ox = tid - oy * TW;
             const int gy = y0 + oy, gx = x0 + ox;
@@ -968,34 +1053,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int oc = 0; oc < LF_C; ++oc) cst += (bias[a.b3 + oc] + bias[a.b1 + oc]) * tail[16 + oc];
             net += rs + cst;
             const bool valid = gy < h && gx < w;
-            if (!interior && (gy < 2 || gy >= h - 2 || gx < 2 || gx >= w - 2)) {
-                // the conv4 taps of this pixel that land outside the image: sum_oc w4[oc][tap] * t3v[position][oc], straight from the
-                // strips' t3v (a fixed summation order: results do not depend on scheduling).  Only pixels within two of an image
-                // edge come here; a position outside in both directions belongs to the row strip.
-                float corr = 0.f;
-                for (int dy = 0; dy < LF_K; ++dy) {
-                    const int r = oy + dy, gyy = gy - 2 + dy;
-                    const bool rowout = gyy < 0 || gyy >= h;
-                    const int ir = r == Rl0 ? 0 : r == Rl1 ? 1 : r == Rl2 ? 2 : 3;
-                    for (int dx = 0; dx < LF_K; ++dx) {
-                        const int c = ox + dx, gxx = gx - 2 + dx;
-                        const bool colout = gxx < 0 || gxx >= w;
-                        if (rowout || colout) {
-                            const int ic = c == Cl0 ? 0 : c == Cl1 ? 1 : c == Cl2 ? 2 : 3;
-                            const int j = rowout ? ir * R3W + c : nR * R3W + ic * (TH + 4) + r;
-                            const floatx4* tv = reinterpret_cast<const floatx4*>(T3Vp(j));
-                            const floatx4* wv = reinterpret_cast<const floatx4*>(W4L + (dy * LF_K + dx) * LF_C);
-                            float u = 0.f;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const floatx4 t = tv[q], ww = wv[q];
-                                u += t[0] * ww[0] + t[1] * ww[1] + t[2] * ww[2] + t[3] * ww[3];
-                            }
-                            corr += u;
-                        }
-                    }
-                }
-                net -= corr;
+            if (!interior) {                   // the conv4 taps of this pixel that land outside the image (CORR, computed above)
+                const int ira = (nRA > 0 && oy == RA0) ? 0 : (nRA > 1 && oy == RA1) ? 1 : (nRA > 2 && oy == RA2) ? 2 : (nRA > 3 && oy == RA3) ? 3 : -1;
+                const int ica = (nCA > 0 && ox == CA0) ? 0 : (nCA > 1 && ox == CA1) ? 1 : (nCA > 2 && ox == CA2) ? 2 : (nCA > 3 && ox == CA3) ? 3 : -1;
+                if (ira >= 0) net -= CORR[ira * TW + ox];
+                else if (ica >= 0) net -= CORR[nRA * TW + (oy - rlo) * nCA + ica];
             }
             const float skip = S[(oy + 8) * SW + ox + 8];
             const float din = din_pre;
@@ -1123,6 +1185,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     item_i = next_item;
     run_j = next_j;
     }                           // tile loop
+    if (tid0 == 0 && atomicAdd(&g_lf_queue[a.qslot][1], 1) == (int)gridDim.x - 1) {     // the last workgroup: nobody draws any more
+        g_lf_queue[a.qslot][0] = 0;
+        g_lf_queue[a.qslot][1] = 0;
+    }
 }
 #undef LF_STAMP
 
@@ -1232,6 +1298,9 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
     a.rl = best_rl;
     a.nseg = (int)cdiv(a.tiles_y, a.rl);
     a.nitems = (int)(Zl * a.tiles_x * a.nseg);
+    a.nborder = (int)(Zl * (a.tiles_x >= 2 ? 2 : 1) * a.nseg);
+    static unsigned launch_seq = 0;
+    a.qslot = (int)(launch_seq++ & 63u);
     const unsigned grid = (unsigned)(a.nitems < ncu ? a.nitems : ncu);      // one resident workgroup per CU
     const int prec = seq ? 0 : g_precision;
     if (seq) hipLaunchKernelGGL((k_lift_fused_f16<true, 0>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
