@@ -1534,7 +1534,7 @@ static int pack_pblock_impl(const float* w1, const float* b1, const float* w2, c
     hipLaunchKernelGGL(k_pack_pblock, grid, dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3, w4, b4, packed, C,
                        K);
     if (with_f16 && lift_f16_floats(C, K) > 0) {
-        int r = lift_f16_pack(w1, w2, w3, w4, packed, o.total, o.f16, planes, (hipStream_t)stream);
+        int r = lift_f16_pack(w1, w2, w3, w4, b1, b3, b4, packed, o.total, o.f16, planes, (hipStream_t)stream);
         if (r) return r;
     }
     return check_launch("pack_pblock");

@@ -18,7 +18,8 @@ constexpr int LF_H_C4 = LF_H_C3 + LF_KS * LF_FRAG;
 constexpr int LF_KSC = 5;                 // conv4 o conv3 composed (9x9, 16 -> 1) as D[dx][px]: K = 9 dy x 16 ch = 144 -> 5 k-steps
 constexpr int LF_H_CC = LF_H_C4 + LF_KS4 * LF_FRAG;           // composite fragments
 constexpr int LF_H_END = LF_H_CC + LF_KSC * LF_FRAG;          // 35 * 1024 halves
-// floats after the fragments: [0..3] s_w1..s_w4, [4] s_wc, [16..31] sum over taps of w4[oc], [32..112] Wr[81] = w4 o w1
+// floats after the fragments: [0..3] s_w1..s_w4, [4] s_wc, [5] b4 + sum_oc (b3 + b1)[oc] * sum_taps w4[oc] (the composed path's
+// constant), [16..31] sum over taps of w4[oc], [32..112] Wr[81] = w4 o w1
 constexpr int LF_TAIL_FLOATS = 128;
 // behind the tail, in HALVES from the section start: a bf16 copy of the scaled weights, 512 per k-step (the one-product bf16 mode)
 constexpr int LF_H_BF = LF_H_END + 2 * LF_TAIL_FLOATS;
@@ -29,8 +30,8 @@ constexpr int LF_FLOATS = 2 * LF_ORIENT_FLOATS;               // both orientatio
 static inline __host__ __device__ int lift_f16_floats(int C, int K) { return (C == LF_C && K == LF_K) ? LF_FLOATS : 0; }
 
 // pack the f16 section of one P/U block (called from lldwt_pack_pblock after the fp32 section is written)
-int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, float* packed, int64_t plane_stride,
-                  int f16_off, int planes, hipStream_t st);
+int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, const float* b1, const float* b3,
+                  const float* b4, float* packed, int64_t plane_stride, int f16_off, int planes, hipStream_t st);
 
 // one fused lifting step (eval): dst_out = dst_in + sign * (skip + rw * P(skip)); returns LLDWT_OK or an error
 struct LiftF16Views {

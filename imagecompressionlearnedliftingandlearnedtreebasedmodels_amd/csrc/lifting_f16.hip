@@ -140,12 +140,25 @@ __device__ __forceinline__ float tanh_scaled(float acc, float kc, float bc) {
     return copysignf(t, u);
 }
 
+// the same times a per-pixel factor pin (ACT_SCALE inside the image, 0 outside) folded into the last FMA: pin - 2 pin r = pin (1 - 2 r),
+// bit-identical to tanh_scaled(..) * pin for a power-of-two pin, one vector instruction less per value (m2pin = -2 pin)
+__device__ __forceinline__ float tanh_scaled_masked(float acc, float kc, float bc, float pin, float m2pin) {
+    const float u = __builtin_fmaf(acc, kc, bc);
+    const float e = __builtin_amdgcn_exp2f(fabsf(u));
+    const float t = __builtin_fmaf(m2pin, __builtin_amdgcn_rcpf(e + 1.f), pin);
+    return copysignf(t, u);
+}
+
 // effective tap t = dy*5+dx of an orientation -> index into the PyTorch (kh,kw) weight
 __device__ __forceinline__ int srctap(int t, int orient) { return orient == 0 ? t : (t % LF_K) * LF_K + t / LF_K; }
 
 __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
-                                const float* __restrict__ w4, float* __restrict__ packed, int64_t plane_stride, int f16_off) {
+                                const float* __restrict__ w4, const float* __restrict__ b1, const float* __restrict__ b3,
+                                const float* __restrict__ b4, float* __restrict__ packed, int64_t plane_stride, int f16_off) {
     const int orient = blockIdx.x, plane = blockIdx.y, tid = threadIdx.x;
+    b1 += (int64_t)plane * LF_C;
+    b3 += (int64_t)plane * LF_C;
+    b4 += plane;
     w1 += (int64_t)plane * LF_C * LF_KK;
     w2 += (int64_t)plane * LF_C * LF_C * LF_KK;
     w3 += (int64_t)plane * LF_C * LF_C * LF_KK;
@@ -239,12 +252,23 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
     float* tail = dst + LF_H_END / 2;
     if (tid < 4) tail[tid] = sw[tid];
     if (tid == 4) tail[4] = swc;
+    if (tid < 4) tail[8 + tid] = 1.f / sw[tid];              // exact (powers of two): the kernel multiplies instead of dividing
+    if (tid == 4) tail[12] = 1.f / swc;
     if (tid < LF_C) {
         float s4 = 0.f;
         for (int t = 0; t < LF_KK; ++t) s4 += w4[tid * LF_KK + t];
         tail[16 + tid] = s4;
     }
     if (tid < 81) tail[32 + tid] = wr[tid];
+    if (tid == 0) {          // the constant of the composed path, in the order the kernel used to sum it per tile
+        float cst = b4[0];
+        for (int oc = 0; oc < LF_C; ++oc) {
+            float s4 = 0.f;
+            for (int t = 0; t < LF_KK; ++t) s4 += w4[oc * LF_KK + t];
+            cst += (b3[oc] + b1[oc]) * s4;
+        }
+        tail[5] = cst;
+    }
 }
 
 struct LfArgs {
@@ -561,15 +585,19 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const LiftF16Views vw = view_of_z(z, zz);
         const float* sp = vw.src + zz * vw.src_sz;
         const int ssy = (int)vw.src_sy, ssx = (int)vw.src_sx;   // per-image offsets fit 32 bits (checked on the host)
-        const int dyv = a.vertical ? 1 : 0, dxv = 1 - dyv;
+        const int dyv = a.vertical ? 1 : 0;
+        const int fstep = dyv ? ssy : ssx, flast = dyv ? h - 1 : w - 1;
 #pragma unroll
         for (int k = 0; k < NS / NTH; ++k) {
             const int i = tid + k * NTH;
             const int sy = i / SW, sx = i - sy * SW;
             const int gy = min(max(y0 - 8 + sy, 0), h - 1), gx = min(max(x0 - 8 + sx, 0), w - 1);
-            pr.c[k] = sp[gy * ssy + gx * ssx];
-            pr.m[k] = sp[max(gy - dyv, 0) * ssy + max(gx - dxv, 0) * ssx];
-            pr.p[k] = sp[min(gy + dyv, h - 1) * ssy + min(gx + dxv, w - 1) * ssx];
+            // the two filter neighbours = the centre's offset -+ one step along the lifting direction, clamped at the image edge
+            const int oc_ = gy * ssy + gx * ssx;
+            const int along = dyv ? gy : gx;
+            pr.c[k] = sp[oc_];
+            pr.m[k] = sp[oc_ - (along > 0 ? fstep : 0)];
+            pr.p[k] = sp[oc_ + (along < flast ? fstep : 0)];
         }
         const int gy = min(y0 + oy_, h - 1), gx = min(x0 + ox_, w - 1);
         pr.din = vw.din[zz * vw.din_sz + gy * (int)vw.din_sy + gx * (int)vw.din_sx];
@@ -580,9 +608,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // down in place, rows 0..7 receive the handed-down rows at the start of the next tile); sequential path: behind its D image
     auto stg = [&](int v, int tid) -> float* {
         if constexpr (SEQ) return reinterpret_cast<float*>(lds + LDS_STG) + v * NTH + tid;
-        else {
-            const int off = (v * NTH + tid) * 4, arr = off / T2HALF;
-            return reinterpret_cast<float*>(lds + LDS_T2 + arr * T2A + T2HALF + (off - arr * T2HALF));
+        else {       // half-slots of 256 floats, five per array: which array is wave-uniform (scalar arithmetic), one add per lane
+            const int hs = 2 * v + __builtin_amdgcn_readfirstlane(tid >> 8), arr = hs / 5;
+            return reinterpret_cast<float*>(lds + LDS_T2 + arr * T2A + T2HALF) + (hs - arr * 5) * 256 + (tid & 255);
         }
     };
     auto stage = [&](int tid, const LfPre& pr) {
@@ -628,6 +656,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const _Float16* frag = reinterpret_cast<const _Float16*>(pk + a.f16);
     const float* scales = pk + a.f16 + LF_H_END / 2;
     const float sw1 = scales[0], sw2 = scales[1], sw3 = scales[2], sw4 = scales[3];
+    const float isw1 = scales[8], isw2 = scales[9], isw3 = scales[10];           // their reciprocals (exact powers of two)
     LfPre pre;
 #pragma unroll
     for (int k = 0; k < NS / NTH; ++k) {
@@ -688,7 +717,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     LF_STAMP(1)
     __syncthreads();
     LF_STAMP(2)
-    if (!hand_down) next_item = *QN;
+    if (!hand_down) next_item = __builtin_amdgcn_readfirstlane(*QN);      // wave-uniform: everything derived from it stays scalar
     float s_skip;
     {
         float m = RED[0];
@@ -696,7 +725,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 1; i < NWAVE; ++i) m = fmaxf(m, RED[i]);
         s_skip = pow2_scale(m);
     }
-    const float inv1 = (1.f / s_skip) * (1.f / sw1);
+    // s_skip = 2^k (|k| <= 120): its reciprocal by exponent arithmetic, exact, instead of a 10-instruction division
+    const float inv1 = __int_as_float(0x7F000000 - __float_as_int(s_skip)) * isw1;
     {   // the scaled split-fp16 images of the patch (this thread's own three values, still in registers)
         _Float16* h0 = reinterpret_cast<_Float16*>(lds + LDS_S16);             // copy 0: hi, lo; copy 1: hi, lo
 #pragma unroll
@@ -765,7 +795,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int t = 0; t < 2; ++t) {
                 float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = tanh_scaled(acc[t][q], inv1c, b1c[q]) * msk[t];
+                for (int q = 0; q < 4; ++q) v[q] = tanh_scaled_masked(acc[t][q], inv1c, b1c[q], msk[t], -2.f * msk[t]);
                 timg_store<N1, PREC>(lds + LDS_T1, pq[t], oc0, v);
             }
         }
@@ -782,7 +812,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float bv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = bias[a.b2 + oc0 + q];
-        const float inv2 = (1.f / ACT_SCALE) * (1.f / sw2);
+        const float inv2 = (1.f / ACT_SCALE) * isw2;
         float bvc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bvc[q] = bv[q] * TWO_LOG2E;
@@ -815,7 +845,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         auto slice = [&](int ks) {
             if (ks < 8) {
                 const int t = ks >> 2, q = ks & 3;
-                ev[ks] = tanh_scaled(pc[t][q], inv2c, bvc[q]) * pin[t];
+                ev[ks] = tanh_scaled_masked(pc[t][q], inv2c, bvc[q], pin[t], -2.f * pin[t]);
             } else if (ks < 10) {
                 const int t = ks - 8;
                 const float v[4] = {ev[4 * t], ev[4 * t + 1], ev[4 * t + 2], ev[4 * t + 3]};
@@ -847,7 +877,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float pin0 = in_image(q0);
                 float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = tanh_scaled(n0[q], inv2c, bvc[q]) * pin0;
+                for (int q = 0; q < 4; ++q) v[q] = tanh_scaled_masked(n0[q], inv2c, bvc[q], pin0, -2.f * pin0);
                 timg_store<N2, PREC>(lds + LDS_T2, q0, oc0, v);
             } else {
 #pragma unroll
@@ -908,7 +938,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float bv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) bv[q] = bias[a.b3 + oc0 + q] + bias[a.b1 + oc0 + q];
-            const float inv3 = (1.f / ACT_SCALE) * (1.f / sw3);
+            const float inv3 = (1.f / ACT_SCALE) * isw3;
             for (int tile = wave; tile * 16 < nF; tile += NWAVE) {
                 const int j = tile * 16 + pl, jc = j < nF ? j : nF - 1;
                 int r, c;
@@ -948,34 +978,42 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // its own -- a fifth of it rides in the shadow of each composite tile's 15 MFMAs
             const int oyc = tid / TW, oxc = tid - oyc * TW;
             const float* Sc = S + (oyc + 4) * SW + oxc + 4;
-#pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const int tile = wave + it * NWAVE;
-                const int p = tile * 16 + pl;
+            // the B fragments of tile it + 1 (5 k-steps, hi and lo) are read from LDS while the 15 MFMAs of tile it run: a tile's own
+            // reads sat right in front of its MFMAs before, and the loop was bound by LDS latency (7.4k cycles for 2.4k of matrix work)
+            half8 cbh[2][LF_KSC], cbl[2][LF_KSC];
+            auto cload = [&](int it, int set) {
+                const int p = (wave + it * NWAVE) * 16 + pl;
                 const int r = p / R2W, c = p - r * R2W;         // D(r, c) <-> output row r, T2 column c; tap dy -> T2 row r + dy
                 const int basein = (r * R2W + c) * 16 + halfsel * (N2 * 16);
-                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < LF_KSC; ++ks) {
                     const int dya = 2 * ks, dyb = 2 * ks + 1 < 9 ? 2 * ks + 1 : 8;            // dy 9 does not exist: weight 0
                     const int off = basein + (hi_tap ? dyb : dya) * (R2W * 16);
-                    const half8 bh = *reinterpret_cast<const half8*>(img + off);
-                    half8 bl;
-                    if constexpr (PREC == 0) bl = *reinterpret_cast<const half8*>(img + 2 * N2 * 16 + off);
-                    acc = mma3<PREC>(ah[ks], al[ks], bh, bl, acc);
+                    cbh[set][ks] = *reinterpret_cast<const half8*>(img + off);
+                    if constexpr (PREC == 0) cbl[set][ks] = *reinterpret_cast<const half8*>(img + 2 * N2 * 16 + off);
                 }
+            };
+            cload(0, 0);
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int p = (wave + it * NWAVE) * 16 + pl;
+                if (it + 1 < 5) cload(it + 1, (it + 1) & 1);
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < LF_KSC; ++ks) acc = mma3<PREC>(ah[ks], al[ks], cbh[it & 1][ks], cbl[it & 1][ks], acc);
                 // rows = dx: lanes kg 0 hold dx 0-3, kg 1 dx 4-7, kg 2 dx 8 (register 0)
                 float* dq = Dp(p);
                 if (kg < 2) *reinterpret_cast<floatx4*>(dq + 4 * kg) = acc;
                 if (kg == 2) dq[8] = acc[0];
 #pragma unroll
-                for (int j = 17 * it; j < 17 * it + 17 && j < 81; ++j) rs += tail[32 + j] * Sc[(j / 9) * SW + j % 9];
+                for (int j = 17 * it; j < 17 * it + 17 && j < 81; ++j) rs = __builtin_fmaf(tail[32 + j], Sc[(j / 9) * SW + j % 9], rs);
 #pragma unroll
                 for (int i = 0; i < (PREC == 0 ? 15 : 5); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, PREC == 0 ? 2 : 5, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, PREC == 0 ? 2 : 5, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         LF_STAMP(7)
@@ -1042,16 +1080,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             const int oy = tid / TW, ox = tid - oy * TW;
             const int gy = y0 + oy, gx = x0 + ox;
-            const float invc = (1.f / ACT_SCALE) * (1.f / swc);
+            const float invc = (1.f / ACT_SCALE) * tail[12];
             float net = 0.f;
             const float* drow = Dp(oy * R2W) + ox * DP;          // a row of the D image lies inside one quarter
 #pragma unroll
             for (int dx = 0; dx < 9; ++dx) net += drow[dx * DP + dx];
             net *= invc;
-            float cst = bias[a.b4];
-#pragma unroll
-            for (int oc = 0; oc < LF_C; ++oc) cst += (bias[a.b3 + oc] + bias[a.b1 + oc]) * tail[16 + oc];
-            net += rs + cst;
+            net += rs + tail[5];            // b4 + sum_oc (b3 + b1)[oc] * sum_taps w4[oc], summed once per weight update (pack)
             const bool valid = gy < h && gx < w;
             if (!interior) {                   // the conv4 taps of this pixel that land outside the image (CORR, computed above)
                 const int ira = (nRA > 0 && oy == RA0) ? 0 : (nRA > 1 && oy == RA1) ? 1 : (nRA > 2 && oy == RA2) ? 2 : (nRA > 3 && oy == RA3) ? 3 : -1;
@@ -1061,8 +1096,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             const float skip = S[(oy + 8) * SW + ox + 8];
             const float din = din_pre;
-            if (valid)
-                vout.dout[zv * vout.dout_sz + (int64_t)gy * vout.dout_sy + (int64_t)gx * vout.dout_sx] = din + a.sign * (skip + a.rw * net);
+            if (valid)      // per-image offsets fit 32 bits (checked on the host)
+                (vout.dout + zv * vout.dout_sz)[gy * (int)vout.dout_sy + gx * (int)vout.dout_sx] = din + a.sign * (skip + a.rw * net);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more) stage(tid, nxt);
@@ -1204,9 +1239,9 @@ void split_set_precision(int p) { g_precision = p; }
 void lift_f16_set_debug(int dbg) { g_lf_dbg = dbg; }
 void lift_f16_set_stamps(void* p, int64_t nbytes) { g_lf_stamps = reinterpret_cast<unsigned long long*>(p); g_lf_stamps_bytes = p ? nbytes : 0; }
 
-int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, float* packed, int64_t plane_stride,
-                  int f16_off, int planes, hipStream_t st) {
-    hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, (unsigned)planes), dim3(256), 0, st, w1, w2, w3, w4, packed, plane_stride, f16_off);
+int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, const float* b1, const float* b3,
+                  const float* b4, float* packed, int64_t plane_stride, int f16_off, int planes, hipStream_t st) {
+    hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, (unsigned)planes), dim3(256), 0, st, w1, w2, w3, w4, b1, b3, b4, packed, plane_stride, f16_off);
     return check_launch("lift_f16_pack");
 }
 
