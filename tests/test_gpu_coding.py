@@ -1,6 +1,14 @@
 """GPU: real entropy coding of conditioned2ZTsepSubbands (wavefront schedule + host range-ANS) -- symbols and CDF indexes
 against the oracle's per-pixel raster loop, bit-exact round trip through the streams, code length against the rate the
-tables promise, and the agent's test() mode."""
+tables promise, and the agent's test() mode.
+
+NON-GOAL, stated once: byte compatibility with streams written by the reference.  Its compress_ar pushes symbols in RASTER
+order into one BufferedRansEncoder (graphs/models/LiftingBasedDWT_net.py:469-470,502-505); the streams here are in WAVEFRONT
+order (step t = x + s*y ascending, rows ascending inside a step, subbands innermost) so that a decoder can evaluate a whole
+anti-diagonal at once.  Same symbols, same tables, different order: a reference-written stream does not decode here and vice
+versa.  (compressai.ans is absent from the image and the reference holds no bitstream, so the byte format could not be pinned
+either way.)  What IS pinned: the symbol and CDF-index VALUES per pixel equal the reference's per-pixel loop as restated in
+oracle/coding.py."""
 import numpy as np
 import pytest
 import torch
