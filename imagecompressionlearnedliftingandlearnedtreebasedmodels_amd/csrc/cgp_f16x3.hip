@@ -197,7 +197,7 @@ __device__ __forceinline__ void next_frags(const floatx16& acc, float k, const f
 // WF: one wavefront step of the real entropy coder (see Cgp16Args): the pixel list is the step's anti-diagonal and the epilogue
 // turns (sigma, mu) into CDF index + symbol + dequantised value (LiftingBasedDWT_net.py:458-506: compress_ar's per-pixel work)
 template <int PREC, bool WF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cgp16(Cgp16Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_cgp16(Cgp16Args a) {
     constexpr int SB = PREC == 2 ? STEP_BYTES / 2 : STEP_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h5 = lane >> 5, pl = lane & 31;

@@ -183,3 +183,46 @@ def test_lifting_program_layout_host_side(inverse, scale):
     # without gains the program and its saved size are what they were before gain ops kept anything
     prog0, total0 = ops.lifting_program(Z, H, W, L, False, 0, inverse, C_, False)
     assert total0 == sum(Z * o.h * o.w * (2 + 3 * C_) for o in prog0)
+
+
+def test_wavefront_step_offsets_match_the_pixel_order():
+    """graphs/models/entropy_coding._step_offsets (what code_tree_level passes to lldwt_cgp16_wavefront_step as `off`) against
+    wavefront(): step t holds the pixels x + s*y == t, rows ascending -- the order the streams are written in."""
+    import numpy as np
+    import torch
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.graphs.models import entropy_coding as ec
+    for H, W, s in ((4, 4, 2), (5, 9, 3), (16, 7, 3), (1, 6, 3), (8, 8, 2)):
+        hs, ws, starts = ec.wavefront(H, W, s, torch.device("cpu"))
+        assert ec._step_offsets(H, W, s) == starts
+        t = (ws + s * hs).numpy()
+        assert (np.diff(t) >= 0).all() and starts[-1] == H * W and len(starts) == W + s * (H - 1) + 1
+        for k in range(len(starts) - 1):
+            seg = slice(starts[k], starts[k + 1])
+            assert (t[seg] == k).all() and (np.diff(hs[seg].numpy()) > 0).all()       # rows ascending inside a step
+            # the kernel's own enumeration of the step: rows y0 .. y0 + n - 1, x = t - s*y inside [0, W)
+            lo = max(0, -(-(k - (W - 1)) // s)) if k - (W - 1) > 0 else 0
+            hi = min(H - 1, k // s)
+            n = hi - lo + 1 if hi >= lo else 0
+            assert n == starts[k + 1] - starts[k]
+            if n:
+                assert int(hs[starts[k]]) == lo
+
+
+def test_precision_names_and_traffic_hashes(monkeypatch):
+    """LLDWT_PRECISION is validated at load (names -> codes of lldwt_set_precision); bench.py's traffic figures are tied to the
+    git blob hash of the kernel sources they were measured on."""
+    import hashlib
+    import json
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import _lib
+    assert _lib.PRECISIONS == {"f16x3": 0, "fp16": 1, "bf16": 2}
+    import bench
+    h = bench.source_hashes()
+    src = os.path.join(REPO, PKG, "csrc", "lifting_f16.hip")
+    b = open(src, "rb").read()
+    assert h["lifting_f16.hip"] == hashlib.sha1(b"blob %d\0" % len(b) + b).hexdigest()
+    assert bench.traffic_is_current({"source_hashes": dict(h)}, ("lifting_f16.hip", "split_f16.h"))
+    stale = dict(h, **{"lifting_f16.hip": "0" * 40})
+    assert not bench.traffic_is_current({"source_hashes": stale}, ("lifting_f16.hip",))
+    assert not bench.traffic_is_current({}, ("conv_f16x3.hip",))
+    tj = json.load(open(os.path.join(REPO, "profiles", "traffic_current.json")))
+    assert set(tj["source_hashes"]) >= {"conv_f16x3.hip", "lifting_f16.hip"}
