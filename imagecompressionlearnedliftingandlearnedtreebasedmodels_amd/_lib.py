@@ -58,6 +58,7 @@ SIGNATURES = {
     "lldwt_cgp16_wavefront_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, C.c_uint32, _i, _i64, _i64, _p]),
     "lldwt_wavefront_apply": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i64, _i64, _p]),
     "lldwt_rans_decode_multi": (_i, [C.POINTER(_p), _i64, _p, _i64, _i64, _p, C.c_int32, C.c_int32, _p, _p, _p]),
+    "lldwt_train_lift_f16": (_i, []),
     "lldwt_set_precision": (_i, [_i]),
     "lldwt_get_precision": (_i, []),
     "lldwt_set_cdf97_short_levels": (_i, [_i]),

@@ -286,14 +286,30 @@ class SqErrSumFn(torch.autograd.Function):
 _BUF_X, _BUF_LROW, _BUF_HROW, _BUF_TMPL, _BUF_TMPH, _BUF_LL0, _BUF_LL1, _BUF_LL, _BUF_YH0 = range(9)
 
 
+_W_KEYS = ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")
+_PACK_MEMO = {"key": None, "val": None}
+
+
 def _pack_forward(W, nblocks):
-    """W: dict of 8 stacked tensors (nblocks,2,P,...) -> packed (P,nblocks,2,total) for the lifting step kernels."""
+    """W: dict of 8 stacked tensors (nblocks,2,P,...) -> packed (P,nblocks,2,total) for the lifting step kernels.
+
+    One training step asks for the same pack four times (encode and decode share their P/U blocks -- lifting_dwt_nets.py:
+    695-707 -- and each backward reads the forward pack again): the last result is kept and reused while every tensor is
+    the same object at the same version (an optimizer step or load_state_dict bumps ``_version``).  With the fused training
+    forward the pack includes the composed 9x9 kernels (0.4 ms per block and call: 6.7 ms per step without the memo)."""
+    key = tuple((k, W[k].data_ptr(), W[k]._version, tuple(W[k].shape)) for k in _W_KEYS) + (nblocks, ops.train_lift_f16())
+    if _PACK_MEMO["key"] == key:
+        return _PACK_MEMO["val"]
     blocks = []
     for b in range(nblocks):
-        pu = [ops.pack_pblock(*[W[k][b, u] for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")], train=True)
-              for u in range(2)]     # training kernels only: no split-fp16 section (re-packed every step)
+        # re-packed every step.  The fused f16x3 training forward (default for 16 channels, 5x5, tanh) reads the split-fp16
+        # section; with LLDWT_TRAIN_LIFT=f32 / LLDWT_LIFT_MODE=f32 only the fp32 kernels run and that section is skipped
+        pu = [ops.pack_pblock(*[W[k][b, u] for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")],
+                              train=not ops.train_lift_f16()) for u in range(2)]
         blocks.append(torch.stack(pu, 1))
-    return torch.stack(blocks, 1).contiguous()
+    out = torch.stack(blocks, 1).contiguous()
+    _PACK_MEMO["key"], _PACK_MEMO["val"] = key, out
+    return out
 
 
 class _LiftBackward:
@@ -395,9 +411,6 @@ class _LiftBackward:
             ops.lift_bwd_fin(g, dsk, srcv, view(op.buf_src, op.off_src, op.sz_src, op.sy_src, op.sx_src), Z, B, h, w,
                              self.taps[op.tap], self.dtaps[op.tap],
                              vert, op.sign, rw)
-
-
-_W_KEYS = ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")
 
 
 def _grad_buffers(P, B, H, W, levels, dev):

@@ -1187,6 +1187,10 @@ struct StepBufs {
     float* srcv;   // (Z,h,w)   or null
 };
 
+// LLDWT_TRAIN_LIFT=f32: the training forward of the lifting steps stays on the three fp32-MFMA launches (default: fused f16x3)
+static const int g_train_lift_f16 = [] { const char* e = getenv("LLDWT_TRAIN_LIFT"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
+extern "C" int lldwt_train_lift_f16(void) { return g_train_lift_f16 && g_lift_mode == 1; }
+
 template <int C, int K>
 static int launch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, int64_t Z, int64_t batch, int64_t h,
                        int64_t w, const float* taps, const float* packed, int64_t pstride, int vertical, float sign,
@@ -1198,6 +1202,16 @@ static int launch_step(lldwt_view src, lldwt_view dst_in, lldwt_view dst_out, in
                            dst_out.p, dst_out.sz, dst_out.sy, dst_out.sx};
             const PackOff o = pack_off(C, K);
             return lift_f16_step(v, Z, batch, h, w, taps, packed, pstride, o.orient, o.f16, vertical, sign, rw, st);
+        }
+        // training forward (intermediates saved), tanh P-block: the same fused kernel on its sequential path, which forms t3
+        // explicitly, + stores of (src, skip, t1, t2, t3) -- the fp16 matrix cores instead of three fp32-MFMA launches.  The packed
+        // buffer must carry the split-fp16 section (lldwt_pack_pblock, not _train); LLDWT_TRAIN_LIFT=f32 keeps the fp32 launches
+        if (g_lift_mode == 1 && g_train_lift_f16 && !linear && b.t1 != nullptr && b.srcv != nullptr) {
+            LiftF16Views v{src.p, src.sz, src.sy, src.sx, dst_in.p, dst_in.sz, dst_in.sy, dst_in.sx,
+                           dst_out.p, dst_out.sz, dst_out.sy, dst_out.sx};
+            const LiftF16Saved sv{b.srcv, b.skip, b.t1, b.t2, b.t3};
+            const PackOff o = pack_off(C, K);
+            return lift_f16_step_train(v, sv, Z, batch, h, w, taps, packed, pstride, o.orient, o.f16, vertical, sign, rw, st);
         }
     }
     dim3 grid((unsigned)cdiv(w, TW), (unsigned)cdiv(h, TH), (unsigned)Z), block(NT);

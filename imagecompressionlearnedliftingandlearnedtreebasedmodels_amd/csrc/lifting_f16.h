@@ -44,6 +44,15 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
                   hipStream_t st);
 // the same step for TWO independent view sets of the same geometry and parameters in one launch (v2 may be null): images
 // 0 .. Z-1 use v, images Z .. 2Z-1 use *v2
+// the training forward of one step on the fused kernel's sequential path: the same step, and the tile interiors of src, skip
+// (Z, h, w) and t1, t2, t3 (Z, 16, h, w) written out for the backward (what k_lift_a/b/c save on the fp32 path)
+struct LiftF16Saved { float* src; float* skip; float* t1; float* t2; float* t3; };
+int lift_f16_step_train(const LiftF16Views& v, const LiftF16Saved& sv, int64_t Z, int64_t batch, int64_t h, int64_t w,
+                        const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off,
+                        int vertical, float sign, float rw, hipStream_t st);
+int lift_f16_step_any(const LiftF16Views& v, const LiftF16Views* v2, const LiftF16Saved* sv, int64_t Z, int64_t batch, int64_t h,
+                      int64_t w, const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off,
+                      int vertical, float sign, float rw, hipStream_t st);
 // arithmetic of the split-fp16 kernel families (lldwt_set_precision): 0 = f16x3 (three products per MAC, fp32-level accuracy),
 // 1 = fp16, 2 = bf16 (one product per MAC).  Defined in lifting_f16.hip, read at launch by conv_f16x3.hip and cgp_f16x3.hip too
 int split_precision();

@@ -152,7 +152,10 @@ __device__ __forceinline__ float tanh_scaled_masked(float acc, float kc, float b
 // effective tap t = dy*5+dx of an orientation -> index into the PyTorch (kh,kw) weight
 __device__ __forceinline__ int srctap(int t, int orient) { return orient == 0 ? t : (t % LF_K) * LF_K + t / LF_K; }
 
-__global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
+// 1024 threads: the composed 9x9 kernels are 1 377 sums of up to 400 double-precision products each; 256 threads took 0.4 ms per
+// block (it runs at every weight update, i.e. every training step)
+constexpr int PACK_NT = 1024, PACK_NW = PACK_NT / 64;
+__global__ __launch_bounds__(PACK_NT) void k_lift_f16_pack(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
                                 const float* __restrict__ w4, const float* __restrict__ b1, const float* __restrict__ b3,
                                 const float* __restrict__ b4, float* __restrict__ packed, int64_t plane_stride, int f16_off) {
     const int orient = blockIdx.x, plane = blockIdx.y, tid = threadIdx.x;
@@ -163,14 +166,14 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
     w2 += (int64_t)plane * LF_C * LF_C * LF_KK;
     w3 += (int64_t)plane * LF_C * LF_C * LF_KK;
     w4 += (int64_t)plane * LF_C * LF_KK;
-    __shared__ float red[4][4];
+    __shared__ float red[4][PACK_NW];
     float m[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < LF_C * LF_KK; i += 256) m[0] = fmaxf(m[0], fabsf(w1[i]));
-    for (int i = tid; i < LF_C * LF_C * LF_KK; i += 256) {
+    for (int i = tid; i < LF_C * LF_KK; i += PACK_NT) m[0] = fmaxf(m[0], fabsf(w1[i]));
+    for (int i = tid; i < LF_C * LF_C * LF_KK; i += PACK_NT) {
         m[1] = fmaxf(m[1], fabsf(w2[i]));
         m[2] = fmaxf(m[2], fabsf(w3[i]));
     }
-    for (int i = tid; i < LF_C * LF_KK; i += 256) m[3] = fmaxf(m[3], fabsf(w4[i]));
+    for (int i = tid; i < LF_C * LF_KK; i += PACK_NT) m[3] = fmaxf(m[3], fabsf(w4[i]));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -180,7 +183,11 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
     __syncthreads();
     float sw[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sw[q] = pow2_scale(fmaxf(fmaxf(red[q][0], red[q][1]), fmaxf(red[q][2], red[q][3])));
+    for (int q = 0; q < 4; ++q) {
+        float mm = 0.f;
+        for (int i = 0; i < PACK_NW; ++i) mm = fmaxf(mm, red[q][i]);
+        sw[q] = pow2_scale(mm);
+    }
     float* dst = packed + (int64_t)plane * plane_stride + f16_off + (int64_t)orient * LF_ORIENT_FLOATS;
     _Float16* hp = reinterpret_cast<_Float16*>(dst);
     // ---- the composed kernels of this orientation (effective taps): P_block_v2.py:50-55 has no nonlinearity between
@@ -189,8 +196,8 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
     // wc[ic][u][v] = sum_oc sum_{p + q = (u, v)} w4[oc][p] w3[oc][ic][q]  (9x9);  wr[u][v] the same with w1 (1 -> 16)
     __shared__ float wc[LF_C * 81];
     __shared__ float wr[81];
-    __shared__ float redc[4];
-    for (int i = tid; i < LF_C * 81 + 81; i += 256) {
+    __shared__ float redc[PACK_NW];
+    for (int i = tid; i < LF_C * 81 + 81; i += PACK_NT) {
         const bool is_r = i >= LF_C * 81;
         const int ic = is_r ? 0 : i / 81, s = is_r ? i - LF_C * 81 : i % 81;
         const int u = s / 9, vv = s % 9;
@@ -212,13 +219,15 @@ __global__ void k_lift_f16_pack(const float* __restrict__ w1, const float* __res
     }
     __syncthreads();
     float mc = 0.f;
-    for (int i = tid; i < LF_C * 81; i += 256) mc = fmaxf(mc, fabsf(wc[i]));
+    for (int i = tid; i < LF_C * 81; i += PACK_NT) mc = fmaxf(mc, fabsf(wc[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mc = fmaxf(mc, __shfl_xor(mc, o, 64));
     if ((tid & 63) == 0) redc[tid >> 6] = mc;
     __syncthreads();
-    const float swc = pow2_scale(fmaxf(fmaxf(redc[0], redc[1]), fmaxf(redc[2], redc[3])));
-    for (int i = tid; i < LF_H_END / 2; i += 256) {          // one (hi, lo) pair per iteration
+    float mcc = 0.f;
+    for (int i = 0; i < PACK_NW; ++i) mcc = fmaxf(mcc, redc[i]);
+    const float swc = pow2_scale(mcc);
+    for (int i = tid; i < LF_H_END / 2; i += PACK_NT) {          // one (hi, lo) pair per iteration
         int rem = i;
         const int j = rem % 8; rem /= 8;
         const int lane = rem % 64; rem /= 64;
@@ -294,6 +303,9 @@ struct LfArgs {
     int nitems;                   // runs of the launch: Z * tiles_x * nseg
     int nborder;                  // the runs of the image's first / last column strip come first in the item order: items 0 .. nborder-1
     int qslot;                    // which of the work-queue counters this launch uses
+    // TRAIN: what the backward needs of this step, dense per image of the (single) view set: the source values and the skip
+    // signal (Z, h, w), t1, t2 (tanh outputs) and t3 = conv3(t2) + b3 + conv1(skip) + b1 (Z, 16, h, w)
+    float* sv_src; float* sv_skip; float* sv_t1; float* sv_t2; float* sv_t3;
 };
 // Work queue of the runs.  A workgroup starts with run blockIdx.x and takes every further one from an atomic counter, so the
 // workgroups that drew border columns (their tiles cost ~25 % more) simply take fewer runs; the border runs come first in the
@@ -532,9 +544,12 @@ struct LfPre {
 // every image.
 // SEQ: the sequential evaluation of conv3 / conv4 for every tile (debug flag 16), the check of the composed path.
 // PREC: 0 = f16x3, 1 = fp16, 2 = bf16 (see mma3)
-template <bool SEQ, int PREC>
+// TRAIN (with SEQ): the training forward -- the sequential path forms t3 explicitly, and the tile's own 16 x 32 pixels of
+// src, skip, t1, t2 and t3 are written out for the backward (what the three fp32 launches k_lift_a/b/c saved)
+template <bool SEQ, int PREC, bool TRAIN = false>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lift_fused_f16(LfArgs a) {
     static_assert(!SEQ || PREC == 0, "the sequential check path exists for the fp32-accurate arithmetic only");
+    static_assert(!TRAIN || SEQ, "the training forward needs t3: sequential path");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* S = reinterpret_cast<float*>(lds + LDS_S);
     float* RED = reinterpret_cast<float*>(lds + LDS_RED);
@@ -708,6 +723,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float v = in ? t0 * m + t1 * pre.c[k] + t2 * p : 0.f;
             S[i] = v;
             sv[k] = v;
+            if constexpr (TRAIN) {
+                if (in && sy >= 8 && sy < 8 + TH && sx >= 8 && sx < 8 + TW) {
+                    const int64_t e = zv * (int64_t)h * w + (int64_t)gy * w + gx;
+                    a.sv_skip[e] = v;
+                    a.sv_src[e] = pre.c[k];
+                }
+            }
             amax = fmaxf(amax, fabsf(v));
         }
 #pragma unroll
@@ -797,6 +819,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = tanh_scaled_masked(acc[t][q], inv1c, b1c[q], msk[t], -2.f * msk[t]);
                 timg_store<N1, PREC>(lds + LDS_T1, pq[t], oc0, v);
+                if constexpr (TRAIN) {
+                    const int r = pq[t] / R1W, c = pq[t] - r * R1W;
+                    const int gy = y0 + r - 6, gx = x0 + c - 6;
+                    if (r >= 6 && r < 6 + TH && c >= 6 && c < 6 + TW && gy < h && gx < w) {
+                        float* d = a.sv_t1 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = v[q] * (1.f / ACT_SCALE);
+                    }
+                }
             }
         }
     }
@@ -850,6 +881,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int t = ks - 8;
                 const float v[4] = {ev[4 * t], ev[4 * t + 1], ev[4 * t + 2], ev[4 * t + 3]};
                 timg_store<N2, PREC>(lds + LDS_T2, pp[t], oc0, v);
+                if constexpr (TRAIN) {
+                    const int r = pp[t] / R2W, c = pp[t] - r * R2W;
+                    const int gy = y0 + r - 4, gx = x0 + c - 4;
+                    if (r >= 4 && r < 4 + TH && c >= 4 && c < 4 + TW && gy < h && gx < w) {
+                        float* d = a.sv_t2 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = v[q] * (1.f / ACT_SCALE);
+                    }
+                }
             }
         };
         if (!(a.dbg & 2)) {
@@ -1136,6 +1176,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     t3v[it][q] = v;
                     amax = fmaxf(amax, fabsf(v));
                 }
+                if constexpr (TRAIN) {
+                    if (in && r >= 2 && r < 2 + TH && c >= 2 && c < 2 + TW) {
+                        float* d = a.sv_t3 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = t3v[it][q];
+                    }
+                }
             }
         }
 #pragma unroll
@@ -1241,7 +1288,7 @@ void lift_f16_set_stamps(void* p, int64_t nbytes) { g_lf_stamps = reinterpret_ca
 
 int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, const float* b1, const float* b3,
                   const float* b4, float* packed, int64_t plane_stride, int f16_off, int planes, hipStream_t st) {
-    hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, (unsigned)planes), dim3(256), 0, st, w1, w2, w3, w4, b1, b3, b4, packed, plane_stride, f16_off);
+    hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, (unsigned)planes), dim3(PACK_NT), 0, st, w1, w2, w3, w4, b1, b3, b4, packed, plane_stride, f16_off);
     return check_launch("lift_f16_pack");
 }
 
@@ -1254,12 +1301,29 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
 int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int64_t batch, int64_t h, int64_t w,
                    const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical,
                    float sign, float rw, hipStream_t st) {
+    return lift_f16_step_any(v, v2, nullptr, Z, batch, h, w, taps, packed, pstride, fp32_orient_floats, f16_off, vertical, sign, rw, st);
+}
+
+int lift_f16_step_train(const LiftF16Views& v, const LiftF16Saved& sv, int64_t Z, int64_t batch, int64_t h, int64_t w,
+                        const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off,
+                        int vertical, float sign, float rw, hipStream_t st) {
+    if (!(sv.src && sv.skip && sv.t1 && sv.t2 && sv.t3)) {
+        set_error("lift_f16_step_train: null saved buffer");
+        return LLDWT_EINVAL;
+    }
+    return lift_f16_step_any(v, nullptr, &sv, Z, batch, h, w, taps, packed, pstride, fp32_orient_floats, f16_off, vertical, sign, rw, st);
+}
+
+int lift_f16_step_any(const LiftF16Views& v, const LiftF16Views* v2, const LiftF16Saved* sv, int64_t Z, int64_t batch, int64_t h,
+                      int64_t w, const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off,
+                      int vertical, float sign, float rw, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)k_lift_fused_f16<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_lift_fused_f16<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_lift_fused_f16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_lift_fused_f16<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess) {
+            hipFuncSetAttribute((const void*)k_lift_fused_f16<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_lift_fused_f16<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess) {
             set_error("lift_f16_step: cannot reserve %d bytes of LDS", LDS_TOTAL2);
             return LLDWT_EHIP;
         }
@@ -1318,7 +1382,9 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
         ncu = prop.multiProcessorCount;
     }
     // the sequential evaluation hands nothing down (its T3 / D images overwrite T1 / T2)
-    const bool seq = (a.dbg & 16) != 0;
+    const bool seq = (a.dbg & 16) != 0 || sv != nullptr;
+    a.sv_src = sv ? sv->src : nullptr; a.sv_skip = sv ? sv->skip : nullptr;
+    a.sv_t1 = sv ? sv->t1 : nullptr; a.sv_t2 = sv ? sv->t2 : nullptr; a.sv_t3 = sv ? sv->t3 : nullptr;
     // run length: a tile that continues a run costs ~0.8 of a first tile; runs are dealt round-robin to one resident
     // workgroup per CU, so the launch takes rounds x (cost of a run) -- the longest run that still fills whole rounds
     int best_rl = 1;
@@ -1338,7 +1404,8 @@ int lift_f16_step2(const LiftF16Views& v, const LiftF16Views* v2, int64_t Z, int
     a.qslot = (int)(launch_seq++ & 63u);
     const unsigned grid = (unsigned)(a.nitems < ncu ? a.nitems : ncu);      // one resident workgroup per CU
     const int prec = seq ? 0 : g_precision;
-    if (seq) hipLaunchKernelGGL((k_lift_fused_f16<true, 0>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
+    if (sv) hipLaunchKernelGGL((k_lift_fused_f16<true, 0, true>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
+    else if (seq) hipLaunchKernelGGL((k_lift_fused_f16<true, 0>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
     else if (prec == 1) hipLaunchKernelGGL((k_lift_fused_f16<false, 1>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
     else if (prec == 2) hipLaunchKernelGGL((k_lift_fused_f16<false, 2>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
     else hipLaunchKernelGGL((k_lift_fused_f16<false, 0>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);

@@ -28,6 +28,12 @@ def plc_mode():
     return m
 
 
+def train_lift_f16():
+    """True when the training forward of the lifting steps runs on the fused f16x3 kernel (lldwt_train_lift_f16: lift mode f16x3
+    and LLDWT_TRAIN_LIFT != f32); the packed P/U blocks must then carry their split-fp16 section."""
+    return bool(_lib.load().lldwt_train_lift_f16())
+
+
 def set_precision(name):
     """Arithmetic of the eval path's matrix kernels (fused lifting step, tree-context pair, cgp chain): 'f16x3' (default: three
     fp16 MFMA products per fp32 MAC, fp32-level accuracy), 'fp16' or 'bf16' (ONE product per MAC on operands rounded to that

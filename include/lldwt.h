@@ -96,6 +96,11 @@ int lldwt_get_precision(void);
  * between the tiles of a column.  The caller keeps the buffer alive until it unregisters it.                      */
 int lldwt_set_diagnostics(int kind, void* stamps, int64_t nbytes, int flags);
 int lldwt_get_lift_mode(void);
+/* 1 when the TRAINING forward of the lifting steps (lldwt_lifting_forward_train / _inverse_train, C = 16, K = 5, tanh blocks)
+ * runs on the fused f16x3 kernel's sequential path, which writes (src, skip, t1, t2, t3) for the backward: lift mode 1 and the
+ * environment variable LLDWT_TRAIN_LIFT != "f32".  The packed blocks must then come from lldwt_pack_pblock (with the split-fp16
+ * section), not lldwt_pack_pblock_train. */
+int lldwt_train_lift_f16(void);
 int lldwt_pack_pblock(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                       const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
                       void* stream);
