@@ -312,6 +312,21 @@ def _pack_forward(W, nblocks):
     return out
 
 
+_BPACK_MEMO = {"key": None, "val": None}
+
+
+def _pack_backward(W, nblocks):
+    """Backward packs (transposed, mirrored weights; ops.pack_pblock_bwd) of every P/U block, (P,nblocks,2,total) like
+    _pack_forward's result, kept while the weights are unchanged (the encode and the decode backward of a step share it)."""
+    key = tuple((k, W[k].data_ptr(), W[k]._version, tuple(W[k].shape)) for k in ("w1", "w2", "w3", "w4")) + (nblocks,)
+    if _BPACK_MEMO["key"] == key:
+        return _BPACK_MEMO["val"]
+    out = torch.stack([torch.stack([ops.pack_pblock_bwd(*[W[k][b, u] for k in ("w1", "w2", "w3", "w4")]) for u in range(2)], 1)
+                       for b in range(nblocks)], 1).contiguous()
+    _BPACK_MEMO["key"], _BPACK_MEMO["val"] = key, out
+    return out
+
+
 class _LiftBackward:
     """Executes the step program in reverse over gradient buffers of the forward layout (include/lldwt.h)."""
 
@@ -326,6 +341,11 @@ class _LiftBackward:
         self.dW = {k: torch.zeros_like(v) for k, v in W.items()}
         self.packs = {}
         self.fwd_pack = _pack_forward(W, W["w1"].shape[0]) if meta["C"] == 16 else None     # (P,nblocks,2,total)
+        # tanh block, 16 channels, 5x5: the backward-data chain runs on the fused split-fp16 kernel (LLDWT_BWD_LIFT=f32: fp32 MFMA)
+        self.bwd_pack, self.taps_id = None, None
+        if meta["C"] == 16 and meta["K"] == 5 and not meta["linear"] and ops.bwd_lift_f16():
+            self.bwd_pack = _pack_backward(W, W["w1"].shape[0])
+            self.taps_id = torch.tensor([0.0, 1.0, 0.0], device=taps.device).repeat(P, 1).contiguous()
 
     def _pack(self, name, blk, u, vertical):
         key = (name, blk, u, vertical)
@@ -384,7 +404,10 @@ class _LiftBackward:
                                   view(op.buf_src, op.off_src, op.sz_src, op.sy_src, op.sx_src),
                                   base, self.P, B, h, w, self.taps[op.tap], self.dtaps[op.tap], pk, nb_ * 2 * tot,
                                   [self.dW[k][blk, u] for k in _W_KEYS], C_, K, rw, op.sign, bool(op.vertical),
-                                  m["linear"])
+                                  m["linear"],
+                                  packed_bwd=None if self.bwd_pack is None else
+                                  ctypes.c_void_p(self.bwd_pack.data_ptr() + 4 * (blk * 2 + u) * tot),
+                                  taps_id=self.taps_id)
                 continue
             g = torch.empty(self.P, B, 1, h, w, device=srcv.device, dtype=torch.float32)
             ops.lift_bwd_pre(view(op.buf_dout, op.off_dout, op.sz_dout, op.sy_dout, op.sx_dout),

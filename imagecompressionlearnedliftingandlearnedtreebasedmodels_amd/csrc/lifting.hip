@@ -1630,12 +1630,68 @@ int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, floa
 // LLDWT_WGRAD16=f32 keeps the fp32-MFMA weight gradient of the 16 -> 16 lifting convs (k_wgrad16<5>); default: split-fp16
 static const int g_wgrad16_f16 = [] { const char* e = getenv("LLDWT_WGRAD16"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
 
+// LLDWT_BWD_LIFT=f32 keeps the three fp32-MFMA backward-data launches even when a backward pack is passed
+static const int g_bwd_lift_f16 = [] { const char* e = getenv("LLDWT_BWD_LIFT"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
+extern "C" int lldwt_bwd_lift_f16(void) { return g_bwd_lift_f16 && g_lift_mode == 1; }
+
+extern "C" int64_t lldwt_pack_pblock_bwd_ws_bytes(int planes) { return (int64_t)sizeof(float) * lift_f16_bwd_scratch_floats(planes); }
+
+// the "backward pack" of a tanh P/U block (C = 16, K = 5): the transposed, mirrored weights in the forward pack's split-fp16 layout,
+// fp32 section zero (no biases in the backward chain).  packed: planes * lldwt_pblock_packed_floats(C, K) floats
+extern "C" int lldwt_pack_pblock_bwd(const float* w1, const float* w2, const float* w3, const float* w4, float* packed,
+                                     void* ws, int64_t ws_bytes, int planes, int C, int K, void* stream) {
+    LLDWT_REQUIRE(planes > 0 && C == LF_C && K == LF_K, "pack_pblock_bwd: built for C=16, K=5 (got planes=%d C=%d K=%d)", planes, C, K);
+    LLDWT_REQUIRE(w1 && w2 && w3 && w4 && packed && ws, "pack_pblock_bwd: null pointer");
+    if (ws_bytes < lldwt_pack_pblock_bwd_ws_bytes(planes)) {
+        set_error("pack_pblock_bwd: workspace %ld < %ld bytes", (long)ws_bytes, (long)lldwt_pack_pblock_bwd_ws_bytes(planes));
+        return LLDWT_EWS;
+    }
+    const PackOff o = pack_off(C, K);
+    if (hipMemsetAsync(packed, 0, sizeof(float) * (size_t)o.total * planes, (hipStream_t)stream) != hipSuccess) {
+        set_error("pack_pblock_bwd: memset failed");
+        return LLDWT_EHIP;
+    }
+    return lift_f16_pack_bwd(w1, w2, w3, w4, (float*)ws, packed, o.total, o.f16, planes, (hipStream_t)stream);
+}
+
+static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_src, const float* saved_step,
+                              int64_t planes, int64_t batch, int64_t h, int64_t w, const float* taps, float* dtaps,
+                              const float* packed, int64_t packed_plane_stride, float* dw1, float* db1, float* dw2,
+                              float* db2, float* dw3, float* db3, float* dw4, float* db4, int C, int K,
+                              float res_weight, float sign, int vertical, int linear, void* ws, int64_t ws_bytes,
+                              const float* packed_bwd, const float* taps_id, void* stream);
+
 extern "C" int lldwt_lift_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_src, const float* saved_step,
                                    int64_t planes, int64_t batch, int64_t h, int64_t w, const float* taps, float* dtaps,
                                    const float* packed, int64_t packed_plane_stride, float* dw1, float* db1, float* dw2,
                                    float* db2, float* dw3, float* db3, float* dw4, float* db4, int C, int K,
                                    float res_weight, float sign, int vertical, int linear, void* ws, int64_t ws_bytes,
                                    void* stream) {
+    return lift_step_bwd_impl(g_dst_out, g_dst_in, g_src, saved_step, planes, batch, h, w, taps, dtaps, packed, packed_plane_stride,
+                              dw1, db1, dw2, db2, dw3, db3, dw4, db4, C, K, res_weight, sign, vertical, linear, ws, ws_bytes,
+                              nullptr, nullptr, stream);
+}
+
+// the same with the backward-data chain (dt3, dpre2, dr, dsk) on the fused split-fp16 kernel's BWD mode: packed_bwd from
+// lldwt_pack_pblock_bwd (stride = the forward pack's), taps_id = (planes, 3) floats (0, 1, 0)
+extern "C" int lldwt_lift_step_bwd_f16(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_src, const float* saved_step,
+                                       int64_t planes, int64_t batch, int64_t h, int64_t w, const float* taps, float* dtaps,
+                                       const float* packed, int64_t packed_plane_stride, float* dw1, float* db1, float* dw2,
+                                       float* db2, float* dw3, float* db3, float* dw4, float* db4, int C, int K,
+                                       float res_weight, float sign, int vertical, int linear, void* ws, int64_t ws_bytes,
+                                       const float* packed_bwd, const float* taps_id, void* stream) {
+    LLDWT_REQUIRE(packed_bwd && taps_id, "lift_step_bwd_f16: null backward pack / identity taps");
+    return lift_step_bwd_impl(g_dst_out, g_dst_in, g_src, saved_step, planes, batch, h, w, taps, dtaps, packed, packed_plane_stride,
+                              dw1, db1, dw2, db2, dw3, db3, dw4, db4, C, K, res_weight, sign, vertical, linear, ws, ws_bytes,
+                              packed_bwd, taps_id, stream);
+}
+
+static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_src, const float* saved_step,
+                              int64_t planes, int64_t batch, int64_t h, int64_t w, const float* taps, float* dtaps,
+                              const float* packed, int64_t packed_plane_stride, float* dw1, float* db1, float* dw2,
+                              float* db2, float* dw3, float* db3, float* dw4, float* db4, int C, int K,
+                              float res_weight, float sign, int vertical, int linear, void* ws, int64_t ws_bytes,
+                              const float* packed_bwd, const float* taps_id, void* stream) {
     LLDWT_REQUIRE(g_dst_out.p && g_dst_in.p && g_src.p && saved_step && taps && dtaps && packed && ws,
                   "lift_step_bwd: null pointer");
     LLDWT_REQUIRE(dw1 && db1 && dw2 && db2 && dw3 && db3 && dw4 && db4, "lift_step_bwd: null gradient pointer");
@@ -1660,7 +1716,14 @@ extern "C" int lldwt_lift_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, ll
     float* dt3 = dsk + n;
     float* dpre2 = dt3 + n * C;
     float* dr = dpre2 + n * C;
-    int r = K == 5 ? launch_step_bwd<5>(g_dst_out, g_dst_in, g, dsk, dt3, dpre2, dr, t1, t2, Z, batch, h, w, packed,
+    int r;
+    if (packed_bwd && K == LF_K && C == LF_C && !linear && g_bwd_lift_f16 && g_lift_mode == 1) {
+        if ((r = lldwt_lift_bwd_pre(g_dst_out, g_dst_in, g, Z, h, w, stream))) return r;
+        const LiftF16Bwd bw{g, t1, t2, dt3, dpre2, dr, dsk};
+        const PackOff o = pack_off(C, K);
+        r = lift_f16_step_bwd(bw, Z, batch, h, w, taps_id, packed_bwd, packed_plane_stride, o.orient, o.f16, vertical, st);
+    } else
+    r = K == 5 ? launch_step_bwd<5>(g_dst_out, g_dst_in, g, dsk, dt3, dpre2, dr, t1, t2, Z, batch, h, w, packed,
                                         packed_plane_stride, vertical, linear, st)
                    : launch_step_bwd<3>(g_dst_out, g_dst_in, g, dsk, dt3, dpre2, dr, t1, t2, Z, batch, h, w, packed,
                                         packed_plane_stride, vertical, linear, st);

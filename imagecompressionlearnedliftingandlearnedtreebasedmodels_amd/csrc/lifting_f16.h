@@ -47,6 +47,15 @@ int lift_f16_step(const LiftF16Views& v, int64_t Z, int64_t batch, int64_t h, in
 // the training forward of one step on the fused kernel's sequential path: the same step, and the tile interiors of src, skip
 // (Z, h, w) and t1, t2, t3 (Z, 16, h, w) written out for the backward (what k_lift_a/b/c save on the fp32 path)
 struct LiftF16Saved { float* src; float* skip; float* t1; float* t2; float* t3; };
+// backward-data of one step on the same kernel (BWD mode): g = dL/dnet dense (Z, h, w); t1, t2 = the saved tanh outputs; out:
+// dt3, dpre2, dr (Z, 16, h, w) and dsk (Z, h, w).  packed_bwd: lift_f16_pack_bwd's buffer (fp32 section zero); taps_id: (planes, 3)
+// floats (0, 1, 0)
+struct LiftF16Bwd { const float* g; const float* t1; const float* t2; float* dt3; float* dpre2; float* dr; float* dsk; };
+int lift_f16_step_bwd(const LiftF16Bwd& b, int64_t Z, int64_t batch, int64_t h, int64_t w, const float* taps_id,
+                      const float* packed_bwd, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical, hipStream_t st);
+int lift_f16_pack_bwd(const float* w1, const float* w2, const float* w3, const float* w4, float* scratch, float* packed,
+                      int64_t plane_stride, int f16_off, int planes, hipStream_t st);
+int64_t lift_f16_bwd_scratch_floats(int planes);
 int lift_f16_step_train(const LiftF16Views& v, const LiftF16Saved& sv, int64_t Z, int64_t batch, int64_t h, int64_t w,
                         const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off,
                         int vertical, float sign, float rw, hipStream_t st);

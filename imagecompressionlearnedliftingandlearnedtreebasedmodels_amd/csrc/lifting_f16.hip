@@ -269,6 +269,16 @@ __global__ __launch_bounds__(PACK_NT) void k_lift_f16_pack(const float* __restri
         tail[16 + tid] = s4;
     }
     if (tid < 81) tail[32 + tid] = wr[tid];
+    // largest row L1 norms of conv1 and conv2: the backward mode bounds its gradient images with them (|conv(x)| <= max|x| * L1)
+    if (tid < 2 * LF_C) {
+        const int oc = tid & (LF_C - 1);
+        float l1 = 0.f;
+        if (tid < LF_C) for (int t = 0; t < LF_KK; ++t) l1 += fabsf(w1[oc * LF_KK + t]);
+        else for (int t = 0; t < LF_C * LF_KK; ++t) l1 += fabsf(w2[oc * LF_C * LF_KK + t]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) l1 = fmaxf(l1, __shfl_xor(l1, o, 64));      // over the 16 rows
+        if (oc == 0) tail[13 + (tid >> 4)] = l1;
+    }
     if (tid == 0) {          // the constant of the composed path, in the order the kernel used to sum it per tile
         float cst = b4[0];
         for (int oc = 0; oc < LF_C; ++oc) {
@@ -306,6 +316,10 @@ struct LfArgs {
     // TRAIN: what the backward needs of this step, dense per image of the (single) view set: the source values and the skip
     // signal (Z, h, w), t1, t2 (tanh outputs) and t3 = conv3(t2) + b3 + conv1(skip) + b1 (Z, 16, h, w)
     float* sv_src; float* sv_skip; float* sv_t1; float* sv_t2; float* sv_t3;
+    // BWD (backward-data of the block on the same sequential path, packed with the transposed, mirrored weights): the saved tanh
+    // outputs t1, t2 (Z, 16, h, w) whose 1 - t^2 gate the gradients; the outputs go to sv_t3 (dt3), sv_t2 (dpre2), sv_t1 (dr),
+    // sv_skip (dsk); src = g = dL/dnet as a dense (Z, h, w) tensor, taps = (0, 1, 0)
+    const float* gate1; const float* gate2;
 };
 // Work queue of the runs.  A workgroup starts with run blockIdx.x and takes every further one from an atomic counter, so the
 // workgroups that drew border columns (their tiles cost ~25 % more) simply take fewer runs; the border runs come first in the
@@ -546,10 +560,16 @@ struct LfPre {
 // PREC: 0 = f16x3, 1 = fp16, 2 = bf16 (see mma3)
 // TRAIN (with SEQ): the training forward -- the sequential path forms t3 explicitly, and the tile's own 16 x 32 pixels of
 // src, skip, t1, t2 and t3 are written out for the backward (what the three fp32 launches k_lift_a/b/c saved)
-template <bool SEQ, int PREC, bool TRAIN = false>
+// BWD (with SEQ): backward-data of the block.  With g = dL/dnet:  dt3 = conv4^T(g),  dpre2 = (1 - t2^2) conv3^T(dt3),
+// dr = (1 - t1^2) conv2^T(dpre2) + dt3,  dsk = conv1^T(dr)  -- the forward's sequential chain 1 -> 16 -> 16 -> 16 -> 1 with the
+// transposed, mirrored weights (lift_f16_pack_bwd), no biases, the tanh replaced by the gates of the SAVED t2 / t1 (t2's gate is
+// staged into the T2 image before conv2' overwrites it pixel by pixel; t1's is loaded per tile in P3), and the gradient images
+// scaled by bounds (max|g| of the tile x the row L1 norms of the pack) instead of the fixed 2^14 of tanh outputs.
+template <bool SEQ, int PREC, bool TRAIN = false, bool BWD = false>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lift_fused_f16(LfArgs a) {
     static_assert(!SEQ || PREC == 0, "the sequential check path exists for the fp32-accurate arithmetic only");
     static_assert(!TRAIN || SEQ, "the training forward needs t3: sequential path");
+    static_assert(!BWD || (SEQ && !TRAIN), "backward-data runs on the sequential path");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* S = reinterpret_cast<float*>(lds + LDS_S);
     float* RED = reinterpret_cast<float*>(lds + LDS_RED);
@@ -740,12 +760,16 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     LF_STAMP(2)
     if (!hand_down) next_item = __builtin_amdgcn_readfirstlane(*QN);      // wave-uniform: everything derived from it stays scalar
-    float s_skip;
+    float s_skip, act1 = ACT_SCALE, act2 = ACT_SCALE;       // operand scales of the T1 / T2 images
     {
         float m = RED[0];
 #pragma unroll
         for (int i = 1; i < NWAVE; ++i) m = fmaxf(m, RED[i]);
         s_skip = pow2_scale(m);
+        if constexpr (BWD) {                                  // |dt3| <= max|g| L1(conv1'), |dpre2| <= that x L1(conv2') (gates <= 1)
+            act1 = pow2_scale(m * scales[13]);
+            act2 = pow2_scale(m * scales[13] * scales[14]);
+        }
     }
     // s_skip = 2^k (|k| <= 120): its reciprocal by exponent arithmetic, exact, instead of a 10-instruction division
     const float inv1 = __int_as_float(0x7F000000 - __float_as_int(s_skip)) * isw1;
@@ -791,6 +815,24 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int q = 0; q < 4; ++q) b1c[q] = b1v[q] * TWO_LOG2E;
     const float inv1c = inv1 * TWO_LOG2E;
 
+    // ---------------- BWD: the gate of conv2' (1 - t2^2 on the 24 x 40 region, x 2^14, split like any T-image value) into the T2
+    // image: the conv2' epilogue reads the gate of a pixel from the very slot it then overwrites with dpre2.  Outside the image
+    // the value is irrelevant (those pixels are masked to 0).  (pixel, group of 4 channels) items, 3 840 of them.
+    if constexpr (BWD) {
+        for (int i = tid; i < N2 * 4; i += NTH) {
+            const int p = i >> 2, c4 = (i & 3) * 4;
+            const int r = p / R2W, c = p - r * R2W;
+            const int gy = min(max(y0 - 4 + r, 0), h - 1), gx = min(max(x0 - 4 + c, 0), w - 1);
+            const float* tp = a.gate2 + (zv * LF_C + c4) * (int64_t)h * w + (int64_t)gy * w + gx;
+            float gq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float t = tp[(int64_t)q * h * w];
+                gq[q] = __builtin_fmaf(-t, t, 1.f) * ACT_SCALE;
+            }
+            timg_store<N2, 0>(lds + LDS_T2, p, c4, gq);
+        }
+    }
     // ---------------- P1: t1 = tanh(conv1(skip) + b1) on 28 x 44.  Two tiles per iteration (independent chains for the
     // scheduler: one tile alone is a latency chain LDS -> MFMA x3 -> tanh -> split -> store); tiles past the end repeat the
     // last one (same bytes stored again)
@@ -810,15 +852,27 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int r = p / R1W, c = p - r * R1W;
                 acc[t] = conv1_tile<PREC>(s16, r * SW + c, kgoff0, kgoff1, a1h, a1l);
                 const int gy = y0 - 6 + r, gx = x0 - 6 + c;
-                msk[t] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? ACT_SCALE : 0.f;
+                msk[t] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? act1 : 0.f;
                 pq[t] = p;
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = tanh_scaled_masked(acc[t][q], inv1c, b1c[q], msk[t], -2.f * msk[t]);
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (BWD) v[q] = acc[t][q] * inv1 * msk[t];          // dt3 = conv4^T(g): no bias, no tanh
+                    else v[q] = tanh_scaled_masked(acc[t][q], inv1c, b1c[q], msk[t], -2.f * msk[t]);
+                }
                 timg_store<N1, PREC>(lds + LDS_T1, pq[t], oc0, v);
+                if constexpr (BWD) {
+                    const int r = pq[t] / R1W, c = pq[t] - r * R1W;
+                    const int gy = y0 + r - 6, gx = x0 + c - 6;
+                    if (r >= 6 && r < 6 + TH && c >= 6 && c < 6 + TW && gy < h && gx < w) {
+                        float* d = a.sv_t3 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = acc[t][q] * inv1;
+                    }
+                }
                 if constexpr (TRAIN) {
                     const int r = pq[t] / R1W, c = pq[t] - r * R1W;
                     const int gy = y0 + r - 6, gx = x0 + c - 6;
@@ -843,7 +897,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float bv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = bias[a.b2 + oc0 + q];
-        const float inv2 = (1.f / ACT_SCALE) * isw2;
+        // the T1 image's operand scale: 2^14 for tanh outputs, the bound-based power of two of the BWD mode (exact reciprocal)
+        const float inv2 = (BWD ? __int_as_float(0x7F000000 - __float_as_int(act1)) : 1.f / ACT_SCALE) * isw2;
+        const float inv_act2 = BWD ? __int_as_float(0x7F000000 - __float_as_int(act2)) : 1.f / ACT_SCALE;
         float bvc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bvc[q] = bv[q] * TWO_LOG2E;
@@ -866,21 +922,38 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // (scale + bias, tanh, mask), then split + store of each tile
         floatx4 pc[2];
         int pp[2];
-        float pin[2];                          // ACT_SCALE inside the image, 0 outside (a factor, not a branch)
+        float pin[2];                          // the image's operand scale inside the image, 0 outside (a factor, not a branch)
+        bool pdup[2] = {false, false};         // BWD: a tile past the end (repeated last tile) must not touch the image again
         float ev[8];
         auto in_image = [&](int p) {
             const int r = p / R2W, c = p - r * R2W;
             const int gy = y0 - 4 + r, gx = x0 - 4 + c;
-            return (gy >= 0 && gy < h && gx >= 0 && gx < w) ? ACT_SCALE : 0.f;
+            return (gy >= 0 && gy < h && gx >= 0 && gx < w) ? act2 : 0.f;
         };
         auto slice = [&](int ks) {
             if (ks < 8) {
                 const int t = ks >> 2, q = ks & 3;
-                ev[ks] = tanh_scaled_masked(pc[t][q], inv2c, bvc[q], pin[t], -2.f * pin[t]);
+                if constexpr (BWD) {           // dpre2 = (1 - t2^2) conv3^T(dt3): the gate waits in this value's own T2 slot
+                    const uint8_t* gp = lds + LDS_T2 + ((oc0 + q) >> 3) * (N2 * 16) + pp[t] * 16 + ((oc0 + q) & 7) * 2;
+                    const float gate = ((float)*reinterpret_cast<const _Float16*>(gp) +
+                                        (float)*reinterpret_cast<const _Float16*>(gp + 2 * N2 * 16)) * (1.f / ACT_SCALE);
+                    ev[ks] = pc[t][q] * inv2 * gate * pin[t];
+                } else {
+                    ev[ks] = tanh_scaled_masked(pc[t][q], inv2c, bvc[q], pin[t], -2.f * pin[t]);
+                }
             } else if (ks < 10) {
                 const int t = ks - 8;
                 const float v[4] = {ev[4 * t], ev[4 * t + 1], ev[4 * t + 2], ev[4 * t + 3]};
-                timg_store<N2, PREC>(lds + LDS_T2, pp[t], oc0, v);
+                if (!BWD || !pdup[t]) timg_store<N2, PREC>(lds + LDS_T2, pp[t], oc0, v);
+                if constexpr (BWD) {
+                    const int r = pp[t] / R2W, c = pp[t] - r * R2W;
+                    const int gy = y0 + r - 4, gx = x0 + c - 4;
+                    if (!pdup[t] && r >= 4 && r < 4 + TH && c >= 4 && c < 4 + TW && gy < h && gx < w) {
+                        float* d = a.sv_t2 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = v[q] * inv_act2;
+                    }
+                }
                 if constexpr (TRAIN) {
                     const int r = pp[t] / R2W, c = pp[t] - r * R2W;
                     const int gy = y0 + r - 4, gx = x0 + c - 4;
@@ -898,6 +971,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 conv16_tile2<R1W, N1, PREC>(lds + LDS_T1, b0, b1, hi_tap, ah, al, pc[0], pc[1], [](int) {});
                 pin[0] = in_image(pp[0]);
                 pin[1] = in_image(pp[1]);
+                pdup[0] = wave >= nt2;
+                pdup[1] = wave + NWAVE >= nt2;
             }
 #pragma unroll 1
             for (int it = 1; it < nit2; ++it) {
@@ -908,6 +983,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 pc[0] = n0; pc[1] = n1; pp[0] = q0; pp[1] = q1;
                 pin[0] = in_image(q0);
                 pin[1] = in_image(q1);
+                pdup[0] = wave + 16 * it >= nt2;
+                pdup[1] = wave + 16 * it + NWAVE >= nt2;
             }
             if (cont) {
                 floatx4 n0;
@@ -1156,7 +1233,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float bv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = bias[a.b3 + oc0 + q] + b1v[q];
-        const float inv3 = (1.f / ACT_SCALE) * (1.f / sw3);
+        const float inv3 = (BWD ? __int_as_float(0x7F000000 - __float_as_int(act2)) : 1.f / ACT_SCALE) * isw3;
         float amax = 0.f;
 #pragma unroll
         for (int it = 0; it < IT3; ++it) {
@@ -1170,11 +1247,27 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const floatx4 accr = conv1_tile(s16, (r + 4) * SW + c + 4, kgoff0, kgoff1, a1h, a1l);
                 const int gy = y0 - 2 + r, gx = x0 - 2 + c;
                 const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+                float gate[4] = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (BWD) {            // dr = (1 - t1^2) conv2^T(dpre2) + dt3 (accr = conv1'(g) = dt3 recomputed)
+                    const float* tp = a.gate1 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)(in ? gy : 0) * w + (in ? gx : 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float t = tp[(int64_t)q * h * w];
+                        gate[q] = __builtin_fmaf(-t, t, 1.f);
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = in ? acc[q] * inv3 + accr[q] * inv1 + bv[q] : 0.f;
+                    const float v = in ? acc[q] * inv3 * gate[q] + accr[q] * inv1 + bv[q] : 0.f;
                     t3v[it][q] = v;
                     amax = fmaxf(amax, fabsf(v));
+                }
+                if constexpr (BWD) {
+                    if (in && r >= 2 && r < 2 + TH && c >= 2 && c < 2 + TW) {
+                        float* d = a.sv_t1 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = t3v[it][q];
+                    }
                 }
                 if constexpr (TRAIN) {
                     if (in && r >= 2 && r < 2 + TH && c >= 2 && c < 2 + TW) {
@@ -1255,7 +1348,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             net = net * inv4 + bias[a.b4];
             const float skip = S[(oy + 8) * SW + ox + 8];
             const float din = din_pre;
-            vout.dout[zv * vout.dout_sz + (int64_t)gy * vout.dout_sy + (int64_t)gx * vout.dout_sx] = din + a.sign * (skip + a.rw * net);
+            if constexpr (BWD) a.sv_skip[zv * (int64_t)h * w + (int64_t)gy * w + gx] = net;       // dsk = conv1^T(dr)
+            else vout.dout[zv * vout.dout_sz + (int64_t)gy * vout.dout_sy + (int64_t)gx * vout.dout_sx] = din + a.sign * (skip + a.rw * net);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1286,6 +1380,53 @@ void split_set_precision(int p) { g_precision = p; }
 void lift_f16_set_debug(int dbg) { g_lf_dbg = dbg; }
 void lift_f16_set_stamps(void* p, int64_t nbytes) { g_lf_stamps = reinterpret_cast<unsigned long long*>(p); g_lf_stamps_bytes = p ? nbytes : 0; }
 
+// Backward-data of a P/U block = the same chain with transposed, mirrored weights (see the BWD mode of the kernel):
+//   conv1' (1 -> 16) = conv4^T: w1'[oc][tap] = w4[oc][24 - tap]          conv2' = conv3^T: w2'[oc][ic][tap] = w3[ic][oc][24 - tap]
+//   conv3' = conv2^T: w3'[oc][ic][tap] = w2[ic][oc][24 - tap]            conv4' (16 -> 1) = conv1^T: w4'[ic][tap] = w1[ic][24 - tap]
+// written per plane into scratch as [w1' | w2' | w3' | w4' | 64 zeros (the biases)], then packed like a forward block
+constexpr int BWD_SCRATCH = 2 * LF_C * LF_KK + 2 * LF_C * LF_C * LF_KK + 64;
+__global__ void k_lift_bwd_prep(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
+                                const float* __restrict__ w4, float* __restrict__ scratch) {
+    const int plane = blockIdx.x;
+    w1 += (int64_t)plane * LF_C * LF_KK;
+    w2 += (int64_t)plane * LF_C * LF_C * LF_KK;
+    w3 += (int64_t)plane * LF_C * LF_C * LF_KK;
+    w4 += (int64_t)plane * LF_C * LF_KK;
+    float* o1 = scratch + (int64_t)plane * BWD_SCRATCH;
+    float* o2 = o1 + LF_C * LF_KK;
+    float* o3 = o2 + LF_C * LF_C * LF_KK;
+    float* o4 = o3 + LF_C * LF_C * LF_KK;
+    for (int i = threadIdx.x; i < LF_C * LF_KK; i += blockDim.x) {
+        const int c = i / LF_KK, t = i - c * LF_KK;
+        o1[i] = w4[c * LF_KK + (LF_KK - 1 - t)];
+        o4[i] = w1[c * LF_KK + (LF_KK - 1 - t)];
+    }
+    for (int i = threadIdx.x; i < LF_C * LF_C * LF_KK; i += blockDim.x) {
+        const int oc = i / (LF_C * LF_KK), r = i - oc * (LF_C * LF_KK), ic = r / LF_KK, t = r - ic * LF_KK;
+        o2[i] = w3[(ic * LF_C + oc) * LF_KK + (LF_KK - 1 - t)];
+        o3[i] = w2[(ic * LF_C + oc) * LF_KK + (LF_KK - 1 - t)];
+    }
+    if (threadIdx.x < 64) o4[LF_C * LF_KK + threadIdx.x] = 0.f;
+}
+
+int lift_f16_pack_bwd(const float* w1, const float* w2, const float* w3, const float* w4, float* scratch, float* packed,
+                      int64_t plane_stride, int f16_off, int planes, hipStream_t st) {
+    hipLaunchKernelGGL(k_lift_bwd_prep, dim3((unsigned)planes), dim3(256), 0, st, w1, w2, w3, w4, scratch);
+    // the pack kernel strides its weight pointers by the forward sizes per plane; the scratch layout is per plane too, so each
+    // plane is packed by its own launch (3 planes)
+    for (int p = 0; p < planes; ++p) {
+        float* o1 = scratch + (int64_t)p * BWD_SCRATCH;
+        float* o2 = o1 + LF_C * LF_KK;
+        float* o3 = o2 + LF_C * LF_C * LF_KK;
+        float* o4 = o3 + LF_C * LF_C * LF_KK;
+        float* z = o4 + LF_C * LF_KK;                   // 64 zeros: b1, b3 (16 each), b4
+        hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, 1), dim3(PACK_NT), 0, st, o1, o2, o3, o4, z, z, z,
+                           packed + (int64_t)p * plane_stride, plane_stride, f16_off);
+    }
+    return check_launch("lift_f16_pack_bwd");
+}
+int64_t lift_f16_bwd_scratch_floats(int planes) { return (int64_t)planes * BWD_SCRATCH; }
+
 int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, const float* b1, const float* b3,
                   const float* b4, float* packed, int64_t plane_stride, int f16_off, int planes, hipStream_t st) {
     hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, (unsigned)planes), dim3(PACK_NT), 0, st, w1, w2, w3, w4, b1, b3, b4, packed, plane_stride, f16_off);
@@ -1314,16 +1455,35 @@ int lift_f16_step_train(const LiftF16Views& v, const LiftF16Saved& sv, int64_t Z
     return lift_f16_step_any(v, nullptr, &sv, Z, batch, h, w, taps, packed, pstride, fp32_orient_floats, f16_off, vertical, sign, rw, st);
 }
 
+static const LiftF16Bwd* g_bwd_call = nullptr;      // set by lift_f16_step_bwd around its call of lift_f16_step_any (host, same thread)
+
+int lift_f16_step_bwd(const LiftF16Bwd& b, int64_t Z, int64_t batch, int64_t h, int64_t w, const float* taps_id,
+                      const float* packed_bwd, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical, hipStream_t st) {
+    if (!(b.g && b.t1 && b.t2 && b.dt3 && b.dpre2 && b.dr && b.dsk && taps_id && packed_bwd)) {
+        set_error("lift_f16_step_bwd: null pointer");
+        return LLDWT_EINVAL;
+    }
+    float* gm = const_cast<float*>(b.g);
+    const LiftF16Views v{b.g, h * w, w, 1, b.g, h * w, w, 1, gm, h * w, w, 1};       // din / dout are not used by the BWD mode
+    g_bwd_call = &b;
+    const int r = lift_f16_step_any(v, nullptr, nullptr, Z, batch, h, w, taps_id, packed_bwd, pstride, fp32_orient_floats, f16_off,
+                                    vertical, 1.f, 1.f, st);
+    g_bwd_call = nullptr;
+    return r;
+}
+
 int lift_f16_step_any(const LiftF16Views& v, const LiftF16Views* v2, const LiftF16Saved* sv, int64_t Z, int64_t batch, int64_t h,
                       int64_t w, const float* taps, const float* packed, int64_t pstride, int fp32_orient_floats, int f16_off,
                       int vertical, float sign, float rw, hipStream_t st) {
+    const LiftF16Bwd* bw = g_bwd_call;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)k_lift_fused_f16<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_lift_fused_f16<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_lift_fused_f16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_lift_fused_f16<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_lift_fused_f16<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess) {
+            hipFuncSetAttribute((const void*)k_lift_fused_f16<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_lift_fused_f16<true, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess) {
             set_error("lift_f16_step: cannot reserve %d bytes of LDS", LDS_TOTAL2);
             return LLDWT_EHIP;
         }
@@ -1382,9 +1542,14 @@ int lift_f16_step_any(const LiftF16Views& v, const LiftF16Views* v2, const LiftF
         ncu = prop.multiProcessorCount;
     }
     // the sequential evaluation hands nothing down (its T3 / D images overwrite T1 / T2)
-    const bool seq = (a.dbg & 16) != 0 || sv != nullptr;
+    const bool seq = (a.dbg & 16) != 0 || sv != nullptr || bw != nullptr;
     a.sv_src = sv ? sv->src : nullptr; a.sv_skip = sv ? sv->skip : nullptr;
     a.sv_t1 = sv ? sv->t1 : nullptr; a.sv_t2 = sv ? sv->t2 : nullptr; a.sv_t3 = sv ? sv->t3 : nullptr;
+    a.gate1 = nullptr; a.gate2 = nullptr;
+    if (bw) {
+        a.sv_skip = bw->dsk; a.sv_t1 = bw->dr; a.sv_t2 = bw->dpre2; a.sv_t3 = bw->dt3;
+        a.gate1 = bw->t1; a.gate2 = bw->t2;
+    }
     // run length: a tile that continues a run costs ~0.8 of a first tile; runs are dealt round-robin to one resident
     // workgroup per CU, so the launch takes rounds x (cost of a run) -- the longest run that still fills whole rounds
     int best_rl = 1;
@@ -1404,7 +1569,8 @@ int lift_f16_step_any(const LiftF16Views& v, const LiftF16Views* v2, const LiftF
     a.qslot = (int)(launch_seq++ & 63u);
     const unsigned grid = (unsigned)(a.nitems < ncu ? a.nitems : ncu);      // one resident workgroup per CU
     const int prec = seq ? 0 : g_precision;
-    if (sv) hipLaunchKernelGGL((k_lift_fused_f16<true, 0, true>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
+    if (bw) hipLaunchKernelGGL((k_lift_fused_f16<true, 0, false, true>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
+    else if (sv) hipLaunchKernelGGL((k_lift_fused_f16<true, 0, true>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
     else if (seq) hipLaunchKernelGGL((k_lift_fused_f16<true, 0>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
     else if (prec == 1) hipLaunchKernelGGL((k_lift_fused_f16<false, 1>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);
     else if (prec == 2) hipLaunchKernelGGL((k_lift_fused_f16<false, 2>), dim3(grid), dim3(NTH), LDS_TOTAL2, st, a);

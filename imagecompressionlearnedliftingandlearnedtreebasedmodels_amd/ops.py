@@ -133,6 +133,23 @@ def pack_pblock(w1, b1, w2, b2, w3, b3, w4, b4, train=False):
     return out
 
 
+def bwd_lift_f16():
+    """True when lift_step_bwd with a backward pack runs the fused split-fp16 backward-data launch (include/lldwt.h)."""
+    return bool(_lib.load().lldwt_bwd_lift_f16())
+
+
+def pack_pblock_bwd(w1, w2, w3, w4):
+    """Backward pack of a tanh P_block_v2 (planes, 16, ., 5, 5): transposed, mirrored weights in the forward pack's layout."""
+    lib = _lib.load()
+    planes, Cc, _, K, _ = w1.shape
+    out = torch.empty(planes, pblock_packed_floats(Cc, K), device=w1.device, dtype=torch.float32)
+    nb = lib.lldwt_pack_pblock_bwd_ws_bytes(planes)
+    ws = workspace(nb, w1.device)
+    check(lib.lldwt_pack_pblock_bwd(_chk(w1), _chk(w2), _chk(w3), _chk(w4), _chk(out), C.c_void_p(ws.data_ptr()), nb, planes,
+                                    Cc, K, _stream()), "pack_pblock_bwd")
+    return out
+
+
 def view_of(t, z, h, w, offset=0, sz=None, sy=None, sx=1):
     """lldwt_view over the storage of ``t`` (element offsets/strides)."""
     return View(C.c_void_p(t.data_ptr() + 4 * offset), sz if sz is not None else h * w, sy if sy is not None else w, sx)
@@ -770,13 +787,20 @@ def lift_bwd_fin(g, dsk, srcv, g_src, Z, batch, h, w, taps, dtaps, vertical, sig
 
 
 def lift_step_bwd(g_dst_out, g_dst_in, g_src, saved_step, P, B, h, w, taps, dtaps, packed, packed_plane_stride, dW, Cc, K,
-                  rw, sign, vertical, linear):
+                  rw, sign, vertical, linear, packed_bwd=None, taps_id=None):
     """Whole backward of one lifting step (include/lldwt.h lldwt_lift_step_bwd).  g_*: lldwt_views over the gradient
     buffers; packed: forward pack of this step's block (pointer already offset to the block); dW: the 8 gradient
-    tensors (w1,b1,...,w4,b4) of the block, each (P,...), accumulated in place."""
+    tensors (w1,b1,...,w4,b4) of the block, each (P,...), accumulated in place.  packed_bwd (pointer, offset like packed) +
+    taps_id ((P,3) of (0,1,0)): the backward-data chain on the fused split-fp16 kernel (lldwt_lift_step_bwd_f16)."""
     lib = _lib.load()
     nb = lib.lldwt_lift_step_bwd_ws_bytes(P * B, h, w, Cc)
     ws = workspace(nb, taps.device)
+    if packed_bwd is not None:
+        check(lib.lldwt_lift_step_bwd_f16(g_dst_out, g_dst_in, g_src, _chk(saved_step), P, B, h, w, _chk(taps), _chk(dtaps),
+                                          packed, packed_plane_stride, *[_chk(t) for t in dW], Cc, K, float(rw), float(sign),
+                                          int(bool(vertical)), int(bool(linear)), C.c_void_p(ws.data_ptr()), nb, packed_bwd,
+                                          _chk(taps_id), _stream()), "lift_step_bwd_f16")
+        return
     check(lib.lldwt_lift_step_bwd(g_dst_out, g_dst_in, g_src, _chk(saved_step), P, B, h, w, _chk(taps), _chk(dtaps),
                                   packed, packed_plane_stride, *[_chk(t) for t in dW], Cc, K, float(rw), float(sign),
                                   int(bool(vertical)), int(bool(linear)), C.c_void_p(ws.data_ptr()), nb, _stream()),

@@ -206,6 +206,22 @@ int lldwt_lift_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_
                         float* dw3, float* db3, float* dw4, float* db4, int C, int K, float res_weight, float sign,
                         int vertical, int linear, void* ws, int64_t ws_bytes, void* stream);
 
+/* The same with the backward-data chain (dt3 = conv4^T g, dpre2 = tanh'(t2) conv3^T dt3, dr = tanh'(t1) conv2^T dpre2 + dt3,
+ * dsk = conv1^T dr) as ONE launch of the fused split-fp16 lifting kernel in its backward mode (C == 16, K == 5, tanh block;
+ * anything else, LLDWT_BWD_LIFT=f32 or lift mode f32 takes the launches of lldwt_lift_step_bwd).  packed_bwd: the "backward
+ * pack" of the block from lldwt_pack_pblock_bwd -- transposed, mirrored weights in the forward pack's layout, same plane stride;
+ * taps_id: (planes, 3) floats (0, 1, 0).  lldwt_bwd_lift_f16(): 1 when the fused backward is what this entry runs. */
+int lldwt_bwd_lift_f16(void);
+int64_t lldwt_pack_pblock_bwd_ws_bytes(int planes);
+int lldwt_pack_pblock_bwd(const float* w1, const float* w2, const float* w3, const float* w4, float* packed, void* ws,
+                          int64_t ws_bytes, int planes, int C, int K, void* stream);
+int lldwt_lift_step_bwd_f16(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_view g_src, const float* saved_step,
+                            int64_t planes, int64_t batch, int64_t h, int64_t w, const float* taps, float* dtaps,
+                            const float* packed, int64_t packed_plane_stride, float* dw1, float* db1, float* dw2, float* db2,
+                            float* dw3, float* db3, float* dw4, float* db4, int C, int K, float res_weight, float sign,
+                            int vertical, int linear, void* ws, int64_t ws_bytes, const float* packed_bwd,
+                            const float* taps_id, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * SubbandAutoEncoder (lifting_dwt_nets.py:99-110): per-coefficient scalar MLP 1 -> Hd -> Hd -> Hd -> 1, tanh
  * between, grouped 1x1 convs (groups == channels).  x,y: (Z,C,h,w).  Parameters per plane, PyTorch layouts:

@@ -355,3 +355,59 @@ def test_colour_and_loss_backward():
     t = gu.dev(torch.rand(3, 4, 5, generator=g)).requires_grad_(True)
     (ag.SumFn.apply(t) * 0.25).sum().backward()
     assert maxdiff(t.grad.cpu(), torch.full((3, 4, 5), 0.25)) < 1e-7
+
+
+@pytest.mark.parametrize("hw", [(40, 72), (19, 33), (96, 160)])
+@pytest.mark.parametrize("vertical", [True, False])
+def test_lift_step_backward_on_the_fused_kernel(hw, vertical):
+    """lldwt_lift_step_bwd_f16 (backward-data chain as one launch of the fused split-fp16 kernel, transposed + mirrored weights
+    from lldwt_pack_pblock_bwd) against lldwt_lift_step_bwd (three fp32-MFMA launches) on the same saved intermediates: the
+    chain's four gradients, the step's input gradient, tap and weight gradients.  Split-fp16 class: 2e-5 of each tensor's
+    maximum (the lifting-forward tests compare both classes with the CPU restatement; P_block_v2.py:40-55 is what they
+    differentiate)."""
+    import ctypes
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    P, B, C, K = 3, 2, 16, 5
+    h, w = hw
+    Z, n = P * B, P * B * h * w
+    W = {"w1": torch.randn(P, C, 1, K, K) * 0.2, "b1": torch.randn(P, C) * 0.1, "w2": torch.randn(P, C, C, K, K) * 0.05,
+         "b2": torch.randn(P, C) * 0.1, "w3": torch.randn(P, C, C, K, K) * 0.05, "b3": torch.randn(P, C) * 0.1,
+         "w4": torch.randn(P, 1, C, K, K) * 0.05, "b4": torch.randn(P, 1) * 0.1}
+    W = {k: v.to(dev).contiguous() for k, v in W.items()}
+    keys = ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")
+    packed = ops.pack_pblock(*[W[k] for k in keys])
+    bpack = ops.pack_pblock_bwd(W["w1"], W["w2"], W["w3"], W["w4"])
+    taps = torch.tensor([0.1, 0.8, 0.1], device=dev).repeat(P, 1).contiguous()
+    tid = torch.tensor([0.0, 1.0, 0.0], device=dev).repeat(P, 1).contiguous()
+    saved = torch.empty(n * (2 + 3 * C), device=dev)
+    saved[:2 * n] = torch.randn(2 * n, device=dev)
+    saved[2 * n:2 * n + 2 * n * C] = torch.tanh(2 * torch.randn(2 * n * C, device=dev))        # t1, t2 (some saturated)
+    saved[2 * n + 2 * n * C:] = torch.randn(n * C, device=dev)
+    gout = torch.randn(Z, h, w, device=dev) * 3.0
+    if not ops.bwd_lift_f16():
+        pytest.skip("LLDWT_BWD_LIFT=f32 / lift mode f32: the fused backward is switched off")
+    res = []
+    for fused in (False, True):
+        gdin, gsrc = torch.zeros(Z, h, w, device=dev), torch.zeros(Z, h, w, device=dev)
+        dW = [torch.zeros_like(W[k]) for k in keys]
+        dtaps = torch.zeros_like(taps)
+        v = lambda t: ops.View(ctypes.c_void_p(t.data_ptr()), h * w, w, 1)
+        ops.lift_step_bwd(v(gout), v(gdin), v(gsrc), saved, P, B, h, w, taps, dtaps, ctypes.c_void_p(packed.data_ptr()),
+                          packed.shape[1], dW, C, K, 0.5, -1.0, vertical, False,
+                          packed_bwd=ctypes.c_void_p(bpack.data_ptr()) if fused else None, taps_id=tid if fused else None)
+        torch.cuda.synchronize()
+        ws = ops.workspace(0, dev).view(torch.float32)
+        chain = {"dsk": ws[n:2 * n], "dt3": ws[2 * n:2 * n + n * C], "dpre2": ws[2 * n + n * C:2 * n + 2 * n * C],
+                 "dr": ws[2 * n + 2 * n * C:2 * n + 3 * n * C]}
+        out = {k: t.clone() for k, t in chain.items()}
+        out.update(gdin=gdin, gsrc=gsrc, dtaps=dtaps)
+        out.update({"d" + k: t for k, t in zip(keys, dW)})
+        res.append(out)
+    ref, got = res
+    assert torch.equal(ref["gdin"], got["gdin"])
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        assert scale > 0, k
+        assert float((ref[k] - got[k]).abs().max()) <= 2e-5 * scale, (k, float((ref[k] - got[k]).abs().max()), scale)
