@@ -291,8 +291,8 @@ struct Wg16Args {
     const float* dy;      // (planes, batch, 16, h, w)
     float* dw;            // (planes, 16, 16, 5, 5)
     float* db;            // (planes, 16) or null
-    const float* sy;      // (planes, 64) max-|dy| slots
-    int batch, h, w, slices, chunks_x, chunks_y;
+    const float* sy;      // max-|dy| slots: 64 per plane, plane stride sy_stride
+    int batch, h, w, slices, chunks_x, chunks_y, sy_stride;
     float alpha;
     int8_t tap_of[25];    // tap (ty * 5 + tx) -> position inside a dW[oc][ic] block (row passes store (kh, kw) swapped)
 };
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int64_t hw = (int64_t)h * w;
     const int nchunk_img = a.chunks_x * a.chunks_y;
     const int nchunk = a.batch * nchunk_img;
-    float ay = a.sy[plane * 64 + lane];
+    float ay = a.sy[plane * a.sy_stride + lane];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ay = fmaxf(ay, __shfl_xor(ay, o, 64));
     const float sY = pow2_scale_for(ay);
@@ -537,15 +537,19 @@ extern "C" int lldwt_conv3x3_wgrad_f16x3(const float* x, const float* dy, float*
 // 16 -> 16 5x5 weight gradient of a P/U block on the fp16 matrix cores (see k_wgrad16_f16x3).  x must be bounded by 1 in magnitude
 // (the tanh outputs t1 / t2); slots_ws: planes * 64 floats.  tap_of: 25 entries, tap (ty*5+tx) -> position inside dW[oc][ic].
 namespace lldwt {
-int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int64_t planes, int64_t batch,
-                  int64_t h, int64_t w_, float alpha, const int8_t* tap_of, hipStream_t st) {
+int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int64_t slots_stride, bool slots_ready,
+                  int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, const int8_t* tap_of, hipStream_t st) {
     LLDWT_REQUIRE(x && dy && dw && slots_ws && tap_of, "wgrad16_f16x3: null pointer");
     LLDWT_REQUIRE(planes > 0 && planes <= 65535 && batch > 0 && h > 0 && w_ >= 4 && w_ % 4 == 0, "wgrad16_f16x3: bad dims");
     LLDWT_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dy) & 15) == 0, "wgrad16_f16x3: x and dy must be 16-byte aligned");
-    int r = lldwt_absmax_slots(dy, planes, batch * 16 * h * w_, slots_ws, st);
-    if (r) return r;
+    // slots_ready: the producer of dy left its per-plane |max| in the slots already (64 per plane, plane stride slots_stride)
+    if (!slots_ready) {
+        LLDWT_REQUIRE(slots_stride == 64, "wgrad16_f16x3: the |max| pass writes 64 slots per plane");
+        int r = lldwt_absmax_slots(dy, planes, batch * 16 * h * w_, slots_ws, st);
+        if (r) return r;
+    }
     Wg16Args a;
-    a.x = x; a.dy = dy; a.dw = dw; a.db = dbias; a.sy = slots_ws;
+    a.x = x; a.dy = dy; a.dw = dw; a.db = dbias; a.sy = slots_ws; a.sy_stride = (int)slots_stride;
     a.batch = (int)batch; a.h = (int)h; a.w = (int)w_; a.alpha = alpha;
     a.chunks_x = (int)cdiv(w_, G_CW);
     a.chunks_y = (int)cdiv(h, G_CR);
@@ -577,5 +581,5 @@ extern "C" int lldwt_wgrad16_f16x3(const float* x, const float* dy, float* dw, f
                                    int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw, void* stream) {
     int8_t tap_of[25];
     for (int t = 0; t < 25; ++t) tap_of[t] = (int8_t)(swap_hw ? (t % 5) * 5 + t / 5 : t);
-    return lldwt::wgrad16_f16x3(x, dy, dw, dbias, slots_ws, planes, batch, h, w_, alpha, tap_of, (hipStream_t)stream);
+    return lldwt::wgrad16_f16x3(x, dy, dw, dbias, slots_ws, 64, false, planes, batch, h, w_, alpha, tap_of, (hipStream_t)stream);
 }

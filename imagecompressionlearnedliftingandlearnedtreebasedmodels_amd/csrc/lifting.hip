@@ -1594,8 +1594,8 @@ extern "C" int lldwt_lift_bwd_fin(const float* g, const float* dsk, const float*
 }
 
 extern "C" int64_t lldwt_lift_step_bwd_ws_bytes(int64_t Z, int64_t h, int64_t w, int C) {
-    // g | dsk | dt3 | dpre2 | dr | 64 |dY|-max slots per plane (split-fp16 weight gradient of the 16 -> 16 convs)
-    return (int64_t)sizeof(float) * (Z * h * w * (2 + 3 * (int64_t)C) + 64 * Z);
+    // g | dsk | dt3 | dpre2 | dr | 2 x 64 |dY|-max slots per plane (split-fp16 weight gradient of the 16 -> 16 convs)
+    return (int64_t)sizeof(float) * (Z * h * w * (2 + 3 * (int64_t)C) + 128 * Z);
 }
 
 template <int K>
@@ -1624,8 +1624,8 @@ static int launch_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, float* g, 
 }
 
 namespace lldwt {
-int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int64_t planes, int64_t batch,
-                  int64_t h, int64_t w_, float alpha, const int8_t* tap_of, hipStream_t st);
+int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int64_t slots_stride, bool slots_ready,
+                  int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, const int8_t* tap_of, hipStream_t st);
 }
 // LLDWT_WGRAD16=f32 keeps the fp32-MFMA weight gradient of the 16 -> 16 lifting convs (k_wgrad16<5>); default: split-fp16
 static const int g_wgrad16_f16 = [] { const char* e = getenv("LLDWT_WGRAD16"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
@@ -1717,9 +1717,19 @@ static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_v
     float* dpre2 = dt3 + n * C;
     float* dr = dpre2 + n * C;
     int r;
+    float* slots = dr + n * C;          // 128 per plane: max |dt3|, max |dpre2| (the split-fp16 weight gradient's dY scales)
+    const bool wg16 = K == 5 && !linear && g_wgrad16_f16 && w % 4 == 0 && batch * h * w >= 500000;
+    bool slots_ready = false;
     if (packed_bwd && K == LF_K && C == LF_C && !linear && g_bwd_lift_f16 && g_lift_mode == 1) {
         if ((r = lldwt_lift_bwd_pre(g_dst_out, g_dst_in, g, Z, h, w, stream))) return r;
-        const LiftF16Bwd bw{g, t1, t2, dt3, dpre2, dr, dsk};
+        if (wg16) {                     // the fused launch leaves both maxima in the slots: no pass over dt3 / dpre2 for them
+            if (hipMemsetAsync(slots, 0, sizeof(float) * 128 * planes, st) != hipSuccess) {
+                set_error("lift_step_bwd: memset failed");
+                return LLDWT_EHIP;
+            }
+            slots_ready = true;
+        }
+        const LiftF16Bwd bw{g, t1, t2, dt3, dpre2, dr, dsk, slots_ready ? slots : nullptr};
         const PackOff o = pack_off(C, K);
         r = lift_f16_step_bwd(bw, Z, batch, h, w, taps_id, packed_bwd, packed_plane_stride, o.orient, o.f16, vertical, st);
     } else
@@ -1740,16 +1750,17 @@ static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_v
     desc(C, 1);
     if ((r = lldwt_conv2d_wgrad_ex(t3, g, dw4, db4, &d, planes, batch, h, w, alpha, swap, stream))) return r;
     desc(C, C);
-    if (K == 5 && !linear && g_wgrad16_f16 && w % 4 == 0 && batch * h * w >= 500000) {
+    if (wg16) {
         // conv3 / conv2: their inputs t2 / t1 are tanh outputs (|x| <= 1): split-fp16 on the fp16 matrix cores (conv_wgrad_f16x3.hip).
         // Only where it wins (measured, 3 planes x 8 images: 360 vs 513 us at 256 x 512, 231 vs 272 at 256 x 256, but 173 vs 146 at
         // 128 x 256 and 146 vs 70 at 128 x 128: below ~0.5 Mpixel per plane the per-plane |dY|-max pass and the 6 400 float atomics
         // of every workgroup weigh more than the matrix work saved)
         int8_t tap_of[25];
         for (int t = 0; t < 25; ++t) tap_of[t] = (int8_t)(swap ? (t % 5) * 5 + t / 5 : t);
-        float* slots = dr + n * C;
-        if ((r = wgrad16_f16x3(t2, dt3, dw3, db3, slots, planes, batch, h, w, alpha, tap_of, st))) return r;
-        if ((r = wgrad16_f16x3(t1, dpre2, dw2, db2, slots, planes, batch, h, w, alpha, tap_of, st))) return r;
+        const int64_t ss = slots_ready ? 128 : 64;
+        if ((r = wgrad16_f16x3(t2, dt3, dw3, db3, slots, ss, slots_ready, planes, batch, h, w, alpha, tap_of, st))) return r;
+        if ((r = wgrad16_f16x3(t1, dpre2, dw2, db2, slots + (slots_ready ? 64 : 0), ss, slots_ready, planes, batch, h, w, alpha, tap_of,
+                               st))) return r;
     } else {
         if ((r = lldwt_conv2d_wgrad_ex(t2, dt3, dw3, db3, &d, planes, batch, h, w, alpha, swap, stream))) return r;
         if ((r = lldwt_conv2d_wgrad_ex(t1, dpre2, dw2, db2, &d, planes, batch, h, w, alpha, swap, stream))) return r;

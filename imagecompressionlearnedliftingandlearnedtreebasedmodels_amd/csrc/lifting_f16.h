@@ -50,7 +50,9 @@ struct LiftF16Saved { float* src; float* skip; float* t1; float* t2; float* t3; 
 // backward-data of one step on the same kernel (BWD mode): g = dL/dnet dense (Z, h, w); t1, t2 = the saved tanh outputs; out:
 // dt3, dpre2, dr (Z, 16, h, w) and dsk (Z, h, w).  packed_bwd: lift_f16_pack_bwd's buffer (fp32 section zero); taps_id: (planes, 3)
 // floats (0, 1, 0)
-struct LiftF16Bwd { const float* g; const float* t1; const float* t2; float* dt3; float* dpre2; float* dr; float* dsk; };
+// mx: null, or (planes, 2, 64) floats zeroed by the caller: the launch leaves max |dt3| (row 0) and max |dpre2| (row 1) of every
+// plane spread over the 64 slots (atomic max), the form lldwt::wgrad16_f16x3 takes its dY maximum in
+struct LiftF16Bwd { const float* g; const float* t1; const float* t2; float* dt3; float* dpre2; float* dr; float* dsk; float* mx; };
 int lift_f16_step_bwd(const LiftF16Bwd& b, int64_t Z, int64_t batch, int64_t h, int64_t w, const float* taps_id,
                       const float* packed_bwd, int64_t pstride, int fp32_orient_floats, int f16_off, int vertical, hipStream_t st);
 int lift_f16_pack_bwd(const float* w1, const float* w2, const float* w3, const float* w4, float* scratch, float* packed,

@@ -320,6 +320,7 @@ struct LfArgs {
     // outputs t1, t2 (Z, 16, h, w) whose 1 - t^2 gate the gradients; the outputs go to sv_t3 (dt3), sv_t2 (dpre2), sv_t1 (dr),
     // sv_skip (dsk); src = g = dL/dnet as a dense (Z, h, w) tensor, taps = (0, 1, 0)
     const float* gate1; const float* gate2;
+    float* mx;                  // BWD: (planes, 2, 64) |.|-max slots of dt3 and dpre2 (atomic max; zeroed by the host), or null
 };
 // Work queue of the runs.  A workgroup starts with run blockIdx.x and takes every further one from an atomic counter, so the
 // workgroups that drew border columns (their tiles cost ~25 % more) simply take fewer runs; the border runs come first in the
@@ -840,6 +841,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // a continuing tile computes rows 12..27 only (tiles 33..76)
         const int nt1 = cont ? NT1C : NT1, tb1 = NT1 - nt1;
         const int nit1 = (nt1 + 2 * NWAVE - 1) / (2 * NWAVE);           // 5, or 3
+        float mx1 = 0.f;                        // BWD: max |dt3| x act1 over this wave's values (for the weight gradient's dY scale)
 #pragma unroll 1
         for (int it = 0; it < nit1; ++it) {
             floatx4 acc[2];
@@ -860,7 +862,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if constexpr (BWD) v[q] = acc[t][q] * inv1 * msk[t];          // dt3 = conv4^T(g): no bias, no tanh
+                    if constexpr (BWD) {          // dt3 = conv4^T(g): no bias, no tanh
+                        v[q] = acc[t][q] * inv1 * msk[t];
+                        mx1 = fmaxf(mx1, fabsf(v[q]));
+                    }
                     else v[q] = tanh_scaled_masked(acc[t][q], inv1c, b1c[q], msk[t], -2.f * msk[t]);
                 }
                 timg_store<N1, PREC>(lds + LDS_T1, pq[t], oc0, v);
@@ -882,6 +887,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = v[q] * (1.f / ACT_SCALE);
                     }
                 }
+            }
+        }
+        if constexpr (BWD) {
+            if (a.mx) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx1 = fmaxf(mx1, __shfl_xor(mx1, o, 64));
+                mx1 *= __int_as_float(0x7F000000 - __float_as_int(act1));
+                if (lane == 0 && mx1 > 0.f)     // >= 0: integer order == float order
+                    atomicMax(reinterpret_cast<int*>(a.mx) + plane * 128 + ((item_i + wave) & 63), __float_as_int(mx1));
             }
         }
     }
@@ -925,6 +939,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float pin[2];                          // the image's operand scale inside the image, 0 outside (a factor, not a branch)
         bool pdup[2] = {false, false};         // BWD: a tile past the end (repeated last tile) must not touch the image again
         float ev[8];
+        float mx2 = 0.f;                       // BWD: max |dpre2| x act2 over this wave's values
         auto in_image = [&](int p) {
             const int r = p / R2W, c = p - r * R2W;
             const int gy = y0 - 4 + r, gx = x0 - 4 + c;
@@ -938,6 +953,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const float gate = ((float)*reinterpret_cast<const _Float16*>(gp) +
                                         (float)*reinterpret_cast<const _Float16*>(gp + 2 * N2 * 16)) * (1.f / ACT_SCALE);
                     ev[ks] = pc[t][q] * inv2 * gate * pin[t];
+                    mx2 = fmaxf(mx2, fabsf(ev[ks]));
                 } else {
                     ev[ks] = tanh_scaled_masked(pc[t][q], inv2c, bvc[q], pin[t], -2.f * pin[t]);
                 }
@@ -999,6 +1015,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 10; ++ks) slice(ks);
+            }
+        }
+        if constexpr (BWD) {
+            if (a.mx) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx2 = fmaxf(mx2, __shfl_xor(mx2, o, 64));
+                mx2 *= inv_act2;
+                if (lane == 0 && mx2 > 0.f)
+                    atomicMax(reinterpret_cast<int*>(a.mx) + plane * 128 + 64 + ((item_i + wave) & 63), __float_as_int(mx2));
             }
         }
     }
@@ -1383,19 +1408,21 @@ void lift_f16_set_stamps(void* p, int64_t nbytes) { g_lf_stamps = reinterpret_ca
 // Backward-data of a P/U block = the same chain with transposed, mirrored weights (see the BWD mode of the kernel):
 //   conv1' (1 -> 16) = conv4^T: w1'[oc][tap] = w4[oc][24 - tap]          conv2' = conv3^T: w2'[oc][ic][tap] = w3[ic][oc][24 - tap]
 //   conv3' = conv2^T: w3'[oc][ic][tap] = w2[ic][oc][24 - tap]            conv4' (16 -> 1) = conv1^T: w4'[ic][tap] = w1[ic][24 - tap]
-// written per plane into scratch as [w1' | w2' | w3' | w4' | 64 zeros (the biases)], then packed like a forward block
+// written into scratch as [w1' of every plane | w2' | w3' | w4' | 64 zeros per plane (the biases)] -- the layout of stacked forward
+// parameters --, then packed like a forward block by one launch
 constexpr int BWD_SCRATCH = 2 * LF_C * LF_KK + 2 * LF_C * LF_C * LF_KK + 64;
 __global__ void k_lift_bwd_prep(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
                                 const float* __restrict__ w4, float* __restrict__ scratch) {
-    const int plane = blockIdx.x;
+    const int plane = blockIdx.x, planes = gridDim.x;
     w1 += (int64_t)plane * LF_C * LF_KK;
     w2 += (int64_t)plane * LF_C * LF_C * LF_KK;
     w3 += (int64_t)plane * LF_C * LF_C * LF_KK;
     w4 += (int64_t)plane * LF_C * LF_KK;
-    float* o1 = scratch + (int64_t)plane * BWD_SCRATCH;
-    float* o2 = o1 + LF_C * LF_KK;
-    float* o3 = o2 + LF_C * LF_C * LF_KK;
-    float* o4 = o3 + LF_C * LF_C * LF_KK;
+    float* o1 = scratch + (int64_t)plane * LF_C * LF_KK;
+    float* o2 = scratch + (int64_t)planes * LF_C * LF_KK + (int64_t)plane * LF_C * LF_C * LF_KK;
+    float* o3 = o2 + (int64_t)planes * LF_C * LF_C * LF_KK;
+    float* o4 = scratch + (int64_t)planes * (LF_C * LF_KK + 2 * LF_C * LF_C * LF_KK) + (int64_t)plane * LF_C * LF_KK;
+    float* z = scratch + (int64_t)planes * (2 * LF_C * LF_KK + 2 * LF_C * LF_C * LF_KK) + plane * 64;
     for (int i = threadIdx.x; i < LF_C * LF_KK; i += blockDim.x) {
         const int c = i / LF_KK, t = i - c * LF_KK;
         o1[i] = w4[c * LF_KK + (LF_KK - 1 - t)];
@@ -1406,23 +1433,19 @@ __global__ void k_lift_bwd_prep(const float* __restrict__ w1, const float* __res
         o2[i] = w3[(ic * LF_C + oc) * LF_KK + (LF_KK - 1 - t)];
         o3[i] = w2[(ic * LF_C + oc) * LF_KK + (LF_KK - 1 - t)];
     }
-    if (threadIdx.x < 64) o4[LF_C * LF_KK + threadIdx.x] = 0.f;
+    if (threadIdx.x < 64) z[threadIdx.x] = 0.f;
 }
 
 int lift_f16_pack_bwd(const float* w1, const float* w2, const float* w3, const float* w4, float* scratch, float* packed,
                       int64_t plane_stride, int f16_off, int planes, hipStream_t st) {
     hipLaunchKernelGGL(k_lift_bwd_prep, dim3((unsigned)planes), dim3(256), 0, st, w1, w2, w3, w4, scratch);
-    // the pack kernel strides its weight pointers by the forward sizes per plane; the scratch layout is per plane too, so each
-    // plane is packed by its own launch (3 planes)
-    for (int p = 0; p < planes; ++p) {
-        float* o1 = scratch + (int64_t)p * BWD_SCRATCH;
-        float* o2 = o1 + LF_C * LF_KK;
-        float* o3 = o2 + LF_C * LF_C * LF_KK;
-        float* o4 = o3 + LF_C * LF_C * LF_KK;
-        float* z = o4 + LF_C * LF_KK;                   // 64 zeros: b1, b3 (16 each), b4
-        hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, 1), dim3(PACK_NT), 0, st, o1, o2, o3, o4, z, z, z,
-                           packed + (int64_t)p * plane_stride, plane_stride, f16_off);
-    }
+    float* o1 = scratch;
+    float* o2 = o1 + (int64_t)planes * LF_C * LF_KK;
+    float* o3 = o2 + (int64_t)planes * LF_C * LF_C * LF_KK;
+    float* o4 = o3 + (int64_t)planes * LF_C * LF_C * LF_KK;
+    float* z = o4 + (int64_t)planes * LF_C * LF_KK;     // 64 zeros per plane: b1, b3 (16 per plane) and b4 (1 per plane) all read zeros
+    hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, (unsigned)planes), dim3(PACK_NT), 0, st, o1, o2, o3, o4, z, z, z, packed,
+                       plane_stride, f16_off);
     return check_launch("lift_f16_pack_bwd");
 }
 int64_t lift_f16_bwd_scratch_floats(int planes) { return (int64_t)planes * BWD_SCRATCH; }
@@ -1545,10 +1568,11 @@ int lift_f16_step_any(const LiftF16Views& v, const LiftF16Views* v2, const LiftF
     const bool seq = (a.dbg & 16) != 0 || sv != nullptr || bw != nullptr;
     a.sv_src = sv ? sv->src : nullptr; a.sv_skip = sv ? sv->skip : nullptr;
     a.sv_t1 = sv ? sv->t1 : nullptr; a.sv_t2 = sv ? sv->t2 : nullptr; a.sv_t3 = sv ? sv->t3 : nullptr;
-    a.gate1 = nullptr; a.gate2 = nullptr;
+    a.gate1 = nullptr; a.gate2 = nullptr; a.mx = nullptr;
     if (bw) {
         a.sv_skip = bw->dsk; a.sv_t1 = bw->dr; a.sv_t2 = bw->dpre2; a.sv_t3 = bw->dt3;
         a.gate1 = bw->t1; a.gate2 = bw->t2;
+        a.mx = bw->mx;
     }
     // run length: a tile that continues a run costs ~0.8 of a first tile; runs are dealt round-robin to one resident
     // workgroup per CU, so the launch takes rounds x (cost of a run) -- the longest run that still fills whole rounds
