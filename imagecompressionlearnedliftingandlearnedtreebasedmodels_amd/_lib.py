@@ -138,6 +138,8 @@ SIGNATURES = {
     "lldwt_ycc_to_rgb_bwd": (_i, [_p, _p, _i64, _i64, _i64, _p]),
     "lldwt_quantize": (_i, [_p, _p, _p, _i64, _p]),
     "lldwt_factorized_rate": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
+    "lldwt_factorized_table": (_i, [_p, _p, _i64, _i, _p]),
+    "lldwt_factorized_rate_tab": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
     "lldwt_factorized_rate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i, _i64, _p]),
     "lldwt_pmf_to_quantized_cdf": (_i, [_p, _i, _i, _p]),
     "lldwt_rans_encode": (_i64, [_p, _p, _i64, _p, C.c_int32, C.c_int32, _p, _p, _p, _i64]),

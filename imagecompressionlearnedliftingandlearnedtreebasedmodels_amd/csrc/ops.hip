@@ -416,6 +416,45 @@ __device__ __forceinline__ void block_accumulate(double v, double* out) {
 }
 
 // ------------------------------------------------------------------------------------------ Gaussian rate
+// erfc without branches (the library erfcf picks one of several range forms per lane: a wave with mixed arguments runs them all,
+// ~70 vector instructions; this is ~35).  For a = |x|: (1 + 2a) exp(a^2) erfc(a) - 1 is a smooth function of q = (a - 2) / (a + 2)
+// on [-1, 0.668] (a <= 10.05, beyond which erfc underflows fp32); a degree-9 polynomial fitted at 400 Chebyshev nodes against
+// scipy.special.erfcx in double (fit error 1.6e-8 relative).  The two reciprocals are the hardware's (1 ulp) followed by one
+// residual step each; exp(-a^2) = 2^(-h) (1 - l ln 2) with h + l = a^2 log2(e) carried in two floats and (a^2 rounded) - a^2
+// folded in at the end.  Relative error <= 2.3e-7 over [0, 9.1] (2 M points against scipy erfc; erfc(9.1) = 7e-38).
+__device__ __forceinline__ float erfc_fast(float x) {
+    const float a = fabsf(x);
+    float r = __builtin_amdgcn_rcpf(a + 2.f);
+    float q = __builtin_fmaf(-4.f, r, 1.f);                        // (a - 2) / (a + 2) = 1 - 4 / (a + 2)
+    const float t0 = __builtin_fmaf(q + 1.f, -2.f, a);
+    q = __builtin_fmaf(r, __builtin_fmaf(-a, q, t0), q);            // + residual / (a + 2)
+    float p = -4.095828658e-04f;
+    p = __builtin_fmaf(p, q, -1.241535299e-03f);
+    p = __builtin_fmaf(p, q, 1.320674849e-03f);
+    p = __builtin_fmaf(p, q, 8.642993991e-03f);
+    p = __builtin_fmaf(p, q, -8.061684272e-03f);
+    p = __builtin_fmaf(p, q, -5.420781631e-02f);
+    p = __builtin_fmaf(p, q, 1.640555406e-01f);
+    p = __builtin_fmaf(p, q, -1.660310709e-01f);
+    p = __builtin_fmaf(p, q, -9.276399062e-02f);
+    p = __builtin_fmaf(p, q, 2.769783880e-01f);
+    r = __builtin_amdgcn_rcpf(__builtin_fmaf(2.f, a, 1.f));
+    const float g = __builtin_fmaf(p, r, r);                       // (p + 1) / (1 + 2a)
+    const float e = __builtin_fmaf(__builtin_fmaf(g, -a, 0.5f), 2.f, p - g);
+    const float sc = __builtin_fmaf(e, r, g);                      // exp(a^2) erfc(a)
+    const float s = a * a;
+    const float ds = __builtin_fmaf(-a, a, s);                     // s - a^2, exact
+    const float L = 1.4426950408889634f;
+    const float h = s * L;
+    float l = __builtin_fmaf(s, L, -h);
+    l = __builtin_fmaf(s, 1.9259629911e-08f, l);                   // log2(e) - (float)log2(e)
+    float ex = __builtin_amdgcn_exp2f(-h);
+    ex = __builtin_fmaf(-ex, l * 0.6931471805599453f, ex);
+    float res = __builtin_fmaf(sc, ex, sc * ex * ds);
+    res = a > 10.0546875f ? 0.f : res;
+    return x < 0.f ? 2.f - res : res;
+}
+
 // compressai GaussianConditional.forward/_likelihood as called at LiftingBasedDWT_net.py:334,345,364,832
 // grid: x over the pixels of one channel plane (4 per lane when aligned), y over (image, channel) -- no per-element
 // division (the first version's two 64-bit divisions per element cost more than the two erfc)
@@ -428,11 +467,15 @@ __global__ __launch_bounds__(256) void k_gauss_rate(const float* __restrict__ x,
         v = train ? xv + nz : rintf(xv - mu) + mu;
         const float a = fabsf(v - mu);
         const float s = fmaxf(sg, 0.11f);
-        const float cst = -0.70710678118654752440f;
-        const float up = 0.5f * erfcf(cst * ((0.5f - a) / s));
-        const float lo = 0.5f * erfcf(cst * ((-0.5f - a) / s));
+        // one reciprocal (v_rcp_f32 + a Newton step: < 1 ulp) instead of two IEEE divisions; the hardware log2 (1 ulp): the
+        // likelihood moves by a few 1e-7 relative, the bits by < 1e-6 (parity bar 1e-4)
+        float rs = __builtin_amdgcn_rcpf(s);
+        rs = __builtin_fmaf(__builtin_fmaf(-s, rs, 1.f), rs, rs);
+        const float k = -0.70710678118654752440f * rs;
+        const float up = 0.5f * erfc_fast(k * (0.5f - a));
+        const float lo = 0.5f * erfc_fast(k * (-0.5f - a));
         const float lik = fmaxf(up - lo, 1e-9f);
-        b = -log2f(lik);
+        b = -__builtin_amdgcn_logf(lik);
     };
     const bool train = noise != nullptr;
     for (int64_t zc = blockIdx.y; zc < ZC; zc += gridDim.y) {
@@ -447,20 +490,35 @@ __global__ __launch_bounds__(256) void k_gauss_rate(const float* __restrict__ x,
         const bool vec = (hw & 3) == 0 && ((((uintptr_t)xp) | ((uintptr_t)ps) | ((uintptr_t)(bp ? bp : xp)) |
                                             ((uintptr_t)(qp ? qp : xp)) | ((uintptr_t)(np ? np : xp))) & 15) == 0;
         if (vec) {
-            for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < (hw >> 2); p += (int64_t)gridDim.x * blockDim.x) {
-                const float4 xv = reinterpret_cast<const float4*>(xp)[p];
-                const float4 sg = reinterpret_cast<const float4*>(ps)[p];
-                const float4 mu = reinterpret_cast<const float4*>(pm)[p];
-                float4 nz = {0.f, 0.f, 0.f, 0.f};
-                if (train) nz = reinterpret_cast<const float4*>(np)[p];
+            // two 16-byte groups per lane and iteration: the six (eight) loads of both are issued before the first erfc
+            const int64_t n4 = hw >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+            for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n4; p += 2 * stride) {
+                const int64_t p1 = p + stride;
+                const bool two = p1 < n4;
+                const int64_t pb = two ? p1 : p;
+                const float4 xa = reinterpret_cast<const float4*>(xp)[p], xb = reinterpret_cast<const float4*>(xp)[pb];
+                const float4 sa = reinterpret_cast<const float4*>(ps)[p], sb = reinterpret_cast<const float4*>(ps)[pb];
+                const float4 ma = reinterpret_cast<const float4*>(pm)[p], mb = reinterpret_cast<const float4*>(pm)[pb];
+                float4 na = {0.f, 0.f, 0.f, 0.f}, nb = na;
+                if (train) { na = reinterpret_cast<const float4*>(np)[p]; nb = reinterpret_cast<const float4*>(np)[pb]; }
                 float4 b, v;
-                one(xv.x, sg.x, mu.x, nz.x, train, b.x, v.x);
-                one(xv.y, sg.y, mu.y, nz.y, train, b.y, v.y);
-                one(xv.z, sg.z, mu.z, nz.z, train, b.z, v.z);
-                one(xv.w, sg.w, mu.w, nz.w, train, b.w, v.w);
+                one(xa.x, sa.x, ma.x, na.x, train, b.x, v.x);
+                one(xa.y, sa.y, ma.y, na.y, train, b.y, v.y);
+                one(xa.z, sa.z, ma.z, na.z, train, b.z, v.z);
+                one(xa.w, sa.w, ma.w, na.w, train, b.w, v.w);
                 if (bp) reinterpret_cast<float4*>(bp)[p] = b;
                 if (qp) reinterpret_cast<float4*>(qp)[p] = v;
-                local += (double)b.x + (double)b.y + (double)b.z + (double)b.w;
+                float part = (b.x + b.y) + (b.z + b.w);
+                if (two) {
+                    one(xb.x, sb.x, mb.x, nb.x, train, b.x, v.x);
+                    one(xb.y, sb.y, mb.y, nb.y, train, b.y, v.y);
+                    one(xb.z, sb.z, mb.z, nb.z, train, b.z, v.z);
+                    one(xb.w, sb.w, mb.w, nb.w, train, b.w, v.w);
+                    if (bp) reinterpret_cast<float4*>(bp)[p1] = b;
+                    if (qp) reinterpret_cast<float4*>(qp)[p1] = v;
+                    part += (b.x + b.y) + (b.z + b.w);
+                }
+                local += (double)part;             // eight values of at most ~30 bits each: fp32 partial, fp64 running sum
             }
         } else {
             for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
@@ -555,15 +613,8 @@ __device__ __forceinline__ float eb_logits(const float* __restrict__ e, float v)
     return o + q[3];
 }
 
-__global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict__ x, const float* __restrict__ eb,
-                                                         const float* __restrict__ noise, float* __restrict__ bits,
-                                                         float* __restrict__ qout, double* __restrict__ bit_sum,
-                                                         int batch, int C, int64_t hw) {
-    __shared__ float e[LLDWT_EB_FLOATS + 5];
-    const int c = blockIdx.y;
-    const int64_t z = blockIdx.z;
-    const int plane = (int)(z / batch);
-    const float* src = eb + ((int64_t)plane * C + c) * LLDWT_EB_FLOATS;
+// raw packed parameters of one (plane, channel) -> the processed ones in LDS (softplus of the matrices, tanh of the factors)
+__device__ __forceinline__ void eb_process(const float* __restrict__ src, float* e) {
     if (threadIdx.x < LLDWT_EB_FLOATS) {
         const int i = threadIdx.x;
         float v = src[i];
@@ -576,28 +627,55 @@ __global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict
         else if (is_f) v = tanhf(v);
         e[i] = v;
     }
+}
+__device__ __forceinline__ float eb_bits(const float* e, float v) {
+    const float lower = eb_logits(e, v - 0.5f);
+    const float upper = eb_logits(e, v + 0.5f);
+    const float sm = lower + upper;
+    const float sign = sm > 0.f ? -1.f : (sm < 0.f ? 1.f : 0.f);
+    const float su = 1.f / (1.f + expf(-sign * upper));
+    const float sl = 1.f / (1.f + expf(-sign * lower));
+    const float lik = fmaxf(fabsf(su - sl), 1e-9f);
+    return -log2f(lik);
+}
+constexpr int EB_TR = 127;                                       // integer offsets -127 .. 127 around the median come from a table
+
+// the eval table of every (plane, channel): bits of median + o for o = -127 .. 127 (256 floats per row, the last unused).
+// Depends on the parameters only: the host keeps it while they are unchanged (compressai's update() keeps its CDFs the same way)
+__global__ __launch_bounds__(256) void k_factorized_table(const float* __restrict__ eb, float* __restrict__ table) {
+    __shared__ float e[LLDWT_EB_FLOATS + 5];
+    eb_process(eb + (int64_t)blockIdx.x * LLDWT_EB_FLOATS, e);
+    __syncthreads();
+    table[(int64_t)blockIdx.x * 256 + threadIdx.x] =
+        threadIdx.x < 2 * EB_TR + 1 ? eb_bits(e, (float)((int)threadIdx.x - EB_TR) + e[58]) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict__ x, const float* __restrict__ eb,
+                                                         const float* __restrict__ noise, float* __restrict__ bits,
+                                                         float* __restrict__ qout, double* __restrict__ bit_sum,
+                                                         int batch, int C, int64_t hw, const float* __restrict__ table) {
+    __shared__ float e[LLDWT_EB_FLOATS + 5];
+    const int c = blockIdx.y;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / batch);
+    eb_process(eb + ((int64_t)plane * C + c) * LLDWT_EB_FLOATS, e);
+    constexpr int TR = EB_TR;
+    __shared__ float tab[2 * TR + 1];
+    if (table && threadIdx.x < 2 * TR + 1) tab[threadIdx.x] = table[((int64_t)plane * C + c) * 256 + threadIdx.x];
     __syncthreads();
     const float med = e[58];
     const int64_t base = (z * C + c) * hw;
     double local = 0;
-    auto bits_of = [&](float v) {
-        const float lower = eb_logits(e, v - 0.5f);
-        const float upper = eb_logits(e, v + 0.5f);
-        const float sm = lower + upper;
-        const float sign = sm > 0.f ? -1.f : (sm < 0.f ? 1.f : 0.f);
-        const float su = 1.f / (1.f + expf(-sign * upper));
-        const float sl = 1.f / (1.f + expf(-sign * lower));
-        const float lik = fmaxf(fabsf(su - sl), 1e-9f);
-        return -log2f(lik);
-    };
+    auto bits_of = [&](float v) { return eb_bits(e, v); };
     if (!noise) {
         // Eval: v = round(x - median) + median takes one value per integer offset, so the 24 tanh + 2 exp + log of the
         // chain are evaluated ONCE per offset and channel into an LDS table (the same arithmetic as the direct path, so the
         // values are identical) and the element loop is load -> round -> table -> store: HBM-bound, 16 bytes per lane.
-        constexpr int TR = 127;                                  // offsets -127 .. 127 from the table, the rest direct
-        __shared__ float tab[2 * TR + 1];
-        if (threadIdx.x < 2 * TR + 1) tab[threadIdx.x] = bits_of((float)((int)threadIdx.x - TR) + med);
-        __syncthreads();
+        // With a precomputed table (k_factorized_table; lldwt_factorized_rate_tab) the workgroup only copies its row.
+        if (!table) {
+            if (threadIdx.x < 2 * TR + 1) tab[threadIdx.x] = bits_of((float)((int)threadIdx.x - TR) + med);
+            __syncthreads();
+        }
         auto one = [&](float xv, float& b, float& q) {
             const float r = rintf(xv - med);
             q = r + med;
@@ -930,9 +1008,14 @@ extern "C" int lldwt_gauss_rate(const float* x, const float* params, const float
                                 double* bit_sum, int64_t Z, int C, int64_t hw, void* stream) {
     LLDWT_REQUIRE(x && params && Z > 0 && C > 0 && hw > 0, "gauss_rate: bad arguments");
     const int64_t ZC = Z * C;
-    int64_t gx = cdiv(hw, 1024);
+    // at most 16 workgroups per CU in all (each ends in one double atomic on bit_sum: thousands of them on one address
+    // serialise), every lane with two or more 16-byte loads per operand to issue
+    int64_t gy = ZC > 65535 ? 65535 : ZC;
+    int64_t gx = cdiv(hw, 2048);                           // two 16-byte groups per lane
+    const int64_t cap = (int64_t)lldwt_num_cus() * 16;
+    if (gx * gy > cap) gx = cdiv(cap, gy);
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
-    hipLaunchKernelGGL(k_gauss_rate, dim3((unsigned)gx, (unsigned)(ZC > 65535 ? 65535 : ZC)), dim3(256), 0, (hipStream_t)stream, x, params, noise, bits, qout,
+    hipLaunchKernelGGL(k_gauss_rate, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, x, params, noise, bits, qout,
                        bit_sum, C, hw, ZC);
     return check_launch("gauss_rate");
 }
@@ -952,8 +1035,27 @@ extern "C" int lldwt_factorized_rate(const float* x, const float* eb, const floa
     if (gx > 1024) gx = 1024;
     dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
     hipLaunchKernelGGL(k_factorized_rate, grid, dim3(256), 0, (hipStream_t)stream, x, eb, noise, bits, qout, bit_sum,
-                       (int)batch, C, hw);
+                       (int)batch, C, hw, (const float*)nullptr);
     return check_launch("factorized_rate");
+}
+extern "C" int lldwt_factorized_table(const float* eb, float* table, int64_t planes, int C, void* stream) {
+    LLDWT_REQUIRE(eb && table && planes > 0 && C > 0 && planes * C <= 65535, "factorized_table: bad arguments");
+    hipLaunchKernelGGL(k_factorized_table, dim3((unsigned)(planes * C)), dim3(256), 0, (hipStream_t)stream, eb, table);
+    return check_launch("factorized_table");
+}
+extern "C" int lldwt_factorized_rate_tab(const float* x, const float* eb, const float* table, float* bits, float* qout,
+                                         double* bit_sum, int64_t planes, int64_t batch, int C, int64_t hw, void* stream) {
+    LLDWT_REQUIRE(x && eb && table && planes > 0 && batch > 0 && C > 0 && hw > 0, "factorized_rate_tab: bad arguments");
+    LLDWT_REQUIRE(planes * batch <= 65535 && C <= 65535, "factorized_rate_tab: grid too large");
+    // no table to build per workgroup: smaller slices (two 16-byte loads per lane), about 8 workgroups per CU in all
+    int64_t gx = cdiv(hw, 2048);
+    const int64_t cap = (int64_t)lldwt_num_cus() * 8, rows = (int64_t)C * planes * batch;
+    if (gx * rows > cap) gx = cdiv(cap, rows);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_factorized_rate, grid, dim3(256), 0, (hipStream_t)stream, x, eb, (const float*)nullptr, bits, qout,
+                       bit_sum, (int)batch, C, hw, table);
+    return check_launch("factorized_rate_tab");
 }
 extern "C" int lldwt_sq_err_sum(const float* a, const float* b, int64_t n, double* out, void* stream) {
     LLDWT_REQUIRE(a && b && out && n > 0, "sq_err_sum: bad arguments");

@@ -610,12 +610,15 @@ def _ae_train(aes, x, decode):
 def _lift_params(nets):
     """taps (4,P,3) and the 8 stacked P/U tensors (nblocks,2,P,...) WITH autograd history to the module parameters."""
     nb = len(nets[0].P_blocks)
-    taps = torch.stack([_tstack(nets, lambda n, j=j: n.preProcessingList[j].weight.reshape(3)) for j in range(4)], 0)
+    # one stack (one copy kernel) per stacked tensor, viewed to its nested shape -- not a stack of stacks of stacks
+    P = len(nets)
+    taps = torch.stack([n.preProcessingList[j].weight.reshape(3) for j in range(4) for n in nets], 0).view(4, P, 3)
     Wt = []
     for cn in ("conv1", "conv2", "conv3", "conv4"):
         for attr in ("weight", "bias"):
-            Wt.append(torch.stack([torch.stack([_tstack(nets, lambda n, k=kind, b=b: getattr(getattr(getattr(n, k)[b], cn), attr))
-                                                for kind in ("P_blocks", "U_blocks")], 0) for b in range(nb)], 0).contiguous())
+            flat = [getattr(getattr(getattr(n, kind)[b], cn), attr) for b in range(nb) for kind in ("P_blocks", "U_blocks")
+                    for n in nets]
+            Wt.append(torch.stack(flat, 0).view(nb, 2, P, *flat[0].shape))
     n0 = nets[0]
     meta = dict(levels=n0.waveletLevel, C=n0.depth_scale, K=n0.conv_filter_size, rw=n0.res_connection_weight,
                 linear=n0.linearityflag != 1, different=n0.blockprop != "same")

@@ -676,6 +676,9 @@ def cgp_bwd(dparams, h1, h2, h3, packed_bwd, dims, groups):
     return dcat, d1, d2, d3
 
 
+_EB_TABLE = {"key": None, "tab": None, "eb": None}
+
+
 def factorized_rate(x, eb, noise=None, bit_sum=None):
     """x: (P,B,C,h,w); eb: (P,C,59) packed EntropyBottleneck parameters -> (bits, q)."""
     P, B, Cc, h, w = x.shape
@@ -683,6 +686,16 @@ def factorized_rate(x, eb, noise=None, bit_sum=None):
     bits = torch.empty_like(x)
     q = torch.empty_like(x)
     bs = C.c_void_p(0) if bit_sum is None else C.c_void_p(bit_sum.data_ptr())
+    if noise is None and not eb.requires_grad:
+        # eval: the per-offset bit table depends on the parameters only -- kept while `eb` is the same tensor at the same version
+        key = (eb.data_ptr(), eb._version, tuple(eb.shape), eb.device)
+        if _EB_TABLE["key"] != key:
+            tab = torch.empty(P, Cc, 256, device=eb.device, dtype=torch.float32)
+            check(_lib.load().lldwt_factorized_table(_chk(eb), _chk(tab), P, Cc, _stream()), "factorized_table")
+            _EB_TABLE["key"], _EB_TABLE["tab"], _EB_TABLE["eb"] = key, tab, eb      # eb kept: its address cannot be reused
+        check(_lib.load().lldwt_factorized_rate_tab(_chk(x), _chk(eb), _chk(_EB_TABLE["tab"]), _chk(bits), _chk(q), bs, P, B,
+                                                    Cc, h * w, _stream()), "factorized_rate_tab")
+        return bits, q
     check(_lib.load().lldwt_factorized_rate(_chk(x), _chk(eb), _opt(noise), _chk(bits), _chk(q), bs, P, B, Cc, h * w,
                                             _stream()), "factorized_rate")
     return bits, q

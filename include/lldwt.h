@@ -501,6 +501,15 @@ int lldwt_cgp_bwd(const float* dparams, const float* h1, const float* h2, const 
 int lldwt_factorized_rate(const float* x, const float* eb, const float* noise, float* bits, float* qout,
                           double* bit_sum, int64_t planes, int64_t batch, int C, int64_t hw, void* stream);
 
+/* Eval with the per-offset table precomputed: lldwt_factorized_table writes, for every (plane, channel), the bits of
+ * median + o for the integer offsets o = -127 .. 127 (table: planes * C rows of 256 floats) -- the values the kernel of
+ * lldwt_factorized_rate builds per workgroup, by the same code; it depends on the parameters only (compressai's update() keeps
+ * its quantised CDFs the same way, entropy_models.py:206-240).  lldwt_factorized_rate_tab is the eval form of
+ * lldwt_factorized_rate reading that table: identical results, no table build in front of every workgroup's stream. */
+int lldwt_factorized_table(const float* eb, float* table, int64_t planes, int C, void* stream);
+int lldwt_factorized_rate_tab(const float* x, const float* eb, const float* table, float* bits, float* qout, double* bit_sum,
+                              int64_t planes, int64_t batch, int C, int64_t hw, void* stream);
+
 /* Backward of lldwt_factorized_rate (training, v = x + noise): dx (Z,C,hw) and deb (planes,C,59) += gradient wrt the RAW
  * packed parameters (softplus' / tanh' applied; median slot stays 0).  deb is accumulated with atomics: zero it first. */
 int lldwt_factorized_rate_bwd(const float* x, const float* eb, const float* noise, const float* gbits, float* dx,

@@ -215,6 +215,21 @@ def test_factorized_rate():
         oq, lik = entropy.entropy_bottleneck_forward(x[p], sds[p], "p%d.e." % p, False)
         assert maxdiff(q[p].cpu(), oq) < 1e-6
         assert maxdiff(bits[p].cpu(), -torch.log2(lik)) < 2e-4
+    # the call above read the per-offset table precomputed once per parameter version (lldwt_factorized_table +
+    # lldwt_factorized_rate_tab); a parameter tensor that requires grad takes the kernel that builds the table per workgroup
+    # (lldwt_factorized_rate): the same code evaluates the entries, the results are the same bits.  Values beyond the table
+    # (|x - median| > 127) take the direct chain in both.
+    xb = gu.dev(x).clone()
+    xb[0, 0, 0, 0, :4] = torch.tensor([300.0, -250.5, 127.4, -128.6], device=xb.device)
+    b_tab, q_tab = ops.factorized_rate(xb, gu.dev(eb))
+    b_ker, q_ker = ops.factorized_rate(xb, gu.dev(eb).requires_grad_(True))
+    assert torch.equal(b_tab, b_ker) and torch.equal(q_tab, q_ker)
+    eb2 = gu.dev(eb)
+    b0, _ = ops.factorized_rate(xb, eb2)
+    eb2[:, :, 58] += 0.25                                   # in-place update of the medians: the cached table must not survive it
+    b1, _ = ops.factorized_rate(xb, eb2)
+    b1k, _ = ops.factorized_rate(xb, eb2.clone().requires_grad_(True))
+    assert not torch.equal(b0, b1) and torch.equal(b1, b1k)
 
 
 def test_cdf97_vs_pywt_and_round_trip():

@@ -1,0 +1,41 @@
+"""Debug: which ATen ops (count, device time, Python call site) run in one training step besides the C-ABI launches."""
+import collections
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.agents.liftingDWT_agent import LiftingBasedDWTAgent
+from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd.utils.config import make_config
+
+dev = torch.device("cuda", 0)
+c = dict(bench.CONFIGS[2])
+x = torch.rand(c["batch"], 3, c["H"], c["W"], device=dev)
+cfg = make_config(dwtlevels=c["levels"], mode="train", batch_size=x.shape[0], patch_size=x.shape[2], seed=1337,
+                  netType=c["netType"], entropy_layer=c["entropy_layer"])
+torch.manual_seed(1337)
+agent = LiftingBasedDWTAgent(cfg)
+agent.model.train()
+for _ in range(2):
+    agent.train_step(x, allreduce=False)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    agent.train_step(x, allreduce=False)
+    torch.cuda.synchronize()
+ev = prof.events()
+agg = collections.defaultdict(lambda: [0, 0.0])
+for e in ev:
+    if not e.name.startswith("aten::") or e.device_time_total <= 0 and e.self_device_time_total <= 0:
+        continue
+    if e.self_device_time_total <= 0:
+        continue
+    st = [s for s in (e.stack or []) if "imagecompression" in s or "bench" in s or "autograd" in s]
+    site = " <- ".join(s.split("/")[-1] for s in st[:3])
+    k = (e.name, site)
+    agg[k][0] += 1
+    agg[k][1] += e.self_device_time_total
+tot = sum(v[1] for v in agg.values())
+print("ATen device time in one training step: %.2f ms over %d ops" % (tot / 1e3, sum(v[0] for v in agg.values())))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    print("%7.1f us %5d  %-22s %s" % (v[1], v[0], k[0], k[1]))
