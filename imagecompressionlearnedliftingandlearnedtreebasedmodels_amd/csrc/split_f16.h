@@ -55,6 +55,15 @@ __device__ __forceinline__ f16_t mma32(const h8_t& a, const h8_t& b, const f16_t
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
 }
+// the 16x16x32 shape
+typedef float f4_t __attribute__((ext_vector_type(4)));
+template <int PREC>
+__device__ __forceinline__ f4_t mma16(const h8_t& a, const h8_t& b, const f4_t& acc) {
+    if constexpr (PREC == 2)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
 // 8 fp32 values -> 8 fp16 (PREC 1) or bf16 (PREC 2) operands, round to nearest
 template <int PREC>
 __device__ __forceinline__ h8_t cvt8(const float (&v)[8]) {

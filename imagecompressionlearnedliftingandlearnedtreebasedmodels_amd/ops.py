@@ -452,6 +452,11 @@ def cgp16_params(plc, xq, packed16, K, tap_mask):
     return params
 
 
+def plc_shape():
+    """MFMA shape of the split-fp16 3x3 conv kernels in this process: 32 (32x32x16, default) or 16 (LLDWT_PLC_SHAPE=16)."""
+    return 16 if _lib.load().lldwt_plc_shape16() else 32
+
+
 def conv_f16x3_pack(w):
     """(P,cout,cin,3,3) fp32 -> packed split-fp16 weights (uint8 tensor (P, bytes)) for conv3x3_f16x3."""
     lib = _lib.load()

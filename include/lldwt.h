@@ -357,6 +357,9 @@ int lldwt_conv3x3_f16in(const void* x16, float* y, const void* packed, const flo
  *   packed1 = lldwt_plc_fused_pack1(w1 (planes,cmid,3,3,3), b1 (planes,cmid)), cmid <= 256
  *   packed2 = lldwt_conv_f16x3_pack(w2 (planes,cout,cmid,3,3));  bias2 (planes,cout) or NULL                              */
 int64_t lldwt_plc_fused_pack1_bytes(int cmid);
+/* 1 when this process packs and runs the split-fp16 3x3 conv kernels in the 16x16x32 MFMA shape (LLDWT_PLC_SHAPE=16, read when
+ * the library loads), 0 for the default 32x32x16. */
+int lldwt_plc_shape16(void);
 int lldwt_plc_fused_pack1(const float* w1, const float* b1, void* packed1, int cmid, int64_t planes, void* stream);
 int lldwt_plc_fused(const float* parent, float* y, const void* packed1, const void* packed2, const float* bias2, int cmid,
                     int cout, int act, int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream);

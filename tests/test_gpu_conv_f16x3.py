@@ -212,3 +212,25 @@ def test_fused_pair_random_shapes():
         worst = max(worst, d)
         assert d < 6e-6, (case, P, B, cmid, cout, hp, wp, act, d)      # two fp32-accurate paths: a few 1e-6 apart
     print("\n[plc_fused] vs the fp32 two-launch engine over 16 random shapes: worst relative difference %.3g" % worst)
+
+
+def test_shape_flag_follows_the_environment():
+    import os
+    assert _ops().plc_shape() == (16 if os.environ.get("LLDWT_PLC_SHAPE") == "16" else 32)
+
+
+def test_the_16x16x32_kernels_pass_this_file():
+    """LLDWT_PLC_SHAPE=16 packs the weights for, and launches, the v_mfma_f32_16x16x32_f16 variants of the conv kernels (a process
+    wide choice read when the library loads; the default 32x32x16 is the faster one on this path).  One child process runs this
+    file's forward tests with it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("LLDWT_PLC_SHAPE"):
+        pytest.skip("already inside the child run")
+    env = dict(os.environ, LLDWT_PLC_SHAPE="16")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "operand_maps or accuracy_is_fp32 or random_shapes or shape_flag"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
