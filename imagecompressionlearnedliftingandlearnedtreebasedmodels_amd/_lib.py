@@ -91,6 +91,8 @@ SIGNATURES = {
     "lldwt_bwd_lift_f16": (_i, []),
     "lldwt_pack_pblock_bwd_ws_bytes": (_i64, [_i]),
     "lldwt_pack_pblock_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
+    "lldwt_subband_mlp_bwd_w_ws_bytes": (_i64, [_i64, _i, _i64]),
+    "lldwt_subband_mlp_bwd_w": (_i, [_p, _p, _p, _i64, _i64, _i, _i64, _i] + [_p] * 7 + [_p] * 8 + [_p, _i64, _p]),
     "lldwt_subband_mlp_bwd": (_i, [_p] * 9 + [_i64, _i64, _i, _i64, _i] + [_p] * 7 + [_p]),
     "lldwt_subband_mlp": (_i, [_p, _p, _i64, _i64, _i, _i64, _i] + [_p] * 8 + [_i, _p]),
     "lldwt_conv_packed_floats": (_i64, [C.POINTER(ConvDesc)]),

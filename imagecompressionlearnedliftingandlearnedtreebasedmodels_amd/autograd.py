@@ -7,6 +7,7 @@ HIP kernel behind the C-ABI (include/lldwt.h).  The reference gets its backward 
   * Gaussian rate            = closed-form d/dx, d/dsigma, d/dmu with both LowerBound gradient rules
 """
 import ctypes
+import os
 
 import torch
 
@@ -81,6 +82,9 @@ class GaussRateFn(torch.autograd.Function):
         return dx, dparams, None
 
 
+_MLP_WGRAD_FUSED = os.environ.get("LLDWT_MLP_WGRAD", "fused") != "gemm"
+
+
 class SubbandMlpFn(torch.autograd.Function):
     """SubbandAutoEncoder MLP (1 -> 32 -> 32 -> 32 -> 1 per coefficient, grouped 1x1 convs) as one forward kernel and one
     backward-data kernel, both on the matrix cores with the activations in registers; the four weight gradients are the
@@ -96,6 +100,11 @@ class SubbandMlpFn(torch.autograd.Function):
         x, w0, b0, w1, b1, w2, b2, w3 = ctx.saved_tensors
         Cc = x.shape[2]
         gy = gy.contiguous()
+        if _MLP_WGRAD_FUSED:
+            # one launch: backward-data and the eight parameter gradients (nothing but x, gy, gx in HBM); LLDWT_MLP_WGRAD=gemm
+            # keeps the form below (hidden activations and gradients written out, four grouped 1x1 weight-gradient GEMMs)
+            gx, grads = ops.subband_mlp_bwd_w(x, gy, w0, b0, w1, b1, w2, b2, w3)
+            return (gx, *grads)
         gx, hs, ds = ops.subband_mlp_bwd(x, gy, w0, b0, w1, b1, w2, b2, w3)
         grads = []
         for xin, dy, w in ((x, ds[0], w0), (hs[0], ds[1], w1), (hs[1], ds[2], w2), (hs[2], gy, w3)):

@@ -290,6 +290,213 @@ __global__ __launch_bounds__(256) void k_subband_mlp_bwd(const float* __restrict
 #undef LLDWT_MLP_WRITE
 }
 
+// The same backward with the weight gradients formed IN the kernel (training default): nothing but x, gy and gx touches HBM -- the
+// six (Z, C*32, hw) tensors of the form above are 768 B per coefficient written and read again by four GEMM launches.
+//   dW1 = sum over coefficients d1 (x) h0,  dW2 = d2 (x) h1    (32 x 32, on v_mfma_f32_16x16x4_f32 with K = coefficients)
+//   dw0 = sum d0 x, db0 = sum d0, db1 = sum d1, db2 = sum d2, dw3 = sum gy h2, db3 = sum gy     (per lane, reduced at the end)
+// The matrix products contract over coefficients, which the register layout above spreads over lanes (a lane = one coefficient
+// column x 8 channels): each wave passes d and h of its 32 coefficients through a private LDS tile [coefficient][channel] (row
+// pitch 48 floats: the transposed 4-byte reads of an MFMA operand -- lane (channel, coefficient mod 4) -- are conflict-free) --
+// no barrier, a wave's LDS operations execute in order.  A workgroup = (slice of the plane, channel, plane) loops over the
+// batch; every WAVE ends by storing its partial sums as one row of `part` (no atomics: k_subband_mlp_wsum adds the rows in a
+// fixed order, the gradients need no zero-fill and do not depend on scheduling).
+constexpr int MLPW_ROW = 2240;          // dW1 1024 | dW2 1024 | dw0 32 | db0 32 | db1 32 | db2 32 | dw3 32 | db3 1 (+ padding)
+constexpr int MLPW_PITCH = 48;
+__global__ __launch_bounds__(256) void k_subband_mlp_bwdw(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          float* __restrict__ gx, float* __restrict__ part, int batch, int C,
+                                                          int64_t hw, const float* __restrict__ w0, const float* __restrict__ b0,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          const float* __restrict__ w3) {
+    constexpr int HD = 32, NC = 2;
+    __shared__ __attribute__((aligned(16))) float tbuf[4][2][32 * MLPW_PITCH];
+    const int c = blockIdx.y, plane = blockIdx.z;
+    const int64_t pc = (int64_t)plane * C + c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    float* bufA = tbuf[wave][0];
+    float* bufB = tbuf[wave][1];
+    float A1[2][8], A2[2][8], A1T[2][8], A2T[2][8], w0b[8], b0b[8], b1d[8], b2d[8], w3d[8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = m * 16 + col, ch = (q >> 2) * 16 + 4 * kk + (q & 3);
+            A1[m][q] = w1[(pc * HD + row) * HD + ch];
+            A2[m][q] = w2[(pc * HD + row) * HD + ch];
+            A1T[m][q] = w1[(pc * HD + ch) * HD + row];
+            A2T[m][q] = w2[(pc * HD + ch) * HD + row];
+        }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int ch = (q >> 2) * 16 + 4 * kk + (q & 3);
+        w0b[q] = w0[pc * HD + ch];
+        b0b[q] = b0[pc * HD + ch];
+        b1d[q] = b1[pc * HD + ch];
+        b2d[q] = b2[pc * HD + ch];
+        w3d[q] = w3[pc * HD + ch];
+    }
+    floatx4m aw1[2][2], aw2[2][2];          // [oc tile][ic tile], D layout: row oc = 4 kk + r, column ic = col
+    float sdw0[8], sdb0[8], sdb1[8], sdb2[8], sdw3[8], sdb3 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) aw1[a][b] = aw2[a][b] = floatx4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sdw0[q] = sdb0[q] = sdb1[q] = sdb2[q] = sdw3[q] = 0.f;
+#define LLDWT_MLPW_GEMM(OUT_, AW_, IN_, BIAS_)                                                                   \
+    {                                                                                                            \
+        floatx4m acc_[2][NC];                                                                                    \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                            \
+            _Pragma("unroll") for (int n = 0; n < NC; ++n)                                                       \
+                acc_[m][n] = floatx4m{BIAS_[m * 4 + 0], BIAS_[m * 4 + 1], BIAS_[m * 4 + 2], BIAS_[m * 4 + 3]};   \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                            \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                        \
+                _Pragma("unroll") for (int n = 0; n < NC; ++n)                                                   \
+                    acc_[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW_[m][q], IN_[n][q], acc_[m][n], 0, 0, 0); \
+        _Pragma("unroll") for (int n = 0; n < NC; ++n)                                                           \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                        \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) OUT_[n][m * 4 + r] = acc_[m][n][r];                \
+    }
+    // tensor in the register layout -> this wave's LDS tile [coefficient n * 16 + col][channel]
+#define LLDWT_MLPW_PUT(BUF_, V_)                                                                                 \
+    _Pragma("unroll") for (int n = 0; n < NC; ++n)                                                               \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                            \
+            *reinterpret_cast<floatx4m*>(BUF_ + (n * 16 + col) * MLPW_PITCH + m * 16 + 4 * kk) =                 \
+                floatx4m{V_[n][m * 4 + 0], V_[n][m * 4 + 1], V_[n][m * 4 + 2], V_[n][m * 4 + 3]};
+    // ACC_[oc tile][ic tile] += (bufA as d)[oc][coefficient] . (bufB as h)[ic][coefficient] over the wave's 32 coefficients
+#define LLDWT_MLPW_OUTER(ACC_)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4 * NC; ++j) {                                                         \
+        const float a0_ = bufA[(4 * j + kk) * MLPW_PITCH + col], a1_ = bufA[(4 * j + kk) * MLPW_PITCH + 16 + col]; \
+        const float b0_ = bufB[(4 * j + kk) * MLPW_PITCH + col], b1_ = bufB[(4 * j + kk) * MLPW_PITCH + 16 + col]; \
+        ACC_[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_, b0_, ACC_[0][0], 0, 0, 0);                        \
+        ACC_[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_, b1_, ACC_[0][1], 0, 0, 0);                        \
+        ACC_[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_, b0_, ACC_[1][0], 0, 0, 0);                        \
+        ACC_[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_, b1_, ACC_[1][1], 0, 0, 0);                        \
+    }
+    const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < batch; ++b) {
+        const int64_t z = (int64_t)plane * batch + b;
+        const float* xp = x + (z * C + c) * hw;
+        const float* gp = gy + (z * C + c) * hw;
+        float* gxp = gx + (z * C + c) * hw;
+        for (int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NC); i0 < hw; i0 += (int64_t)gridDim.x * 4 * 16 * NC) {
+            float xv[NC], gv[NC];
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                const int64_t i = i0 + n * 16 + col;
+                xv[n] = xp[i < hw ? i : 0];
+                gv[n] = i < hw ? gp[i] : 0.f;            // past the end: no gradient, so every sum below gets zeros
+            }
+            float h0[NC][8], h1[NC][8], h2[NC][8], d[NC][8], t[NC][8];
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h0[n][q] = fast_tanh(fmaf(w0b[q], xv[n], b0b[q]));
+            LLDWT_MLPW_GEMM(t, A1, h0, b1d)
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h1[n][q] = fast_tanh(t[n][q]);
+            LLDWT_MLPW_GEMM(t, A2, h1, b2d)
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h2[n][q] = fast_tanh(t[n][q]);
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                if (kk == 0) sdb3 += gv[n];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    sdw3[q] = fmaf(gv[n], h2[n][q], sdw3[q]);
+                    d[n][q] = w3d[q] * gv[n] * (1.f - h2[n][q] * h2[n][q]);           // d2
+                    sdb2[q] += d[n][q];
+                }
+            }
+            LLDWT_MLPW_PUT(bufA, d)
+            LLDWT_MLPW_PUT(bufB, h1)
+            LLDWT_MLPW_OUTER(aw2)
+            LLDWT_MLPW_GEMM(t, A2T, d, zero8)
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    d[n][q] = t[n][q] * (1.f - h1[n][q] * h1[n][q]);                    // d1
+                    sdb1[q] += d[n][q];
+                }
+            LLDWT_MLPW_PUT(bufA, d)
+            LLDWT_MLPW_PUT(bufB, h0)
+            LLDWT_MLPW_OUTER(aw1)
+            LLDWT_MLPW_GEMM(t, A1T, d, zero8)
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                float o = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float d0 = t[n][q] * (1.f - h0[n][q] * h0[n][q]);
+                    sdb0[q] += d0;
+                    sdw0[q] = fmaf(d0, xv[n], sdw0[q]);
+                    o = fmaf(w0b[q], d0, o);
+                }
+                o += __shfl_xor(o, 16, 64);
+                o += __shfl_xor(o, 32, 64);
+                const int64_t i = i0 + n * 16 + col;
+                if (kk == 0 && i < hw) gxp[i] = o;
+            }
+        }
+    }
+#undef LLDWT_MLPW_GEMM
+#undef LLDWT_MLPW_PUT
+#undef LLDWT_MLPW_OUTER
+    // this wave's row of partial sums
+    float* row = part + ((pc * gridDim.x + blockIdx.x) * 4 + wave) * (int64_t)MLPW_ROW;
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = (mo * 16 + 4 * kk + r) * HD + mi * 16 + col;
+                row[j] = aw1[mo][mi][r];
+                row[1024 + j] = aw2[mo][mi][r];
+            }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                       // sums over the 16 coefficient columns of the lane's channel
+        float v[5] = {sdw0[q], sdb0[q], sdb1[q], sdb2[q], sdw3[q]};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v[k] += __shfl_xor(v[k], o, 64);
+            if (col == 0) row[2048 + 32 * k + (q >> 2) * 16 + 4 * kk + (q & 3)] = v[k];
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) sdb3 += __shfl_xor(sdb3, o, 64);
+    if (lane == 0) row[2048 + 160] = sdb3;
+}
+
+// rows of partial sums -> the eight gradient tensors of one (plane, channel): out = alpha-free plain sums in row order
+__global__ __launch_bounds__(256) void k_subband_mlp_wsum(const float* __restrict__ part, int nrows, float* __restrict__ dw0,
+                                                          float* __restrict__ db0, float* __restrict__ dw1,
+                                                          float* __restrict__ db1, float* __restrict__ dw2,
+                                                          float* __restrict__ db2, float* __restrict__ dw3,
+                                                          float* __restrict__ db3) {
+    const int64_t pc = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= 2048 + 161) return;
+    const float* p = part + pc * nrows * (int64_t)MLPW_ROW + j;
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += p[(int64_t)r * MLPW_ROW];
+    if (j < 1024) dw1[pc * 1024 + j] = s;
+    else if (j < 2048) dw2[pc * 1024 + j - 1024] = s;
+    else {
+        const int k = (j - 2048) >> 5, ch = (j - 2048) & 31;
+        float* dst = k == 0 ? dw0 : k == 1 ? db0 : k == 2 ? db1 : k == 3 ? db2 : k == 4 ? dw3 : db3;
+        if (k < 5) dst[pc * 32 + ch] = s;
+        else if (ch == 0) dst[pc] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ direct conv (reference order)
 constexpr int OCB = 8;
 __global__ __launch_bounds__(256) void k_conv_direct(const float* __restrict__ x, float* __restrict__ y,
@@ -938,6 +1145,38 @@ extern "C" int lldwt_subband_mlp_bwd(const float* x, const float* gy, float* gx,
     hipLaunchKernelGGL(k_subband_mlp_bwd, grid, dim3(256), 0, (hipStream_t)stream, x, gy, gx, h0, h1, h2, d0, d1, d2, (int)batch,
                        C, hw, w0, b0, w1, b1, w2, b2, w3);
     return check_launch("subband_mlp_bwd");
+}
+
+static inline int64_t mlpw_slices(int64_t planes, int C, int64_t hw) {
+    // about two workgroups per CU in all; a slice is at least one round of the four waves (128 coefficients)
+    int64_t s = (int64_t)lldwt_num_cus() * 2 / (planes * C);
+    const int64_t most = cdiv(hw, 128);
+    s = s > most ? most : s;
+    return s < 1 ? 1 : s;
+}
+extern "C" int64_t lldwt_subband_mlp_bwd_w_ws_bytes(int64_t planes, int C, int64_t hw) {
+    return (int64_t)sizeof(float) * planes * C * mlpw_slices(planes, C, hw) * 4 * MLPW_ROW;
+}
+extern "C" int lldwt_subband_mlp_bwd_w(const float* x, const float* gy, float* gx, int64_t planes, int64_t batch, int C, int64_t hw,
+                                       int Hd, const float* w0, const float* b0, const float* w1, const float* b1,
+                                       const float* w2, const float* b2, const float* w3, float* dw0, float* db0, float* dw1,
+                                       float* db1, float* dw2, float* db2, float* dw3, float* db3, void* ws, int64_t ws_bytes,
+                                       void* stream) {
+    LLDWT_REQUIRE(x && gy && gx && w0 && b0 && w1 && b1 && w2 && b2 && w3 && dw0 && db0 && dw1 && db1 && dw2 && db2 && dw3 && db3 &&
+                  ws, "subband_mlp_bwd_w: null pointer");
+    LLDWT_REQUIRE(planes > 0 && batch > 0 && C > 0 && hw > 0, "subband_mlp_bwd_w: bad dims");
+    LLDWT_REQUIRE(Hd == 32, "subband_mlp_bwd_w: hidden width %d unsupported (reference uses H=32, lifting_dwt_nets.py:98)", Hd);
+    LLDWT_REQUIRE(planes <= 65535 && C <= 65535, "subband_mlp_bwd_w: grid too large");
+    if (ws_bytes < lldwt_subband_mlp_bwd_w_ws_bytes(planes, C, hw)) {
+        set_error("subband_mlp_bwd_w: workspace %ld < %ld bytes", (long)ws_bytes, (long)lldwt_subband_mlp_bwd_w_ws_bytes(planes, C, hw));
+        return LLDWT_EWS;
+    }
+    const int64_t sl = mlpw_slices(planes, C, hw);
+    hipLaunchKernelGGL(k_subband_mlp_bwdw, dim3((unsigned)sl, (unsigned)C, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, x,
+                       gy, gx, (float*)ws, (int)batch, C, hw, w0, b0, w1, b1, w2, b2, w3);
+    hipLaunchKernelGGL(k_subband_mlp_wsum, dim3((unsigned)cdiv(2048 + 161, 256), (unsigned)(planes * C)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)ws, (int)(sl * 4), dw0, db0, dw1, db1, dw2, db2, dw3, db3);
+    return check_launch("subband_mlp_bwd_w");
 }
 
 extern "C" int lldwt_conv2d_direct(const float* x, float* y, const float* w, const float* bias, const lldwt_conv_desc* d,

@@ -267,6 +267,23 @@ def subband_mlp_bwd(x, gy, w0, b0, w1, b1, w2, b2, w3, hidden=32):
     return gx, hs[:3], hs[3:]
 
 
+def subband_mlp_bwd_w(x, gy, w0, b0, w1, b1, w2, b2, w3, hidden=32):
+    """Backward of the encode-layout subband MLP with the parameter gradients formed in the kernel (lldwt_subband_mlp_bwd_w):
+    -> (gx, [dw0, db0, dw1, db1, dw2, db2, dw3, db3]) in the shapes of the parameters."""
+    lib = _lib.load()
+    P, B, Cc, h, w = x.shape
+    gx = torch.empty_like(x)
+    shapes = [(P, Cc * hidden, 1, 1, 1), (P, Cc * hidden), (P, Cc * hidden, hidden, 1, 1), (P, Cc * hidden),
+              (P, Cc * hidden, hidden, 1, 1), (P, Cc * hidden), (P, Cc, hidden, 1, 1), (P, Cc)]
+    g = [torch.empty(s, device=x.device, dtype=torch.float32) for s in shapes]
+    nb = lib.lldwt_subband_mlp_bwd_w_ws_bytes(P, Cc, h * w)
+    ws = workspace(nb, x.device)
+    check(lib.lldwt_subband_mlp_bwd_w(_chk(x, "x"), _chk(gy, "gy"), _chk(gx), P, B, Cc, h * w, hidden, _chk(w0), _chk(b0),
+                                      _chk(w1), _chk(b1), _chk(w2), _chk(b2), _chk(w3), *[_chk(t) for t in g],
+                                      C.c_void_p(ws.data_ptr()), nb, _stream()), "subband_mlp_bwd_w")
+    return gx, g
+
+
 def conv_desc(cin, cout, K, groups=1, act=ACT_NONE, upsample2=False, transposed=False, tap_mask=None, oc_block=None,
               oc_stride=0, oc_off=0, ytot=None, ic_block=0, ic_stride=0, ic_off=0, xtot=0, epi=0):
     return ConvDesc(cin, cout, K, groups, act, int(bool(upsample2)), int(bool(transposed)),

@@ -238,6 +238,14 @@ int lldwt_subband_mlp_bwd(const float* x, const float* gy, float* gx, float* h0,
                           float* d2, int64_t planes, int64_t batch, int C, int64_t hw, int Hd, const float* w0,
                           const float* b0, const float* w1, const float* b1, const float* w2, const float* b2,
                           const float* w3, void* stream);
+/* The same backward with the eight parameter gradients formed inside the kernel (training default): only x, gy and gx touch HBM.
+ * dw0, db0, db1, db2, dw3: (planes, C*Hd); dw1, dw2: (planes, C*Hd, Hd); db3: (planes, C) -- WRITTEN (not accumulated; fixed
+ * summation order: the result does not depend on scheduling).  ws: lldwt_subband_mlp_bwd_w_ws_bytes (per-wave partial sums). */
+int64_t lldwt_subband_mlp_bwd_w_ws_bytes(int64_t planes, int C, int64_t hw);
+int lldwt_subband_mlp_bwd_w(const float* x, const float* gy, float* gx, int64_t planes, int64_t batch, int C, int64_t hw, int Hd,
+                            const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                            const float* b2, const float* w3, float* dw0, float* db0, float* dw1, float* db1, float* dw2,
+                            float* db2, float* dw3, float* db3, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * General conv layer for the context models and the Berk auto-encoder

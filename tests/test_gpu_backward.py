@@ -182,11 +182,15 @@ def test_cgp_fused_forward_backward(dims, hw, PB):
             assert maxdiff(a.grad[p].cpu(), b.grad) < 5e-4 * scale, name
 
 
-@pytest.mark.parametrize("C,hw", [(3, (7, 19)), (1, (16, 40))])
-def test_subband_mlp_fused_forward_backward(C, hw):
-    """SubbandMlpFn (in-register MFMA MLP, forward and backward-data, + grouped 1x1 weight gradients) vs torch autograd:
-    ragged coefficient counts (not multiples of the 32/64-coefficient wave tiles), 1 and 3 channels."""
+@pytest.mark.parametrize("fused_wgrad", [True, False])
+@pytest.mark.parametrize("C,hw", [(3, (7, 19)), (1, (16, 40)), (3, (72, 100))])
+def test_subband_mlp_fused_forward_backward(C, hw, fused_wgrad, monkeypatch):
+    """SubbandMlpFn (in-register MFMA MLP, forward and backward) vs torch autograd: ragged coefficient counts (not multiples of
+    the 32/64-coefficient wave tiles), 1 and 3 channels, one plane large enough for several rounds of every wave.  fused_wgrad:
+    the eight parameter gradients formed inside the backward kernel (lldwt_subband_mlp_bwd_w, the default) or by the four
+    grouped 1x1 weight-gradient GEMMs over tensors written out (LLDWT_MLP_WGRAD=gemm)."""
     ag, ops, gu = _mods()
+    monkeypatch.setattr(ag, "_MLP_WGRAD_FUSED", fused_wgrad)
     g = torch.Generator().manual_seed(40 + C)
     P, B, H = 2, 2, 32
     h, w = hw
