@@ -1629,6 +1629,8 @@ int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, floa
 }
 // LLDWT_WGRAD16=f32 keeps the fp32-MFMA weight gradient of the 16 -> 16 lifting convs (k_wgrad16<5>); default: split-fp16
 static const int g_wgrad16_f16 = [] { const char* e = getenv("LLDWT_WGRAD16"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
+// smallest batch * h * w per plane at which the split-fp16 kernel takes the 16 -> 16 weight gradients (LLDWT_WGRAD16_MIN overrides)
+static const int64_t g_wgrad16_min = [] { const char* e = getenv("LLDWT_WGRAD16_MIN"); return e ? (int64_t)atoll(e) : (int64_t)500000; }();
 
 // LLDWT_BWD_LIFT=f32 keeps the three fp32-MFMA backward-data launches even when a backward pack is passed
 static const int g_bwd_lift_f16 = [] { const char* e = getenv("LLDWT_BWD_LIFT"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
@@ -1718,7 +1720,7 @@ static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_v
     float* dr = dpre2 + n * C;
     int r;
     float* slots = dr + n * C;          // 128 per plane: max |dt3|, max |dpre2| (the split-fp16 weight gradient's dY scales)
-    const bool wg16 = K == 5 && !linear && g_wgrad16_f16 && w % 4 == 0 && batch * h * w >= 500000;
+    const bool wg16 = K == 5 && !linear && g_wgrad16_f16 && w % 4 == 0 && batch * h * w >= g_wgrad16_min;
     bool slots_ready = false;
     if (packed_bwd && K == LF_K && C == LF_C && !linear && g_bwd_lift_f16 && g_lift_mode == 1) {
         if ((r = lldwt_lift_bwd_pre(g_dst_out, g_dst_in, g, Z, h, w, stream))) return r;
