@@ -416,3 +416,36 @@ def test_lift_step_backward_on_the_fused_kernel(hw, vertical):
         scale = float(ref[k].abs().max())
         assert scale > 0, k
         assert float((ref[k] - got[k]).abs().max()) <= 2e-5 * scale, (k, float((ref[k] - got[k]).abs().max()), scale)
+
+
+def test_new_backward_entries_refuse_bad_arguments():
+    """The round-3 backward entry points fail loudly (LLDWT_EINVAL / LLDWT_EWS -> LLDWTError), never silently: a backward pack for
+    a block the fused kernel is not built for, a fused step backward without its pack, a workspace that is too small."""
+    import ctypes
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import _lib, ops
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd._lib import LLDWTError
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    P = 2
+    w1, w2 = torch.zeros(P, 16, 1, 3, 3, device=dev), torch.zeros(P, 16, 16, 3, 3, device=dev)
+    w4 = torch.zeros(P, 1, 16, 3, 3, device=dev)
+    with pytest.raises(LLDWTError, match="K=5"):
+        ops.pack_pblock_bwd(w1, w2, w2, w4)                                    # 3 x 3 block: the fused kernel is 5 x 5 only
+    x = torch.zeros(P, 2, 3, 8, 8, device=dev)
+    par = [torch.zeros(P, 96, 1, 1, 1, device=dev), torch.zeros(P, 96, device=dev), torch.zeros(P, 96, 32, 1, 1, device=dev),
+           torch.zeros(P, 96, device=dev), torch.zeros(P, 96, 32, 1, 1, device=dev), torch.zeros(P, 96, device=dev),
+           torch.zeros(P, 3, 32, 1, 1, device=dev)]
+    grads = [torch.zeros(4096, device=dev) for _ in range(8)]
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    ws = torch.zeros(64, device=dev)
+    rc = lib.lldwt_subband_mlp_bwd_w(ptr(x), ptr(x), ptr(torch.empty_like(x)), P, 2, 3, 64, 32, *[ptr(t) for t in par],
+                                     *[ptr(t) for t in grads], ptr(ws), 256, None)
+    assert rc == -3 and b"workspace" in lib.lldwt_last_error()                  # LLDWT_EWS
+    rc = lib.lldwt_subband_mlp_bwd_w(ptr(x), ptr(x), ptr(torch.empty_like(x)), P, 2, 3, 64, 16, *[ptr(t) for t in par],
+                                     *[ptr(t) for t in grads], ptr(ws), 256, None)
+    assert rc == -1 and b"hidden width" in lib.lldwt_last_error()               # LLDWT_EINVAL: H = 32 only
+    v = ops.View(ptr(x), 64, 8, 1)
+    with pytest.raises(LLDWTError, match="null"):
+        lib_rc = lib.lldwt_lift_step_bwd_f16(v, v, v, ptr(x), P, 2, 8, 8, ptr(x), ptr(x), ptr(x), 0, *[ptr(x)] * 8, 16, 5, 0.1, 1.0,
+                                             1, 0, ptr(x), 1 << 20, None, None, None)
+        _lib.check(lib_rc, "lift_step_bwd_f16")
