@@ -271,7 +271,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // registers; 150 MFMAs per chunk and wave against 44 fragment reads).  No register prefetch (the accumulators leave no room
 // for it): load -> split -> LDS store of the next chunk happen between two barriers, and the OTHER workgroup resident on the
 // CU (two at 255 registers per lane) runs its MFMAs meanwhile.  K is also split over workgroups (one resident round); the partial 16 x 16 x 25
-// tiles of the four waves are summed in LDS and added to dW with one coalesced float atomic per element.
+// tiles of the four waves are summed in LDS (the waves take turns: LDS float atomics cost 50-65 us per launch) and added to dW with
+// one coalesced float atomic per element.  Measured with phases masked at 3 x 8 x 256 x 512 (356 us with the |max| pass): the MFMA
+// phase is 41 us of it, the LDS reduction was 65, load + split + store of the operands 250 -- 50 KB per chunk in row pieces of
+// 128-176 B, everyone loading at once between two barriers; one workgroup per CU with the next chunk prefetched in registers
+// (433 of them) was no faster (357 us) -- the chunk shape, not the overlap, bounds it.
 // Scales: X has a fixed 2^14 (tanh outputs); dY one power of two per plane from its |max| (lldwt_absmax_slots).
 constexpr int G_CR = 8, G_CW = 32;                          // chunk: 8 rows x 32 pixels
 constexpr int G_AP = G_CR * G_CW * 2 + 16;                  // dY bytes per oc: 528 (132 dwords = 4 mod 64: conflict-free b128)
@@ -451,19 +455,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- epilogue: the four waves' partial tiles summed in LDS in dW order, then one coalesced atomic per element (every
     // workgroup of a plane adds to the same 6 400 addresses: scattered lanes would touch 64 cache lines per instruction)
+    // (LDS float atomics from the four waves took 50-65 us per launch -- about one lane per 4-5 clocks; the waves take turns instead:
+    // wave 0 stores its tile, each following wave adds its own with plain read-modify-writes, a barrier between two turns)
     float* tile = reinterpret_cast<float*>(lds);
-    for (int i = tid; i < 16 * 16 * 25; i += 256) tile[i] = 0.f;
-    __syncthreads();
-    if (slice < nchunk) {
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn && slice < nchunk) {
 #pragma unroll
-        for (int t = 0; t < 25; ++t) {
-            const int tap = a.tap_of[t];
+            for (int t = 0; t < 25; ++t) {
+                const int tap = a.tap_of[t];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)               // D row = oc = 4 kg + q, col = ic = lane & 15
-                __hip_atomic_fetch_add(tile + ((4 * kg + q) * 16 + l15) * 25 + tap, acc[t][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int q = 0; q < 4; ++q) {         // D row = oc = 4 kg + q, col = ic = lane & 15
+                    float* d = tile + ((4 * kg + q) * 16 + l15) * 25 + tap;
+                    *d = turn == 0 ? acc[t][q] : *d + acc[t][q];
+                }
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     if (slice >= nchunk) return;
     const float inv = a.alpha * (1.f / sX) * (1.f / sY);
     float* dwp = a.dw + (int64_t)plane * 16 * 16 * 25;

@@ -1630,7 +1630,7 @@ int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, floa
 // LLDWT_WGRAD16=f32 keeps the fp32-MFMA weight gradient of the 16 -> 16 lifting convs (k_wgrad16<5>); default: split-fp16
 static const int g_wgrad16_f16 = [] { const char* e = getenv("LLDWT_WGRAD16"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
 // smallest batch * h * w per plane at which the split-fp16 kernel takes the 16 -> 16 weight gradients (LLDWT_WGRAD16_MIN overrides)
-static const int64_t g_wgrad16_min = [] { const char* e = getenv("LLDWT_WGRAD16_MIN"); return e ? (int64_t)atoll(e) : (int64_t)500000; }();
+static const int64_t g_wgrad16_min = [] { const char* e = getenv("LLDWT_WGRAD16_MIN"); return e ? (int64_t)atoll(e) : (int64_t)250000; }();
 
 // LLDWT_BWD_LIFT=f32 keeps the three fp32-MFMA backward-data launches even when a backward pack is passed
 static const int g_bwd_lift_f16 = [] { const char* e = getenv("LLDWT_BWD_LIFT"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
@@ -1754,9 +1754,9 @@ static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_v
     desc(C, C);
     if (wg16) {
         // conv3 / conv2: their inputs t2 / t1 are tanh outputs (|x| <= 1): split-fp16 on the fp16 matrix cores (conv_wgrad_f16x3.hip).
-        // Only where it wins (measured, 3 planes x 8 images: 360 vs 513 us at 256 x 512, 231 vs 272 at 256 x 256, but 173 vs 146 at
-        // 128 x 256 and 146 vs 70 at 128 x 128: below ~0.5 Mpixel per plane the per-plane |dY|-max pass and the 6 400 float atomics
-        // of every workgroup weigh more than the matrix work saved)
+        // Only where it wins (measured, 3 planes x 8 images, kernel alone: 228 vs 530 us at 256 x 512, 148 vs 272 at 256 x 256,
+        // 111 vs 146 at 128 x 256, but 97 vs 71 at 128 x 128: below ~0.25 Mpixel per plane the fixed cost of a launch -- prologue,
+        // tile reduction, 6 400 float atomics per workgroup -- weighs more than the matrix work saved)
         int8_t tap_of[25];
         for (int t = 0; t < 25; ++t) tap_of[t] = (int8_t)(swap ? (t % 5) * 5 + t / 5 : t);
         const int64_t ss = slots_ready ? 128 : 64;
