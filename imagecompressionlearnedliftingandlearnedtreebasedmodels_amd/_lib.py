@@ -105,6 +105,7 @@ SIGNATURES = {
     "lldwt_conv2d_wgrad": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _p]),
     "lldwt_conv2d_wgrad_ex": (_i, [_p, _p, _p, _p, C.POINTER(ConvDesc), _i64, _i64, _i64, _i64, _f, _i, _p]),
     "lldwt_conv3x3_wgrad_f16x3": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _i64, _f, _p]),
+    "lldwt_conv3x3_wgrad_f16x3_ex": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i64, _i64, _i64, _f, _p]),
     "lldwt_conv_f16x3_packed_bytes": (_i64, [_i, _i]),
     "lldwt_plc_shape16": (_i, []),
     "lldwt_plc_fused_pack1_bytes": (_i64, [_i]),

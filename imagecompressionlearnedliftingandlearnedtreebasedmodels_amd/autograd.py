@@ -28,13 +28,16 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, K, groups, act, upsample2, tap_mask):
         fast = ConvFn._f16x3(x, w, K, groups, upsample2, tap_mask, residual)
+        xs = None
         if fast:
-            y = ops.conv3x3_f16x3(x, ops.conv_f16x3_pack(w.detach().contiguous()), b, w.shape[1], act=act)
+            xs = ops.absmax_slots(x)            # kept for the weight gradient: one |max| pass over x per step instead of two
+            y = ops.conv3x3_f16x3(x, ops.conv_f16x3_pack(w.detach().contiguous()), b, w.shape[1], act=act, slots=xs)
         else:
             y = ops.conv2d(x, w, b, K, groups=groups, act=act, upsample2=upsample2, tap_mask=tap_mask, residual=residual)
         ctx.save_for_backward(x, w, y if act != ops.ACT_NONE else None)
         ctx.cfg = (K, groups, act, upsample2, tap_mask, b is not None, residual is not None)
         ctx.fast = fast
+        ctx.x_slots = xs
         return y
 
     @staticmethod
@@ -44,9 +47,10 @@ class ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dpre = ops.act_bwd(dy, y, act) if act != ops.ACT_NONE else dy
         dx = dw = db = None
+        ds = ops.absmax_slots(dpre) if ctx.fast else None                      # shared by backward-data and backward-weights
         if ctx.needs_input_grad[0] and ctx.fast:
             wt = w.detach().transpose(1, 2).flip(-1, -2).contiguous()          # (P, cin, cout, 3, 3): the adjoint conv's weight
-            dx = ops.conv3x3_f16x3(dpre, ops.conv_f16x3_pack(wt), None, w.shape[2])
+            dx = ops.conv3x3_f16x3(dpre, ops.conv_f16x3_pack(wt), None, w.shape[2], slots=ds)
         elif ctx.needs_input_grad[0]:
             # backward-data: the forward weight read as a ConvTranspose2d weight (cin' = cout) with flipped taps
             dx = ops.conv2d(dpre, w, None, K, groups=groups, transposed=True, tap_mask=ops.flip_mask(tap_mask, K))
@@ -54,7 +58,8 @@ class ConvFn(torch.autograd.Function):
                 dx = ops.downsum2(dx)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             if ctx.fast and x.shape[-1] % 4 == 0:
-                dw, db = ops.conv3x3_wgrad_f16x3(x, dpre, tuple(w.shape), want_bias=has_b)     # split-fp16 matrix cores
+                dw, db = ops.conv3x3_wgrad_f16x3(x, dpre, tuple(w.shape), want_bias=has_b,      # split-fp16 matrix cores
+                                                 x_slots=ctx.x_slots, dy_slots=ds)
             else:
                 dw, db = ops.conv2d_wgrad(x, dpre, tuple(w.shape), K, groups=groups, upsample2=upsample2, tap_mask=tap_mask,
                                           want_bias=has_b)

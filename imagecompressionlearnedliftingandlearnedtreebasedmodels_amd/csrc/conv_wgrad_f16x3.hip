@@ -19,6 +19,8 @@
 // barriers.  K is also split over workgroups (slices of the chunk sequence), partial tiles are added with float atomics.
 // Scales: one power of two per plane for dY and for X (max |.| from lldwt_absmax_slots), so every chunk accumulates at
 // the same scale.
+#include <cstring>
+#include <type_traits>
 #include "common.h"
 #include "split_f16.h"
 
@@ -246,6 +248,278 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             float s = dbs[j];
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);       // the 16 threads that stage one oc row
+            const int oc = oc0 + ((tid + 256 * j) >> 4);
+            if ((tid & 15) == 0 && oc < a.cout) atomicAdd(a.db + (int64_t)plane * a.cout + oc, s * a.alpha);
+        }
+    }
+}
+
+
+// ================================================================================================================
+// k_wgrad3_f16x3_v2 -- the same GEMM, tile and K split as k_wgrad3_f16x3 with the staging taken OFF the critical path.
+// v1 kept three pre-shifted copies of the input rows (one per horizontal tap): 14 scattered 2- / 4-byte LDS stores and a dozen
+// address selects per staged float4, all of it between two barriers with the matrix pipe idle (one wave per SIMD) -- the
+// chunk loop ran ~10k cycles for 3.5k cycles of MFMAs.  Here:
+//   * ONE copy of the input rows, [32 ic][4 rows][40 px] fp16 (columns x0-4 .. x0+35).  A lane reads the two aligned 16-byte
+//     windows that hold all three horizontal shifts of its 8-pixel fragment and extracts them in registers: tx = 1 is whole
+//     dwords, tx = 0 / 2 are four v_alignbit_b32 each.  Two 8-byte stores per staged float4, 21 KB instead of 63 KB per chunk;
+//   * that makes room for TWO LDS buffers (2 x 58 KB): chunk n+1 is split and stored into the other buffer WHILE chunk n is
+//     multiplied -- the staging is cut into 13 branch-free pieces (one float4 each) that ride in the shadow of the MFMAs
+//     (a 32x32x16 MFMA leaves 24 of its 32 cycles to the vector / LDS issue), the fragment reads of block b+1 and their
+//     alignbits sit under block b.  One barrier per chunk;
+//   * two register sets for the global loads: chunk n+2 is in flight for a whole chunk period.
+constexpr int B2_ROW = 80;                        // 40 elements: columns x0-4 .. x0+35
+constexpr int B2_IC = (CR + 2) * B2_ROW + 16;     // 336 B per channel (21 16-byte slots: odd -> conflict-free ds_read_b128)
+constexpr int B2_PART = WIC * B2_IC;              // 10,752 B (hi or lo)
+constexpr int V2_B = 2 * A_PART;                  // the A image keeps v1's layout
+constexpr int V2_BUF = V2_B + 2 * B2_PART;        // 58,368 B per buffer
+constexpr int V2_TOTAL = 2 * V2_BUF;              // 116,736 B
+static_assert(WIC * (CR + 2) * XSEG == NX4 * 256 && XSEG * 8 == B2_ROW, "five whole staging rounds of the input rows");
+// 13 staging pieces (5 of the input rows, then 8 of dY) over the 8 MFMA blocks of a chunk: 1 2 2 1 | 1 2 2 2
+__host__ __device__ constexpr int v2_first_piece(int b) {
+    return b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 3 : b == 3 ? 5 : b == 4 ? 6 : b == 5 ? 7 : b == 6 ? 9 : b == 7 ? 11 : 13;
+}
+static_assert(v2_first_piece(8) == NX4 + NA4, "every staging piece has a block");
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_wgrad3_f16x3_v2(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int plane = blockIdx.z;
+    const int ncol = a.nicb * a.nocb;                 // block order: see k_wgrad3_f16x3
+    const int s_lo = blockIdx.x & 7, t_ = blockIdx.x >> 3;
+    const int column = t_ % ncol, slice = (t_ / ncol) * 8 + s_lo;
+    const int icb = column % a.nicb, ocb = column / a.nicb;
+    const int ic0 = icb * WIC, oc0 = ocb * WM;
+    const int h = a.h, w = a.w;
+    const int hw = h * w;                             // WM * h * w < 2^31 (checked on the host): 32-bit offsets inside an image
+    const int nchunk_img = a.chunks_x * a.chunks_y;
+    const int nchunk = a.batch * nchunk_img;
+    if (slice >= nchunk) return;                      // uniform, before any barrier
+
+    float ax = a.sx[plane * 64 + lane], ay = a.sy[plane * 64 + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ax = fmaxf(ax, __shfl_xor(ax, o, 64));
+        ay = fmaxf(ay, __shfl_xor(ay, o, 64));
+    }
+    const float sX = pow2_scale_for(ax), sY = pow2_scale_for(ay);
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    const float* xp = a.x + ((int64_t)plane * a.batch * a.cin + ic0) * (int64_t)hw;
+    const float* yp = a.dy + ((int64_t)plane * a.batch * a.cout + oc0) * (int64_t)hw;
+    // ONE register set for the operands in flight: piece j of chunk n+1 is split and stored somewhere inside chunk n's MFMA
+    // blocks and its registers are reloaded with piece j of chunk n+2 right there, so every load has a whole chunk period
+    floatx4 ra[NA4], rx[NX4];
+    float dbs[NA4];
+#pragma unroll
+    for (int j = 0; j < NA4; ++j) dbs[j] = 0.f;
+
+    struct Pos { const float* xb; const float* yb; int y0, x0; };       // wave-uniform (scalar registers)
+    auto coords = [&](int chunk) -> Pos {
+        const int img = chunk / nchunk_img, rem = chunk - img * nchunk_img, cy = rem / a.chunks_x;
+        return Pos{xp + (int64_t)img * a.cin * hw, yp + (int64_t)img * a.cout * hw, cy * CR, (rem - cy * a.chunks_x) * CW};
+    };
+    // dY piece j: float4 f = tid + 256 j -> oc = f / 16, row = (f % 16) / 8, x4 = 4 (f % 8);  clamped address, masked at the store
+    auto load_a = [&](int j, const Pos& c) {
+        const int f = tid + 256 * j;
+        const int oc = f >> 4, row = (f >> 3) & 1, x4 = (f & 7) * 4;
+        const int gy = min(c.y0 + row, h - 1), gx = min(c.x0 + x4, w - 4), occ = min(oc0 + oc, a.cout - 1) - oc0;
+        ra[j] = *reinterpret_cast<const floatx4*>(c.yb + (unsigned)(occ * hw + __mul24(gy, w) + gx));      // h, w < 2^23: full-rate multiply
+    };
+    // x piece j: f = tid + 256 j -> ic = f / 40, row = (f % 40) / 10 (image row y0 - 1 + row), segment s = f % 10 (cols x0-4+4s ..)
+    auto load_x = [&](int j, const Pos& c) {
+        const int f = tid + 256 * j;
+        const int ic = f / ((CR + 2) * XSEG), r2 = f - ic * ((CR + 2) * XSEG), row = r2 / XSEG, s = r2 - row * XSEG;
+        const int gy = min(max(c.y0 - 1 + row, 0), h - 1), gx = min(max(c.x0 - 4 + 4 * s, 0), w - 4);
+        const int icc = min(ic0 + ic, a.cin - 1) - ic0;
+        rx[j] = *reinterpret_cast<const floatx4*>(c.xb + (unsigned)(icc * hw + __mul24(gy, w) + gx));
+    };
+    // `live` = the chunk exists (the last chunk of a slice stages a dummy: no branch in the chunk loop)
+    auto stage_a = [&](int j, const Pos& c, bool live, uint8_t* buf) {
+        const int f = tid + 256 * j;
+        const int oc = f >> 4, row = (f >> 3) & 1, x4 = (f & 7) * 4;
+        const bool ok = (int)live & (int)(oc0 + oc < a.cout) & (int)(c.y0 + row < h) & (int)(c.x0 + x4 < w);     // '&': no branch
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ok ? ra[j][i] : 0.f;
+        dbs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= sY;
+        half4 hi, lo;
+        split4v(v, hi, lo);
+        uint8_t* d = buf + oc * A_PITCH + (row * CW + x4) * 2;
+        *reinterpret_cast<half4*>(d) = hi;
+        *reinterpret_cast<half4*>(d + A_PART) = lo;
+    };
+    auto stage_x = [&](int j, const Pos& c, uint8_t* buf) {
+        const int f = tid + 256 * j;
+        const int ic = f / ((CR + 2) * XSEG), r2 = f - ic * ((CR + 2) * XSEG), row = r2 / XSEG, s = r2 - row * XSEG;
+        const int gy = c.y0 - 1 + row, gx = c.x0 - 4 + 4 * s;         // w % 4 == 0: a float4 lies inside the row or outside
+        const bool ok = (int)(ic0 + ic < a.cin) & (int)((unsigned)gy < (unsigned)h) & (int)((unsigned)gx < (unsigned)w);   // '&': no branch
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ok ? rx[j][i] * sX : 0.f;
+        half4 hi, lo;
+        split4v(v, hi, lo);
+        uint8_t* d = buf + V2_B + ic * B2_IC + row * B2_ROW + s * 8;
+        *reinterpret_cast<half4*>(d) = hi;
+        *reinterpret_cast<half4*>(d + B2_PART) = lo;
+    };
+
+    const int kg = lane >> 5, l31 = lane & 31;
+    // the three horizontal shifts of a lane's fragment from its two aligned windows (elements 8m .. 8m+15 of the row, m = 2 xh + kg;
+    // output pixel j of the fragment with tap tx reads element 8m + 3 + tx + j)
+    auto shifted = [&](const uintx4& w0, const uintx4& w1, int tx) -> half8 {
+        const unsigned d[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+        uintx4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[i] = tx == 1 ? d[i + 2] : tx == 0 ? __builtin_amdgcn_alignbit(d[i + 2], d[i + 1], 16) : __builtin_amdgcn_alignbit(d[i + 3], d[i + 2], 16);
+        return __builtin_bit_cast(half8, o);
+    };
+
+    // ---- chunks slice, slice + slices, ...; LDS buffer `cur` is multiplied while the other one is filled
+    int chunk = slice;
+    {
+        const Pos c = coords(chunk);
+#pragma unroll
+        for (int j = 0; j < NX4; ++j) load_x(j, c);
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) load_a(j, c);
+#pragma unroll
+        for (int j = 0; j < NX4; ++j) stage_x(j, c, lds);
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) stage_a(j, c, true, lds);
+        const Pos c1 = coords(min(chunk + a.slices, nchunk - 1));
+#pragma unroll
+        for (int j = 0; j < NX4; ++j) load_x(j, c1);
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) load_a(j, c1);
+    }
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    while (true) {
+        const int nxt = chunk + a.slices;
+        const bool live = nxt < nchunk;
+        const Pos cn = coords(min(nxt, nchunk - 1));              // staged during this chunk (already in the registers)
+        const Pos c2 = coords(min(nxt + a.slices, nchunk - 1));   // loaded during this chunk
+        const uint8_t* cb = lds + cur * V2_BUF;
+        uint8_t* sb = lds + (cur ^ 1) * V2_BUF;
+        const uint8_t* ab = cb + (wave * 32 + l31) * A_PITCH + kg * 16;
+        const uint8_t* bb = cb + V2_B + l31 * B2_IC + kg * 16;
+        half8 fah[2][2], fal[2][2];                   // A fragments [xh][chunk row]
+#pragma unroll
+        for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                fah[xh][r] = *reinterpret_cast<const half8*>(ab + (r * CW + 16 * xh) * 2);
+                fal[xh][r] = *reinterpret_cast<const half8*>(ab + (r * CW + 16 * xh) * 2 + A_PART);
+            }
+        half8 bh[2][3], bl[2][3];                     // B fragments [set][tx]
+        uintx4 wh[2][2], wl[2][2];                    // the aligned windows they are cut from [set][window]
+        // two-deep: block b issues the window reads of block b+2 and cuts the fragments of block b+1 from the windows read during
+        // block b-1 (fragments cut right behind their reads left the wave parked for an LDS round trip in every block)
+        auto windows = [&](int blk, int set) {
+            const int xh = blk >> 2, row = blk & 3;
+            const uint8_t* p = bb + row * B2_ROW + xh * 32;
+            wh[set][0] = *reinterpret_cast<const uintx4*>(p);
+            wh[set][1] = *reinterpret_cast<const uintx4*>(p + 16);
+            wl[set][0] = *reinterpret_cast<const uintx4*>(p + B2_PART);
+            wl[set][1] = *reinterpret_cast<const uintx4*>(p + B2_PART + 16);
+        };
+        auto cut = [&](int set) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                bh[set][tx] = shifted(wh[set][0], wh[set][1], tx);
+                bl[set][tx] = shifted(wl[set][0], wl[set][1], tx);
+            }
+        };
+        windows(0, 0);
+        windows(1, 1);
+        cut(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // the 108 MFMAs in 8 blocks (xh, patch row); block b carries the fragment reads + alignbits of block b+1 and its share of the
+        // 13 staging pieces, each followed by the reload of its registers
+        auto block = [&](auto BLK) {
+            constexpr int blk = decltype(BLK)::value;
+            constexpr int xh = blk >> 2, row = blk & 3, set = blk & 1;
+            constexpr int nm = (row == 0 || row == 3) ? 9 : 18;          // patch row 0 / 3 meets one chunk row, 1 / 2 meet both
+            constexpr int p0 = v2_first_piece(blk), p1 = v2_first_piece(blk + 1), npc = p1 - p0;
+            if constexpr (blk + 1 < 8) cut(set ^ 1);                      // windows of block b+1: read during block b-1
+            if constexpr (blk + 2 < 8) windows(blk + 2, set);            // (its own windows are cut: the set is free)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int ty = row - r;
+                if (ty < 0 || ty > 2) continue;
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const int t = ty * 3 + tx;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[xh][r], bh[set][tx], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[xh][r], bl[set][tx], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[xh][r], bh[set][tx], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int pc = p0; pc < p1; ++pc) {
+                if (pc < NX4) {
+                    stage_x(pc, cn, sb);
+                    load_x(pc, c2);
+                } else {
+                    stage_a(pc - NX4, cn, live, sb);
+                    load_a(pc - NX4, c2);
+                }
+            }
+            // issue order inside the block: an MFMA, then a share of the block's vector / LDS / memory work
+#pragma unroll
+            for (int i = 0; i < nm; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (blk + 2 < 8 && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, nm == 9 ? (npc == 2 ? 9 : 7) : 6, 0);
+                if (i >= nm - 2 * npc) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (i >= nm - npc) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        block(std::integral_constant<int, 0>{});
+        block(std::integral_constant<int, 1>{});
+        block(std::integral_constant<int, 2>{});
+        block(std::integral_constant<int, 3>{});
+        block(std::integral_constant<int, 4>{});
+        block(std::integral_constant<int, 5>{});
+        block(std::integral_constant<int, 6>{});
+        block(std::integral_constant<int, 7>{});
+        __syncthreads();
+        chunk = nxt;
+        cur ^= 1;
+        if (!live) break;
+    }
+
+    // ---- epilogue: as k_wgrad3_f16x3
+    const float inv = a.alpha * (1.f / sX) * (1.f / sY);
+    const int ic = ic0 + l31;
+    float* dwp = a.dw + (int64_t)plane * a.cout * a.cin * 9;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int oc = oc0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+        if (oc < a.cout && ic < a.cin) {
+            float* p = dwp + ((int64_t)oc * a.cin + ic) * 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) atomicAdd(p + t, acc[t][q] * inv);
+        }
+    }
+    if (a.db && icb == 0) {
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) {
+            float s = dbs[j];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             const int oc = oc0 + ((tid + 256 * j) >> 4);
             if ((tid & 15) == 0 && oc < a.cout) atomicAdd(a.db + (int64_t)plane * a.cout + oc, s * a.alpha);
         }
@@ -493,23 +767,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 using namespace lldwt;
 
 extern "C" int lldwt_absmax_slots(const float* x, int64_t planes, int64_t n_per_plane, float* slots, void* stream);
+extern "C" int lldwt_conv3x3_wgrad_f16x3_ex(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws,
+                                            const float* x_slots, const float* dy_slots, int cin, int cout, int64_t planes,
+                                            int64_t batch, int64_t h, int64_t w_, float alpha, void* stream);
 
 extern "C" int lldwt_conv3x3_wgrad_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int cin,
                                          int cout, int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha,
                                          void* stream) {
-    LLDWT_REQUIRE(x && dy && dw && slots_ws, "conv3x3_wgrad_f16x3: null pointer");
+    return lldwt_conv3x3_wgrad_f16x3_ex(x, dy, dw, dbias, slots_ws, nullptr, nullptr, cin, cout, planes, batch, h, w_, alpha, stream);
+}
+
+// + the per-plane |max| slots of x and / or dy when the caller holds them already (planes x 64 floats each, as lldwt_absmax_slots or
+// lldwt_conv2d_absmax leave them): the pass over that tensor is skipped.  slots_ws may be null when both are given.
+extern "C" int lldwt_conv3x3_wgrad_f16x3_ex(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws,
+                                            const float* x_slots, const float* dy_slots, int cin, int cout, int64_t planes,
+                                            int64_t batch, int64_t h, int64_t w_, float alpha, void* stream) {
+    LLDWT_REQUIRE(x && dy && dw && (slots_ws || (x_slots && dy_slots)), "conv3x3_wgrad_f16x3: null pointer");
     LLDWT_REQUIRE(cin > 0 && cout > 0 && planes > 0 && planes <= 65535 && batch > 0 && h > 0 && w_ >= 4, "conv3x3_wgrad_f16x3: bad dims");
     LLDWT_REQUIRE(w_ % 4 == 0, "conv3x3_wgrad_f16x3: the row length must be a multiple of 4 (16-byte row segments)");
     LLDWT_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dy) & 15) == 0, "conv3x3_wgrad_f16x3: x and dy must be 16-byte aligned");
     LLDWT_REQUIRE((int64_t)batch * (cin > cout ? cin : cout) * h * w_ < ((int64_t)1 << 40), "conv3x3_wgrad_f16x3: tensor too large");
+    LLDWT_REQUIRE((int64_t)WM * h * w_ < ((int64_t)1 << 31), "conv3x3_wgrad_f16x3: 128 * h * w = %ld exceeds the 32-bit offsets inside an image",
+                  (long)((int64_t)WM * h * w_));
+    LLDWT_REQUIRE(h < (1 << 23) && w_ < (1 << 23), "conv3x3_wgrad_f16x3: h, w must be below 2^23 (24-bit row offsets)");
     hipStream_t st = (hipStream_t)stream;
     // per-plane max |x| and max |dy| (two passes at HBM speed; 64 slots each)
-    float* sx = slots_ws;
-    float* sy = slots_ws + planes * 64;
-    int r = lldwt_absmax_slots(x, planes, batch * cin * h * w_, sx, stream);
-    if (r) return r;
-    r = lldwt_absmax_slots(dy, planes, batch * cout * h * w_, sy, stream);
-    if (r) return r;
+    const float* sx = x_slots ? x_slots : slots_ws;
+    const float* sy = dy_slots ? dy_slots : slots_ws + planes * 64;
+    int r;
+    if (!x_slots && (r = lldwt_absmax_slots(x, planes, batch * cin * h * w_, slots_ws, stream))) return r;
+    if (!dy_slots && (r = lldwt_absmax_slots(dy, planes, batch * cout * h * w_, slots_ws + planes * 64, stream))) return r;
     WgArgs a;
     a.x = x; a.dy = dy; a.dw = dw; a.db = dbias; a.sx = sx; a.sy = sy;
     a.cin = cin; a.cout = cout; a.batch = (int)batch; a.h = (int)h; a.w = (int)w_;
@@ -528,16 +815,20 @@ extern "C" int lldwt_conv3x3_wgrad_f16x3(const float* x, const float* dy, float*
         if (planes * ncol * s >= 2 * ncu && (planes * ncol * s) % ncu == 0) { slices = s; break; }
     while (slices > 8 && slices * 4 > nchunk) slices -= 8;
     a.slices = (int)slices;
+    // LLDWT_WGRAD3=v1 keeps the first kernel (three pre-shifted copies of the input rows, staging between two barriers)
+    static const bool v1 = [] { const char* e = getenv("LLDWT_WGRAD3"); return e && !strcmp(e, "v1"); }();
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_wgrad3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) {
-            set_error("conv3x3_wgrad_f16x3: cannot reserve %d bytes of LDS", LDS_TOTAL);
+        if (hipFuncSetAttribute((const void*)k_wgrad3_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad3_f16x3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, V2_TOTAL) != hipSuccess) {
+            set_error("conv3x3_wgrad_f16x3: cannot reserve %d bytes of LDS", V2_TOTAL);
             return LLDWT_EHIP;
         }
         attr = true;
     }
     dim3 grid((unsigned)(slices * ncol), 1, (unsigned)planes);
-    hipLaunchKernelGGL(k_wgrad3_f16x3, grid, dim3(256), LDS_TOTAL, st, a);
+    if (v1) hipLaunchKernelGGL(k_wgrad3_f16x3, grid, dim3(256), LDS_TOTAL, st, a);
+    else hipLaunchKernelGGL(k_wgrad3_f16x3_v2, grid, dim3(256), V2_TOTAL, st, a);
     return check_launch("conv3x3_wgrad_f16x3");
 }
 

@@ -538,18 +538,23 @@ def wgrad16_f16x3(x, dy, dw=None, db=None, alpha=1.0, swap_hw=False):
     return dw, db
 
 
-def conv3x3_wgrad_f16x3(x, dy, wshape, want_bias=True, alpha=1.0):
-    """Backward-weights of a dense 3x3 conv on the fp16 matrix cores, split-fp16 operands (lldwt_conv3x3_wgrad_f16x3).
-    x (P,B,cin,h,w), dy (P,B,cout,h,w) -> (dw (P,cout,cin,3,3), dbias (P,cout) or None)."""
+def conv3x3_wgrad_f16x3(x, dy, wshape, want_bias=True, alpha=1.0, x_slots=None, dy_slots=None):
+    """Backward-weights of a dense 3x3 conv on the fp16 matrix cores, split-fp16 operands (lldwt_conv3x3_wgrad_f16x3_ex).
+    x (P,B,cin,h,w), dy (P,B,cout,h,w) -> (dw (P,cout,cin,3,3), dbias (P,cout) or None).  x_slots / dy_slots: the (P,64)
+    |max| slots of x / dy (absmax_slots) if the caller has them already -- that pass is then skipped."""
     P, B, cin, h, wd = x.shape
     cout = dy.shape[2]
     if tuple(wshape) != (P, cout, cin, 3, 3) or dy.shape != (P, B, cout, h, wd):
         raise _lib.LLDWTError("conv3x3_wgrad_f16x3: shapes %r %r %r" % (tuple(x.shape), tuple(dy.shape), tuple(wshape)))
     dw = torch.zeros(wshape, device=x.device, dtype=torch.float32)
     db = torch.zeros(P, cout, device=x.device, dtype=torch.float32) if want_bias else None
-    slots = torch.empty(P * 128, device=x.device, dtype=torch.float32)
-    check(_lib.load().lldwt_conv3x3_wgrad_f16x3(_chk(x, "x"), _chk(dy, "dy"), _chk(dw), _opt(db), _chk(slots), cin, cout, P, B,
-                                               h, wd, float(alpha), _stream()), "conv3x3_wgrad_f16x3")
+    slots = torch.empty(P * 128, device=x.device, dtype=torch.float32) if x_slots is None or dy_slots is None else None
+    for nm, t in (("x_slots", x_slots), ("dy_slots", dy_slots)):
+        if t is not None and (t.numel() != P * 64 or t.dtype != torch.float32):
+            raise _lib.LLDWTError("conv3x3_wgrad_f16x3: %s must hold (P, 64) floats" % nm)
+    check(_lib.load().lldwt_conv3x3_wgrad_f16x3_ex(_chk(x, "x"), _chk(dy, "dy"), _chk(dw), _opt(db), _opt(slots), _opt(x_slots, "x_slots"),
+                                                  _opt(dy_slots, "dy_slots"), cin, cout, P, B, h, wd, float(alpha), _stream()),
+          "conv3x3_wgrad_f16x3")
     return dw, db
 
 

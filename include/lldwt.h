@@ -316,6 +316,13 @@ int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, float* dbi
  * path of the 243 -> 243 tree-context conv (LiftingBasedDWT_net.py:271-272); lldwt_conv2d_wgrad covers every other shape. */
 int lldwt_conv3x3_wgrad_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int cin, int cout,
                               int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, void* stream);
+/* As lldwt_conv3x3_wgrad_f16x3; x_slots / dy_slots (planes,64), if not null, are the per-plane |max| slots of x / dy the caller
+ * holds already (lldwt_absmax_slots, lldwt_conv2d_absmax): the pass over that tensor is skipped -- in a training step the forward
+ * conv has measured x and the backward-data conv dy (autograd of LiftingBasedDWT_net.py:271-272).  slots_ws may be null when
+ * both are given.                                                                                                           */
+int lldwt_conv3x3_wgrad_f16x3_ex(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws,
+                                 const float* x_slots, const float* dy_slots, int cin, int cout, int64_t planes, int64_t batch,
+                                 int64_t h, int64_t w_, float alpha, void* stream);
 /* Backward-weights of the 16 -> 16 5x5 convs of a P/U block (conv2 / conv3 of graphs/layers/P_block_v2.py:40-55; autograd of
  * agents/liftingDWT_agent.py:97) on the fp16 matrix cores, split-fp16 operands (fp32-level accuracy):
  *   dw[p][oc][ic][ty][tx] += alpha * sum_{b,y,x} dy[p][b][oc][y][x] * x[p][b][ic][y+ty-2][x+tx-2],  dbias += alpha * sum dy.

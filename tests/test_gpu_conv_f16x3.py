@@ -184,6 +184,39 @@ def test_wgrad_f16x3_vs_float64_and_fp32_kernel(shape):
     # accumulation semantics: alpha, and += into an existing buffer is the caller's (zeroed here)
     dw2, _ = ops.conv3x3_wgrad_f16x3(x.to(DEV), dy.to(DEV), (P, cout, cin, 3, 3), want_bias=False, alpha=-0.5)
     assert float((dw2 + 0.5 * dw).abs().max()) < 1e-5 * float(dw.abs().max())
+    # the |max| slots handed in by the caller (lldwt_conv3x3_wgrad_f16x3_ex): same scales, same arithmetic -- equal up to the order of
+    # the float atomics; either one alone, too
+    xs, ds = ops.absmax_slots(x.to(DEV)), ops.absmax_slots(dy.to(DEV))
+    for kw in (dict(x_slots=xs, dy_slots=ds), dict(x_slots=xs), dict(dy_slots=ds)):
+        dw3, db3 = ops.conv3x3_wgrad_f16x3(x.to(DEV), dy.to(DEV), (P, cout, cin, 3, 3), **kw)
+        assert float((dw3 - dw).abs().max()) < 1e-5 * float(dw.abs().max())
+        assert float((db3 - db).abs().max()) < 1e-5 * float(db.abs().max())
+    with pytest.raises(Exception):
+        ops.conv3x3_wgrad_f16x3(x.to(DEV), dy.to(DEV), (P, cout, cin, 3, 3), x_slots=xs[:, :32].contiguous())
+
+
+def test_wgrad_f16x3_both_kernels_agree():
+    """k_wgrad3_f16x3_v2 (one copy of the input rows + register shifts, staging in the MFMA shadow; the default) against the first
+    kernel (LLDWT_WGRAD3=v1, read at the first call: a child process) on a shape with several chunks per slice, partial channel
+    blocks and a ragged last chunk column."""
+    import subprocess, sys, os
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import ops\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "x = ((torch.rand(2, 3, 100, 38, 84, generator=g) - 0.3) * 2).cuda(); dy = (torch.randn(2, 3, 243, 38, 84, generator=g) * 1e-3).cuda()\n"
+        "dw, db = ops.conv3x3_wgrad_f16x3(x, dy, (2, 243, 100, 3, 3))\n"
+        "torch.save((dw.cpu(), db.cpu()), sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("v1", "v2"):
+            env = dict(os.environ, LLDWT_WGRAD3=mode)
+            f = os.path.join(td, mode + ".pt")
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
+            out[mode] = torch.load(f, weights_only=True)
+    for a, b in zip(out["v1"], out["v2"]):
+        assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
 
 
 def test_fused_pair_random_shapes():
