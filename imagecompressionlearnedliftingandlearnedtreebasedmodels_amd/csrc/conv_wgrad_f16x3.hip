@@ -281,6 +281,17 @@ __host__ __device__ constexpr int v2_first_piece(int b) {
 }
 static_assert(v2_first_piece(8) == NX4 + NA4, "every staging piece has a block");
 
+// hi / lo split in plain C for k_wgrad3_f16x3_v2: the v_fma_mix form of split4v is inline assembly, which the scheduler cannot
+// place into the VALU groups of a sched_group_barrier sequence (the staging pieces then cluster behind the MFMAs)
+__device__ __forceinline__ void split4c(const float (&v)[4], half4& hi, half4& lo) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const half2 a = __builtin_convertvector((f2){v[0], v[1]}, half2), b = __builtin_convertvector((f2){v[2], v[3]}, half2);
+    hi = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+    const half2 c = __builtin_convertvector((f2){v[0] - (float)a[0], v[1] - (float)a[1]}, half2);
+    const half2 d = __builtin_convertvector((f2){v[2] - (float)b[0], v[3] - (float)b[1]}, half2);
+    lo = __builtin_shufflevector(c, d, 0, 1, 2, 3);
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_wgrad3_f16x3_v2(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] *= sY;
         half4 hi, lo;
-        split4v(v, hi, lo);
+        split4c(v, hi, lo);
         uint8_t* d = buf + oc * A_PITCH + (row * CW + x4) * 2;
         *reinterpret_cast<half4*>(d) = hi;
         *reinterpret_cast<half4*>(d + A_PART) = lo;
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = ok ? rx[j][i] * sX : 0.f;
         half4 hi, lo;
-        split4v(v, hi, lo);
+        split4c(v, hi, lo);
         uint8_t* d = buf + V2_B + ic * B2_IC + row * B2_ROW + s * 8;
         *reinterpret_cast<half4*>(d) = hi;
         *reinterpret_cast<half4*>(d + B2_PART) = lo;
@@ -404,12 +415,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
     int cur = 0;
+    // positions of the chunk staged during the current one (cn; its operands are in the registers) and of the chunk loaded during it
+    // (c2); the next iteration's c2 is worked out in the middle of this one (scalar divisions: ~90 instructions that sat at the top of
+    // every chunk with the matrix pipe empty)
+    Pos cn = coords(min(chunk + a.slices, nchunk - 1)), c2 = coords(min(chunk + 2 * a.slices, nchunk - 1)), c3 = c2;
 #pragma unroll 1
     while (true) {
         const int nxt = chunk + a.slices;
         const bool live = nxt < nchunk;
-        const Pos cn = coords(min(nxt, nchunk - 1));              // staged during this chunk (already in the registers)
-        const Pos c2 = coords(min(nxt + a.slices, nchunk - 1));   // loaded during this chunk
         const uint8_t* cb = lds + cur * V2_BUF;
         uint8_t* sb = lds + (cur ^ 1) * V2_BUF;
         const uint8_t* ab = cb + (wave * 32 + l31) * A_PITCH + kg * 16;
@@ -476,12 +489,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     load_a(pc - NX4, c2);
                 }
             }
+            if constexpr (blk == 4) c3 = coords(min(nxt + 2 * a.slices, nchunk - 1));
             // issue order inside the block: an MFMA, then a share of the block's vector / LDS / memory work
 #pragma unroll
             for (int i = 0; i < nm; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (blk + 2 < 8 && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, nm == 9 ? (npc == 2 ? 9 : 7) : 6, 0);
+                if (blk == 4) __builtin_amdgcn_sched_group_barrier(0x004, 5, 0);        // the scalar chain of c3
                 if (i >= nm - 2 * npc) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 if (i >= nm - npc) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
@@ -498,6 +513,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
         chunk = nxt;
         cur ^= 1;
+        cn = c2;
+        c2 = c3;
         if (!live) break;
     }
 
