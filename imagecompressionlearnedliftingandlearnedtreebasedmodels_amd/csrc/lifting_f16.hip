@@ -91,10 +91,11 @@ constexpr int LDS_S16 = LDS_T2 + 4 * N2 * 16;                         // skip pa
 constexpr int NS16 = NS + 48;                                         // copy 1 is copy 0 shifted by one element (aligned pair reads
 constexpr int LDS_TOTAL = LDS_S16 + 4 * NS16 * 2;                     // at odd columns); tails zeroed; copy 1 starts 16 banks after
 static_assert((2 * NS16 * 2) % 128 == 64, "even- and odd-column lanes read different banks");   // copy 0.  159,360 B
-constexpr int LDS_T3 = LDS_T1, LDS_D = LDS_T2;
-constexpr int LDS_STG = LDS_T2 + 20480;                               // sequential path: next tile's operands, 10 floats per thread, inside T2
-static_assert(ND * 8 * 4 <= 20480 && 20480 + 10 * NTH * 4 <= 4 * N2 * 16, "staging fits T2 behind the sequential path's D image");
-static_assert(4 * N3 * 16 <= 4 * N1 * 16 && ND * 8 * 4 <= 4 * N2 * 16, "aliases fit");
+// sequential path (debug check, TRAIN, BWD): T3 takes the front of the T1 region and the D image sits behind it, so that the T2 image
+// stays whole until the tile ends -- its last rows are handed down to the tile below like on the composed path (T1 is not: T3
+// overwrites it), and the next tile's staged operands use the composed path's slots in T2 rows 8..15
+constexpr int LDS_T3 = LDS_T1, LDS_D = LDS_T1 + 4 * N3 * 16;
+static_assert(4 * N3 * 16 + ND * 8 * 4 <= 4 * N1 * 16, "T3 and the D image of the sequential path fit the T1 region");
 // ---- vertical reuse (composed path).  A workgroup walks DOWN a column of tiles (a "run"); the tile below needs t1 on image
 // rows y0 + 10 .. y0 + 38 and t2 on y0 + 12 .. y0 + 36, of which the first 12 (t1) and 8 (t2) rows are the LAST rows of this
 // tile's T images: they are handed down (moved to the top of the images through registers while the skip patch of the next
@@ -106,6 +107,9 @@ static_assert(4 * N3 * 16 <= 4 * N1 * 16 && ND * 8 * 4 <= 4 * N2 * 16, "aliases 
 constexpr int KEEP1 = 12, KEEP2 = 8;                                  // rows handed down
 constexpr int T1A = N1 * 16, T2A = N2 * 16;                           // bytes per array
 constexpr int NT1C = (N1 - KEEP1 * R1W) / 16, NT2C = (N2 - KEEP2 * R2W) / 16;      // 44, 40
+// sequential path: only T2 is handed down, so a continuing tile needs t1 on rows 8..27 (the 20 rows under its 16 new t2 rows)
+constexpr int NT1S = (N1 - KEEP2 * R1W) / 16;                                      // 55
+static_assert((KEEP2 * R1W) % 16 == 0, "a continuing tile of the sequential path starts t1 on a whole MFMA tile");
 static_assert((KEEP1 * R1W) % 16 == 0 && (KEEP2 * R2W) % 16 == 0, "a continuing tile starts on a whole MFMA tile");
 constexpr int DPIECE_PX = 4 * R2W, DPIECE_BYTES = DPIECE_PX * 12 * 4;  // 160 px, 7 680 B
 constexpr int T3V_PER = 56;
@@ -643,11 +647,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // slot v (0..9) of thread tid.  Composed path: 20 KB laid across rows 8..15 of the four T2 arrays (rows 16..23 are handed
     // down in place, rows 0..7 receive the handed-down rows at the start of the next tile); sequential path: behind its D image
     auto stg = [&](int v, int tid) -> float* {
-        if constexpr (SEQ) return reinterpret_cast<float*>(lds + LDS_STG) + v * NTH + tid;
-        else {       // half-slots of 256 floats, five per array: which array is wave-uniform (scalar arithmetic), one add per lane
-            const int hs = 2 * v + __builtin_amdgcn_readfirstlane(tid >> 8), arr = hs / 5;
-            return reinterpret_cast<float*>(lds + LDS_T2 + arr * T2A + T2HALF) + (hs - arr * 5) * 256 + (tid & 255);
-        }
+        // half-slots of 256 floats, five per array: which array is wave-uniform (scalar arithmetic), one add per lane
+        const int hs = 2 * v + __builtin_amdgcn_readfirstlane(tid >> 8), arr = hs / 5;
+        return reinterpret_cast<float*>(lds + LDS_T2 + arr * T2A + T2HALF) + (hs - arr * 5) * 256 + (tid & 255);
     };
     auto stage = [&](int tid, const LfPre& pr) {
 #pragma unroll
@@ -665,6 +667,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         stage(tid0, pr0);
     }
     int item_i = (int)blockIdx.x, run_j = 0;
+    float act2_prev = ACT_SCALE;                               // BWD: the operand scale of the T2 rows the tile above handed down
     while (item_i < a.nitems) {
     // every per-lane index below derives from an OPAQUE copy of the thread id: otherwise the compiler hoists all the
     // tile-invariant per-lane address arithmetic of all phases out of the tile loop and spills it
@@ -677,8 +680,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int64_t z;
     int y0, x0, seglen;
     decode(item_i, run_j, z, y0, x0, seglen);
-    const bool cont = !SEQ && run_j > 0;                       // the tile above handed down its last T1 / T2 rows
-    const bool hand_down = !SEQ && run_j + 1 < seglen;
+    const bool cont = run_j > 0;                               // the tile above handed down its last T2 rows (composed path: and T1 rows)
+    const bool hand_down = run_j + 1 < seglen;
+    // TRAIN / BWD: the rows of T1 / T2 this tile writes out.  A tile's own 16 rows are T1 rows 6..21 (T2: 4..19); a continuing tile
+    // does not compute its first T1 rows 6, 7 (T2: 4..7) -- the tile above does, as its rows 22, 23 (T2: 20..23), and stores them
+    const int st1_lo = cont ? KEEP2 : 6, st1_hi = hand_down ? 6 + TH + 2 : 6 + TH;
+    const int st2_lo = cont ? KEEP2 : 4, st2_hi = hand_down ? 4 + TH + 4 : 4 + TH;
+    (void)st1_lo; (void)st1_hi; (void)st2_lo; (void)st2_hi;
     int next_item = item_i;
     const int next_j = hand_down ? run_j + 1 : 0;
     int* QN = reinterpret_cast<int*>(lds + LDS_RED) + 16;       // the run this workgroup takes next (broadcast through LDS)
@@ -707,12 +715,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
         constexpr int NARR = PREC == 0 ? 4 : 2;                                       // one product: the two hi arrays only
         constexpr int MV1 = NARR * KEEP1 * R1W, MV2 = NARR * KEEP2 * R2W;             // 16-byte pieces: 2112, 1280
+        if constexpr (!SEQ) {
 #pragma unroll
-        for (int k = 0; k < (MV1 + NTH - 1) / NTH; ++k) {
-            const int c = tid + k * NTH, arr = c / (KEEP1 * R1W), px = c - arr * (KEEP1 * R1W);
-            if (c < MV1)
-                *reinterpret_cast<uintx4_t*>(lds + LDS_T1 + arr * T1A + px * 16) =
-                    *reinterpret_cast<const uintx4_t*>(lds + LDS_T1 + arr * T1A + ((N1 - KEEP1 * R1W) + px) * 16);
+            for (int k = 0; k < (MV1 + NTH - 1) / NTH; ++k) {
+                const int c = tid + k * NTH, arr = c / (KEEP1 * R1W), px = c - arr * (KEEP1 * R1W);
+                if (c < MV1)
+                    *reinterpret_cast<uintx4_t*>(lds + LDS_T1 + arr * T1A + px * 16) =
+                        *reinterpret_cast<const uintx4_t*>(lds + LDS_T1 + arr * T1A + ((N1 - KEEP1 * R1W) + px) * 16);
+            }
         }
 #pragma unroll
         for (int k = 0; k < (MV2 + NTH - 1) / NTH; ++k) {
@@ -772,6 +782,27 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             act2 = pow2_scale(m * scales[13] * scales[14]);
         }
     }
+    if constexpr (BWD) {
+        // the handed-down dpre2 rows carry the scale of the tile above (bound-based, per tile): bring them to this tile's.  Each
+        // thread rescales the pieces it moved itself (rows 0..7, nobody else touches them before P2); both scales are powers of two
+        // and the values obey this tile's bound too (they depend on g rows y0 - 8 .. y0 + 7 only, all inside this tile's patch)
+        if (cont && act2 != act2_prev) {
+            const float ratio = act2 * __int_as_float(0x7F000000 - __float_as_int(act2_prev));
+            constexpr int MV2 = 4 * KEEP2 * R2W;
+#pragma unroll
+            for (int k = 0; k < (MV2 + NTH - 1) / NTH; ++k) {
+                const int c = tid + k * NTH, arr = c / (KEEP2 * R2W), px = c - arr * (KEEP2 * R2W);
+                if (c < MV2) {
+                    half8* q = reinterpret_cast<half8*>(lds + LDS_T2 + arr * T2A + px * 16);
+                    half8 v = *q;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] * ratio);
+                    *q = v;
+                }
+            }
+        }
+        act2_prev = act2;
+    }
     // s_skip = 2^k (|k| <= 120): its reciprocal by exponent arithmetic, exact, instead of a 10-instruction division
     const float inv1 = __int_as_float(0x7F000000 - __float_as_int(s_skip)) * isw1;
     {   // the scaled split-fp16 images of the patch (this thread's own three values, still in registers)
@@ -820,7 +851,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // image: the conv2' epilogue reads the gate of a pixel from the very slot it then overwrites with dpre2.  Outside the image
     // the value is irrelevant (those pixels are masked to 0).  (pixel, group of 4 channels) items, 3 840 of them.
     if constexpr (BWD) {
-        for (int i = tid; i < N2 * 4; i += NTH) {
+        for (int i = (cont ? KEEP2 * R2W * 4 : 0) + tid; i < N2 * 4; i += NTH) {      // a continuing tile: rows 8..23 (0..7 hold dpre2)
             const int p = i >> 2, c4 = (i & 3) * 4;
             const int r = p / R2W, c = p - r * R2W;
             const int gy = min(max(y0 - 4 + r, 0), h - 1), gx = min(max(x0 - 4 + c, 0), w - 1);
@@ -839,8 +870,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // last one (same bytes stored again)
     if (!(a.dbg & 1)) {
         // a continuing tile computes rows 12..27 only (tiles 33..76)
-        const int nt1 = cont ? NT1C : NT1, tb1 = NT1 - nt1;
-        const int nit1 = (nt1 + 2 * NWAVE - 1) / (2 * NWAVE);           // 5, or 3
+        // (sequential path: rows 8..27, tiles 22..76 -- T1 itself is not handed down there)
+        const int nt1 = cont ? (SEQ ? NT1S : NT1C) : NT1, tb1 = NT1 - nt1;
+        const int nit1 = (nt1 + 2 * NWAVE - 1) / (2 * NWAVE);           // 5, or 3 (sequential path: 4)
+
         float mx1 = 0.f;                        // BWD: max |dt3| x act1 over this wave's values (for the weight gradient's dY scale)
 #pragma unroll 1
         for (int it = 0; it < nit1; ++it) {
@@ -872,7 +905,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if constexpr (BWD) {
                     const int r = pq[t] / R1W, c = pq[t] - r * R1W;
                     const int gy = y0 + r - 6, gx = x0 + c - 6;
-                    if (r >= 6 && r < 6 + TH && c >= 6 && c < 6 + TW && gy < h && gx < w) {
+                    if (r >= st1_lo && r < st1_hi && c >= 6 && c < 6 + TW && gy < h && gx < w) {
                         float* d = a.sv_t3 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = acc[t][q] * inv1;
@@ -881,7 +914,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if constexpr (TRAIN) {
                     const int r = pq[t] / R1W, c = pq[t] - r * R1W;
                     const int gy = y0 + r - 6, gx = x0 + c - 6;
-                    if (r >= 6 && r < 6 + TH && c >= 6 && c < 6 + TW && gy < h && gx < w) {
+                    if (r >= st1_lo && r < st1_hi && c >= 6 && c < 6 + TW && gy < h && gx < w) {
                         float* d = a.sv_t1 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = v[q] * (1.f / ACT_SCALE);
@@ -964,7 +997,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if constexpr (BWD) {
                     const int r = pp[t] / R2W, c = pp[t] - r * R2W;
                     const int gy = y0 + r - 4, gx = x0 + c - 4;
-                    if (!pdup[t] && r >= 4 && r < 4 + TH && c >= 4 && c < 4 + TW && gy < h && gx < w) {
+                    if (!pdup[t] && r >= st2_lo && r < st2_hi && c >= 4 && c < 4 + TW && gy < h && gx < w) {
                         float* d = a.sv_t2 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = v[q] * inv_act2;
@@ -973,7 +1006,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if constexpr (TRAIN) {
                     const int r = pp[t] / R2W, c = pp[t] - r * R2W;
                     const int gy = y0 + r - 4, gx = x0 + c - 4;
-                    if (r >= 4 && r < 4 + TH && c >= 4 && c < 4 + TW && gy < h && gx < w) {
+                    if (r >= st2_lo && r < st2_hi && c >= 4 && c < 4 + TW && gy < h && gx < w) {
                         float* d = a.sv_t2 + (zv * LF_C + oc0) * (int64_t)h * w + (int64_t)gy * w + gx;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) d[(int64_t)q * h * w] = v[q] * (1.f / ACT_SCALE);
@@ -1007,11 +1040,18 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 int q0;
                 const int b0 = tile_base(wave + 4 * NWAVE, q0);
                 conv16_tile1<R1W, N1, PREC>(lds + LDS_T1, b0, hi_tap, ah, al, n0, slice);
-                const float pin0 = in_image(q0);
-                float v[4];
+                if constexpr (SEQ) {            // TRAIN / BWD: the single tile's epilogue is a pair's first half (gates, saved tensors, maxima)
+                    pc[0] = n0; pp[0] = q0; pin[0] = in_image(q0); pdup[0] = false;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = tanh_scaled_masked(n0[q], inv2c, bvc[q], pin0, -2.f * pin0);
-                timg_store<N2, PREC>(lds + LDS_T2, q0, oc0, v);
+                    for (int ks = 0; ks < 4; ++ks) slice(ks);
+                    slice(8);
+                } else {
+                    const float pin0 = in_image(q0);
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = tanh_scaled_masked(n0[q], inv2c, bvc[q], pin0, -2.f * pin0);
+                    timg_store<N2, PREC>(lds + LDS_T2, q0, oc0, v);
+                }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 10; ++ks) slice(ks);
@@ -1564,7 +1604,8 @@ int lift_f16_step_any(const LiftF16Views& v, const LiftF16Views* v2, const LiftF
         }
         ncu = prop.multiProcessorCount;
     }
-    // the sequential evaluation hands nothing down (its T3 / D images overwrite T1 / T2)
+    // the sequential evaluation (debug check, TRAIN, BWD) hands down T2 only (its T3 image overwrites T1): a continuing tile still
+    // saves a third of conv2 and 29 % of conv1
     const bool seq = (a.dbg & 16) != 0 || sv != nullptr || bw != nullptr;
     a.sv_src = sv ? sv->src : nullptr; a.sv_skip = sv ? sv->skip : nullptr;
     a.sv_t1 = sv ? sv->t1 : nullptr; a.sv_t2 = sv ? sv->t2 : nullptr; a.sv_t3 = sv ? sv->t3 : nullptr;
@@ -1577,14 +1618,17 @@ int lift_f16_step_any(const LiftF16Views& v, const LiftF16Views* v2, const LiftF
     // run length: a tile that continues a run costs ~0.8 of a first tile; runs are dealt round-robin to one resident
     // workgroup per CU, so the launch takes rounds x (cost of a run) -- the longest run that still fills whole rounds
     int best_rl = 1;
-    if (!seq && !(a.dbg & 32)) {
+    if (!(a.dbg & 32)) {
+        const double cont_cost = seq ? 0.85 : 0.8;
         double best = 1e30;
         for (int rl = 1; rl <= a.tiles_y; ++rl) {
             const int64_t items = (int64_t)Zl * a.tiles_x * cdiv(a.tiles_y, rl);
-            const double cost = (double)cdiv(items, ncu) * (1.0 + 0.8 * (rl - 1));
+            const double cost = (double)cdiv(items, ncu) * (1.0 + cont_cost * (rl - 1));
             if (cost < best - 1e-9) { best = cost; best_rl = rl; }
         }
     }
+    static const int force_rl = [] { const char* e = getenv("LLDWT_LF_RL"); return e ? atoi(e) : 0; }();      // diagnostics: fixed run length
+    if (force_rl > 0) best_rl = force_rl < a.tiles_y ? force_rl : a.tiles_y;
     a.rl = best_rl;
     a.nseg = (int)cdiv(a.tiles_y, a.rl);
     a.nitems = (int)(Zl * a.tiles_x * a.nseg);
