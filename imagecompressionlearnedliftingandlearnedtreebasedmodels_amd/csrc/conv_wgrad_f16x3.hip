@@ -596,7 +596,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int plane = blockIdx.z, slice = blockIdx.x;
+    // workgroups go to the 8 XCDs round-robin: with a multiple of 8 slices per plane, workgroup x runs on XCD x % 8.  The chunks of a
+    // step are dealt so that one XCD gets a CONTIGUOUS eighth of them (horizontal and vertical neighbours): the halo columns / rows
+    // two neighbouring chunks both read (x is fetched 2.06 times otherwise) then meet in that XCD's L2
+    const int plane = blockIdx.z;
+    const int slice = (a.slices & 7) == 0 ? ((int)blockIdx.x & 7) * (a.slices >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int h = a.h, w = a.w;
     const int64_t hw = (int64_t)h * w;
     const int nchunk_img = a.chunks_x * a.chunks_y;
@@ -779,6 +783,258 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+
+// ================================================================================================================
+// k_wgrad16_f16x3_v2 -- the same GEMM, chunk and LDS images as k_wgrad16_f16x3 with the recipe of k_wgrad3_f16x3_v2: TWO LDS buffers
+// (2 x 48 KB, one workgroup per CU, one wave per SIMD), the 13 float4 pieces of chunk n+1 split and stored into the other buffer in
+// the shadow of chunk n's 150 MFMAs, each piece's registers reloaded right behind it with chunk n+2 (a whole chunk period in flight:
+// v1 issued a chunk's loads and consumed them between the same two barriers, so every chunk paid an HBM round trip that only the
+// second workgroup of the CU could hide), window reads two blocks ahead, one barrier per chunk.  10 blocks (chunk row of the wave,
+// vertical tap) of 15 MFMAs; the 16 x 16 x 32 MFMA leaves two vector issue slots per MFMA, so this kernel is bound by its vector
+// work (fragment cuts + staging, ~850 instructions per chunk) and, behind that, by the operand bytes (50 KB per chunk).
+constexpr int G2_BUF = G_LDS_DUMP;                           // 48 128 B per buffer (dY hi | lo, x hi | lo)
+constexpr int G2_DUMP = 2 * G2_BUF;
+constexpr int G2_TOTAL = G2_DUMP + 64;                       // 96 320 B
+// 13 staging pieces (9 of x, then 4 of dY) over the 10 MFMA blocks: 1 1 2 1 1 2 1 1 2 1
+__host__ __device__ constexpr int g2_first_piece(int b) { return b + b / 3; }
+static_assert(g2_first_piece(0) == 0 && g2_first_piece(3) == 4 && g2_first_piece(9) == 12 && g2_first_piece(10) == 13, "13 pieces over 10 blocks");
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_wgrad16_f16x3_v2(Wg16Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int plane = blockIdx.z;
+    const int slice = (a.slices & 7) == 0 ? ((int)blockIdx.x & 7) * (a.slices >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;   // see v1
+    const int h = a.h, w = a.w;
+    const int hw = h * w;                             // 16 * h * w < 2^31 (checked on the host): 32-bit offsets inside an image
+    const int nchunk_img = a.chunks_x * a.chunks_y;
+    const int nchunk = a.batch * nchunk_img;
+    if (slice >= nchunk) return;                      // uniform, before any barrier
+    float ay = a.sy[plane * a.sy_stride + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ay = fmaxf(ay, __shfl_xor(ay, o, 64));
+    const float sY = pow2_scale_for(ay);
+    constexpr float sX = 16384.f;
+
+    floatx4 acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const float* xp = a.x + (int64_t)plane * a.batch * 16 * hw;
+    const float* yp = a.dy + (int64_t)plane * a.batch * 16 * hw;
+    floatx4 ra[G_NA4], rx[G_NX4];
+    float dbs[G_NA4];
+#pragma unroll
+    for (int j = 0; j < G_NA4; ++j) dbs[j] = 0.f;
+
+    struct Pos { const float* xb; const float* yb; int y0, x0; };       // wave-uniform
+    auto coords = [&](int chunk) -> Pos {
+        const int img = chunk / nchunk_img, rem = chunk - img * nchunk_img, cy = rem / a.chunks_x;
+        return Pos{xp + (int64_t)img * 16 * hw, yp + (int64_t)img * 16 * hw, cy * G_CR, (rem - cy * a.chunks_x) * G_CW};
+    };
+    // dY piece j: float4 f = tid + 256 j -> oc = f / 64, row = (f % 64) / 8, x4 = 4 (f % 8)
+    auto load_a = [&](int j, const Pos& c) {
+        const int f = tid + 256 * j;
+        const int oc = f >> 6, row = (f >> 3) & 7, x4 = (f & 7) * 4;
+        const int gy = min(c.y0 + row, h - 1), gx = min(c.x0 + x4, w - 4);
+        ra[j] = *reinterpret_cast<const floatx4*>(c.yb + (unsigned)(oc * hw + __mul24(gy, w) + gx));
+    };
+    // x piece j: f = tid + 256 j -> ic = f / 132, row = (f % 132) / 11 (image row y0 - 2 + row), segment s = f % 11 (columns x0-4+4s ..)
+    auto load_x = [&](int j, const Pos& c) {
+        const int f = min(tid + 256 * j, 16 * G_XR * G_XSEG - 1);
+        const int ic = f / (G_XR * G_XSEG), r2 = f - ic * (G_XR * G_XSEG), row = r2 / G_XSEG, s = r2 - row * G_XSEG;
+        const int gy = min(max(c.y0 - 2 + row, 0), h - 1), gx = min(max(c.x0 - 4 + 4 * s, 0), w - 4);
+        rx[j] = *reinterpret_cast<const floatx4*>(c.xb + (unsigned)(ic * hw + __mul24(gy, w) + gx));
+    };
+    auto stage_a = [&](int j, const Pos& c, bool livec, uint8_t* buf) {
+        const int f = tid + 256 * j;
+        const int oc = f >> 6, row = (f >> 3) & 7, x4 = (f & 7) * 4;
+        const bool ok = (int)livec & (int)(c.y0 + row < h) & (int)(c.x0 + x4 < w);
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ok ? ra[j][i] : 0.f;
+        dbs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= sY;
+        half4 hi, lo;
+        split4c(v, hi, lo);
+        uint8_t* d = buf + G_LDS_A + oc * G_AP + (row * G_CW + x4) * 2;
+        *reinterpret_cast<half4*>(d) = hi;
+        *reinterpret_cast<half4*>(d + G_APART) = lo;
+    };
+    auto stage_x = [&](int j, const Pos& c, uint8_t* buf) {
+        const int f = tid + 256 * j;
+        const bool live = f < 16 * G_XR * G_XSEG;
+        const int fc = live ? f : 0;
+        const int ic = fc / (G_XR * G_XSEG), r2 = fc - ic * (G_XR * G_XSEG), row = r2 / G_XSEG, s = r2 - row * G_XSEG;
+        const int gy = c.y0 - 2 + row, gx = c.x0 - 4 + 4 * s;
+        const bool ok = (int)((unsigned)gy < (unsigned)h) & (int)((unsigned)gx < (unsigned)w);     // w % 4 == 0: whole segments
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ok ? rx[j][i] * sX : 0.f;
+        half4 hi, lo;
+        split4c(v, hi, lo);
+        // element e of a patch row holds column x0 - 2 + e: this segment's columns are elements 4s-2 .. 4s+1 = two aligned fp16 pairs;
+        // pairs outside the 40 slots and dead tasks go to a dump slot
+        uint8_t* rowp = buf + G_LDS_B + ic * G_BC + row * G_BR;
+        uint8_t* dump = lds + G2_DUMP;
+        const int e0 = 4 * s - 2;
+        const bool k0 = (int)live & (int)(e0 >= 0), k1 = (int)live & (int)(e0 + 2 < 40);
+        uint8_t* d0 = k0 ? rowp + e0 * 2 : dump;
+        uint8_t* d1 = k1 ? rowp + (e0 + 2) * 2 : dump + 8;
+        *reinterpret_cast<half2*>(d0) = half2{hi[0], hi[1]};
+        *reinterpret_cast<half2*>(d0 + (k0 ? G_BPART : 4)) = half2{lo[0], lo[1]};
+        *reinterpret_cast<half2*>(d1) = half2{hi[2], hi[3]};
+        *reinterpret_cast<half2*>(d1 + (k1 ? G_BPART : 4)) = half2{lo[2], lo[3]};
+    };
+
+    const int kg = lane >> 4, l15 = lane & 15;
+    int chunk = slice;
+    {
+        const Pos c = coords(chunk);
+#pragma unroll
+        for (int j = 0; j < G_NX4; ++j) load_x(j, c);
+#pragma unroll
+        for (int j = 0; j < G_NA4; ++j) load_a(j, c);
+#pragma unroll
+        for (int j = 0; j < G_NX4; ++j) stage_x(j, c, lds);
+#pragma unroll
+        for (int j = 0; j < G_NA4; ++j) stage_a(j, c, true, lds);
+        const Pos c1 = coords(min(chunk + a.slices, nchunk - 1));
+#pragma unroll
+        for (int j = 0; j < G_NX4; ++j) load_x(j, c1);
+#pragma unroll
+        for (int j = 0; j < G_NA4; ++j) load_a(j, c1);
+    }
+    __syncthreads();
+    int cur = 0;
+    Pos cn = coords(min(chunk + a.slices, nchunk - 1)), c2 = coords(min(chunk + 2 * a.slices, nchunk - 1)), c3 = c2;
+#pragma unroll 1
+    while (true) {
+        const int nxt = chunk + a.slices;
+        const bool livec = nxt < nchunk;
+        const uint8_t* cb = lds + cur * G2_BUF;
+        uint8_t* sb = lds + (cur ^ 1) * G2_BUF;
+        const uint8_t* abase = cb + G_LDS_A + l15 * G_AP + kg * 16;
+        const uint8_t* bbase = cb + G_LDS_B + l15 * G_BC + kg * 16;
+        half8 fah[2], fal[2];                         // A fragments of the wave's two chunk rows
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            fah[rr] = *reinterpret_cast<const half8*>(abase + (wave + 4 * rr) * G_CW * 2);
+            fal[rr] = *reinterpret_cast<const half8*>(abase + (wave + 4 * rr) * G_CW * 2 + G_APART);
+        }
+        half8 bh[2][5], bl[2][5];                     // B fragments [set][tx]
+        uintx4 wh[2][2], wl[2][2];                    // the aligned windows they are cut from [set][window]
+        auto windows = [&](int blk, int set) {        // block = (rr, ty): patch row wave + 4 rr + ty
+            const int rr = blk / 5, ty = blk - 5 * rr;
+            const uint8_t* bp = bbase + (wave + 4 * rr + ty) * G_BR;
+            wh[set][0] = *reinterpret_cast<const uintx4*>(bp);
+            wh[set][1] = *reinterpret_cast<const uintx4*>(bp + 16);
+            wl[set][0] = *reinterpret_cast<const uintx4*>(bp + G_BPART);
+            wl[set][1] = *reinterpret_cast<const uintx4*>(bp + G_BPART + 16);
+        };
+        auto cut = [&](int set) {                     // shift tx: elements tx .. tx + 7 of the 16 in the two windows
+            const unsigned dh[8] = {wh[set][0][0], wh[set][0][1], wh[set][0][2], wh[set][0][3], wh[set][1][0], wh[set][1][1], wh[set][1][2], wh[set][1][3]};
+            const unsigned dl[8] = {wl[set][0][0], wl[set][0][1], wl[set][0][2], wl[set][0][3], wl[set][1][0], wl[set][1][1], wl[set][1][2], wl[set][1][3]};
+#pragma unroll
+            for (int tx = 0; tx < 5; ++tx) {
+                uintx4 fh, fl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fh[i] = tx % 2 == 0 ? dh[tx / 2 + i] : __builtin_amdgcn_alignbit(dh[tx / 2 + i + 1], dh[tx / 2 + i], 16);
+                    fl[i] = tx % 2 == 0 ? dl[tx / 2 + i] : __builtin_amdgcn_alignbit(dl[tx / 2 + i + 1], dl[tx / 2 + i], 16);
+                }
+                bh[set][tx] = __builtin_bit_cast(half8, fh);
+                bl[set][tx] = __builtin_bit_cast(half8, fl);
+            }
+        };
+        windows(0, 0);
+        windows(1, 1);
+        cut(0);
+        __builtin_amdgcn_sched_barrier(0);
+        auto block = [&](auto BLK) {
+            constexpr int blk = decltype(BLK)::value;
+            constexpr int rr = blk / 5, ty = blk - 5 * rr, set = blk & 1;
+            constexpr int p0 = g2_first_piece(blk), p1 = g2_first_piece(blk + 1), npc = p1 - p0;
+            if constexpr (blk + 1 < 10) cut(set ^ 1);
+            if constexpr (blk + 2 < 10) windows(blk + 2, set);
+#pragma unroll
+            for (int tx = 0; tx < 5; ++tx) {
+                const int t = ty * 5 + tx;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal[rr], bh[set][tx], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[rr], bl[set][tx], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[rr], bh[set][tx], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int pc = p0; pc < p1; ++pc) {
+                if (pc < G_NX4) {
+                    stage_x(pc, cn, sb);
+                    load_x(pc, c2);
+                } else {
+                    stage_a(pc - G_NX4, cn, livec, sb);
+                    load_a(pc - G_NX4, c2);
+                }
+            }
+            if constexpr (blk == 5) c3 = coords(min(nxt + 2 * a.slices, nchunk - 1));
+#pragma unroll
+            for (int i = 0; i < 15; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (blk + 2 < 10 && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, npc == 2 ? 9 : 7, 0);
+                if (blk == 5) __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+                if (i >= 15 - 5 * npc) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (i >= 15 - npc) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        block(std::integral_constant<int, 0>{});
+        block(std::integral_constant<int, 1>{});
+        block(std::integral_constant<int, 2>{});
+        block(std::integral_constant<int, 3>{});
+        block(std::integral_constant<int, 4>{});
+        block(std::integral_constant<int, 5>{});
+        block(std::integral_constant<int, 6>{});
+        block(std::integral_constant<int, 7>{});
+        block(std::integral_constant<int, 8>{});
+        block(std::integral_constant<int, 9>{});
+        __syncthreads();
+        chunk = nxt;
+        cur ^= 1;
+        cn = c2;
+        c2 = c3;
+        if (!livec) break;
+    }
+
+    // ---- epilogue: as k_wgrad16_f16x3 (the waves take turns adding their tiles in LDS, one coalesced atomic per element)
+    float* tile = reinterpret_cast<float*>(lds);
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int t = 0; t < 25; ++t) {
+                const int tap = a.tap_of[t];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {         // D row = oc = 4 kg + q, col = ic = lane & 15
+                    float* d = tile + ((4 * kg + q) * 16 + l15) * 25 + tap;
+                    *d = turn == 0 ? acc[t][q] : *d + acc[t][q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const float inv = a.alpha * (1.f / sX) * (1.f / sY);
+    float* dwp = a.dw + (int64_t)plane * 16 * 16 * 25;
+    for (int i = tid; i < 16 * 16 * 25; i += 256) atomicAdd(dwp + i, tile[i] * inv);
+    if (a.db) {
+#pragma unroll
+        for (int j = 0; j < G_NA4; ++j) {
+            float s_ = dbs[j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o, 64);
+            const int oc = (tid + 256 * j) >> 6;
+            if (lane == 0) atomicAdd(a.db + (int64_t)plane * 16 + oc, s_ * a.alpha);
+        }
+    }
+}
+
 }  // namespace
 }  // namespace lldwt
 using namespace lldwt;
@@ -871,24 +1127,30 @@ int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, floa
     a.chunks_y = (int)cdiv(h, G_CR);
     for (int t = 0; t < 25; ++t) a.tap_of[t] = tap_of[t];
     const int64_t nchunk = batch * a.chunks_x * a.chunks_y;
+    // LLDWT_WGRAD16K=v1 keeps the first kernel (two workgroups per CU, a chunk's loads issued and consumed between the same barriers)
+    static const bool v1 = [] { const char* e = getenv("LLDWT_WGRAD16K"); return e && !strcmp(e, "v1"); }();
     static bool attr = false;
     static int per_cu = 2;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_wgrad16_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_TOTAL) != hipSuccess) {
-            set_error("wgrad16_f16x3: cannot reserve %d bytes of LDS", G_LDS_TOTAL);
+        if (hipFuncSetAttribute((const void*)k_wgrad16_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_TOTAL) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad16_f16x3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, G2_TOTAL) != hipSuccess) {
+            set_error("wgrad16_f16x3: cannot reserve %d bytes of LDS", G2_TOTAL);
             return LLDWT_EHIP;
         }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_wgrad16_f16x3, 256, G_LDS_TOTAL) != hipSuccess || per_cu < 1)
             per_cu = 2;
         attr = true;
     }
+    LLDWT_REQUIRE((int64_t)16 * h * w_ < ((int64_t)1 << 31) && h < (1 << 23) && w_ < (1 << 23), "wgrad16_f16x3: image too large for 32-bit offsets");
     // one resident round over all planes (equal-time workgroups), at least 2 chunks per workgroup
-    int64_t slices = (int64_t)lldwt_num_cus() * per_cu / planes;
+    int64_t slices = (int64_t)lldwt_num_cus() * (v1 ? per_cu : 1) / planes;
     if (slices > nchunk / 2) slices = nchunk / 2;
+    if (slices >= 16) slices &= ~(int64_t)7;            // a multiple of 8: the XCD-aware chunk order of the kernel
     if (slices < 1) slices = 1;
     a.slices = (int)slices;
     dim3 grid((unsigned)slices, 1, (unsigned)planes);
-    hipLaunchKernelGGL(k_wgrad16_f16x3, grid, dim3(256), G_LDS_TOTAL, st, a);
+    if (v1) hipLaunchKernelGGL(k_wgrad16_f16x3, grid, dim3(256), G_LDS_TOTAL, st, a);
+    else hipLaunchKernelGGL(k_wgrad16_f16x3_v2, grid, dim3(256), G2_TOTAL, st, a);
     return check_launch("wgrad16_f16x3");
 }
 }  // namespace lldwt
