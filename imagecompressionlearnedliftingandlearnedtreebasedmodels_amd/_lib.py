@@ -65,6 +65,7 @@ SIGNATURES = {
     "lldwt_get_lift_mode": (_i, []),
     "lldwt_pack_pblock": (_i, [_p] * 9 + [_i, _i, _i, _p]),
     "lldwt_pack_pblock_train": (_i, [_p] * 9 + [_i, _i, _i, _p]),
+    "lldwt_pack_pblock_seq": (_i, [_p] * 9 + [_i, _i, _i, _p]),
     "lldwt_lift_step_ws_bytes": (_i64, [_i64, _i64, _i64, _i]),
     "lldwt_lift_step": (_i, [View, View, View, _i64, _i64, _i64, _i64, _p, _p, _i, _i, _i, _f, _f, _i, _p, _i64, _p]),
     "lldwt_lifting_ws_bytes": (_i64, [_i64, _i64, _i64, _i]),

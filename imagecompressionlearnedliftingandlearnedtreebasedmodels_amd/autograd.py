@@ -292,8 +292,8 @@ class SqErrSumFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        s = 2.0 * float(g)
-        return None, ops.axpby(b.contiguous(), a.contiguous(), s, -s)
+        # 2 g (b - a) with g left on the device: float(g) stalled the host here until the whole forward had drained
+        return None, ops.axpby(b.contiguous(), a.contiguous(), 2.0, -2.0).mul_(g.to(torch.float32))
 
 
 # ------------------------------------------------------------------------------------------------ lifting transform
@@ -319,7 +319,7 @@ def _pack_forward(W, nblocks):
         # re-packed every step.  The fused f16x3 training forward (default for 16 channels, 5x5, tanh) reads the split-fp16
         # section; with LLDWT_TRAIN_LIFT=f32 / LLDWT_LIFT_MODE=f32 only the fp32 kernels run and that section is skipped
         pu = [ops.pack_pblock(*[W[k][b, u] for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")],
-                              train=not ops.train_lift_f16()) for u in range(2)]
+                              train=not ops.train_lift_f16(), compose=False) for u in range(2)]
         blocks.append(torch.stack(pu, 1))
     out = torch.stack(blocks, 1).contiguous()
     _PACK_MEMO["key"], _PACK_MEMO["val"] = key, out

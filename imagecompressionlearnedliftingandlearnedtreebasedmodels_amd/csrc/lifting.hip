@@ -1524,7 +1524,7 @@ extern "C" int lldwt_get_lift_mode(void) { return g_lift_mode; }
 
 static int pack_pblock_impl(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                             const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
-                            bool with_f16, void* stream);
+                            bool with_f16, void* stream, bool compose = true);
 
 extern "C" int lldwt_pack_pblock(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                  const float* b3, const float* w4, const float* b4, float* packed, int planes, int C,
@@ -1538,9 +1538,17 @@ extern "C" int lldwt_pack_pblock_train(const float* w1, const float* b1, const f
     return pack_pblock_impl(w1, b1, w2, b2, w3, b3, w4, b4, packed, planes, C, K, false, stream);
 }
 
+// the whole pack for the fused kernel's SEQUENTIAL path (training forward): everything lldwt_pack_pblock writes except the composed
+// 9x9 kernels of the eval path, which are nine tenths of the pack's time and which no training kernel reads
+extern "C" int lldwt_pack_pblock_seq(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                     const float* b3, const float* w4, const float* b4, float* packed, int planes, int C,
+                                     int K, void* stream) {
+    return pack_pblock_impl(w1, b1, w2, b2, w3, b3, w4, b4, packed, planes, C, K, true, stream, false);
+}
+
 static int pack_pblock_impl(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                             const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
-                            bool with_f16, void* stream) {
+                            bool with_f16, void* stream, bool compose) {
     LLDWT_REQUIRE(planes > 0 && C > 0 && (K == 3 || K == 5), "pack_pblock: bad planes/C/K (%d,%d,%d)", planes, C, K);
     LLDWT_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && w4 && b4 && packed, "pack_pblock: null pointer");
     const PackOff o = pack_off(C, K);
@@ -1548,7 +1556,7 @@ static int pack_pblock_impl(const float* w1, const float* b1, const float* w2, c
     hipLaunchKernelGGL(k_pack_pblock, grid, dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3, w4, b4, packed, C,
                        K);
     if (with_f16 && lift_f16_floats(C, K) > 0) {
-        int r = lift_f16_pack(w1, w2, w3, w4, b1, b3, b4, packed, o.total, o.f16, planes, (hipStream_t)stream);
+        int r = lift_f16_pack(w1, w2, w3, w4, b1, b3, b4, packed, o.total, o.f16, planes, compose ? 1 : 0, (hipStream_t)stream);
         if (r) return r;
     }
     return check_launch("pack_pblock");

@@ -31,7 +31,7 @@ static inline __host__ __device__ int lift_f16_floats(int C, int K) { return (C 
 
 // pack the f16 section of one P/U block (called from lldwt_pack_pblock after the fp32 section is written)
 int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, const float* b1, const float* b3,
-                  const float* b4, float* packed, int64_t plane_stride, int f16_off, int planes, hipStream_t st);
+                  const float* b4, float* packed, int64_t plane_stride, int f16_off, int planes, int compose, hipStream_t st);
 
 // one fused lifting step (eval): dst_out = dst_in + sign * (skip + rw * P(skip)); returns LLDWT_OK or an error
 struct LiftF16Views {

@@ -161,7 +161,9 @@ __device__ __forceinline__ int srctap(int t, int orient) { return orient == 0 ? 
 constexpr int PACK_NT = 1024, PACK_NW = PACK_NT / 64;
 __global__ __launch_bounds__(PACK_NT) void k_lift_f16_pack(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
                                 const float* __restrict__ w4, const float* __restrict__ b1, const float* __restrict__ b3,
-                                const float* __restrict__ b4, float* __restrict__ packed, int64_t plane_stride, int f16_off) {
+                                const float* __restrict__ b4, float* __restrict__ packed, int64_t plane_stride, int f16_off, int compose) {
+    // compose == 0: the composed 9x9 kernels (read by the eval path only) are left zero -- the packs of the training forward and of
+    // the backward-data chain are rebuilt at every weight update, and the composition is nine tenths of this kernel's time
     const int orient = blockIdx.x, plane = blockIdx.y, tid = threadIdx.x;
     b1 += (int64_t)plane * LF_C;
     b3 += (int64_t)plane * LF_C;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(PACK_NT) void k_lift_f16_pack(const float* __restri
         const int ic = is_r ? 0 : i / 81, s = is_r ? i - LF_C * 81 : i % 81;
         const int u = s / 9, vv = s % 9;
         double acc = 0.0;
-        for (int oc = 0; oc < LF_C; ++oc)
+        for (int oc = 0; oc < (compose ? LF_C : 0); ++oc)
             for (int py = 0; py < LF_K; ++py) {
                 const int qy = u - py;
                 if (qy < 0 || qy >= LF_K) continue;
@@ -1485,14 +1487,15 @@ int lift_f16_pack_bwd(const float* w1, const float* w2, const float* w3, const f
     float* o4 = o3 + (int64_t)planes * LF_C * LF_C * LF_KK;
     float* z = o4 + (int64_t)planes * LF_C * LF_KK;     // 64 zeros per plane: b1, b3 (16 per plane) and b4 (1 per plane) all read zeros
     hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, (unsigned)planes), dim3(PACK_NT), 0, st, o1, o2, o3, o4, z, z, z, packed,
-                       plane_stride, f16_off);
+                       plane_stride, f16_off, 0);          // the backward chain runs the sequential path: no composed kernels
     return check_launch("lift_f16_pack_bwd");
 }
 int64_t lift_f16_bwd_scratch_floats(int planes) { return (int64_t)planes * BWD_SCRATCH; }
 
 int lift_f16_pack(const float* w1, const float* w2, const float* w3, const float* w4, const float* b1, const float* b3,
-                  const float* b4, float* packed, int64_t plane_stride, int f16_off, int planes, hipStream_t st) {
-    hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, (unsigned)planes), dim3(PACK_NT), 0, st, w1, w2, w3, w4, b1, b3, b4, packed, plane_stride, f16_off);
+                  const float* b4, float* packed, int64_t plane_stride, int f16_off, int planes, int compose, hipStream_t st) {
+    hipLaunchKernelGGL(k_lift_f16_pack, dim3(2, (unsigned)planes), dim3(PACK_NT), 0, st, w1, w2, w3, w4, b1, b3, b4, packed, plane_stride, f16_off,
+                       compose);
     return check_launch("lift_f16_pack");
 }
 

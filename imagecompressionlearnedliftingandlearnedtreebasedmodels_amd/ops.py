@@ -121,13 +121,14 @@ def pblock_packed_floats(Cc, K):
     return int(_lib.load().lldwt_pblock_packed_floats(Cc, K))
 
 
-def pack_pblock(w1, b1, w2, b2, w3, b3, w4, b4, train=False):
+def pack_pblock(w1, b1, w2, b2, w3, b3, w4, b4, train=False, compose=True):
     """Stacked P_block_v2 parameters (planes, ...) in PyTorch layout -> packed (planes, total) buffer.  train=True: for the
-    training kernels only (the split-fp16 section of the buffer, which only the fused eval kernel reads, is not written)."""
+    fp32 training kernels only (the split-fp16 section of the buffer is not written).  compose=False: the split-fp16 section
+    without the composed 9x9 kernels of the eval path (lldwt_pack_pblock_seq: the fused training forward's pack)."""
     lib = _lib.load()
     planes, Cc, _, K, _ = w1.shape
     out = torch.empty(planes, pblock_packed_floats(Cc, K), device=w1.device, dtype=torch.float32)
-    fn = lib.lldwt_pack_pblock_train if train else lib.lldwt_pack_pblock
+    fn = lib.lldwt_pack_pblock_train if train else (lib.lldwt_pack_pblock if compose else lib.lldwt_pack_pblock_seq)
     check(fn(_chk(w1), _chk(b1), _chk(w2), _chk(b2), _chk(w3), _chk(b3), _chk(w4), _chk(b4), _chk(out), planes, Cc, K,
              _stream()), "pack_pblock")
     return out

@@ -110,6 +110,12 @@ int lldwt_pack_pblock(const float* w1, const float* b1, const float* w2, const f
 int lldwt_pack_pblock_train(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                             const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
                             void* stream);
+/* As lldwt_pack_pblock without the composed 9x9 kernels of the eval path (left zero): the pack of the fused kernel's sequential
+ * path -- the training forward (lldwt_lifting_forward_train / _inverse_train), rebuilt at every weight update.  NOT for the eval
+ * entry points.                                                                                                              */
+int lldwt_pack_pblock_seq(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                          const float* b3, const float* w4, const float* b4, float* packed, int planes, int C, int K,
+                          void* stream);
 
 /* One lifting step (wavelet_forward_v2.py:60-62 and the three like it; inverse wavelet_inverse_v2.py:76-90):
  *     skip = conv3x1(src, taps)            zero padded, along rows if vertical else along columns

@@ -20,7 +20,7 @@ for _ in range(2):
     agent.train_step(x, allreduce=False)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     agent.train_step(x, allreduce=False)
     torch.cuda.synchronize()
 ev = prof.events()
@@ -32,7 +32,8 @@ for e in ev:
         continue
     st = [s for s in (e.stack or []) if "imagecompression" in s or "bench" in s or "autograd" in s]
     site = " <- ".join(s.split("/")[-1] for s in st[:3])
-    k = (e.name, site)
+    shp = str([tuple(x) for x in (e.input_shapes or []) if x][:2]) if e.name in ("aten::copy_", "aten::cat", "aten::fill_") else ""
+    k = (e.name, site + shp)
     agg[k][0] += 1
     agg[k][1] += e.self_device_time_total
 tot = sum(v[1] for v in agg.values())
