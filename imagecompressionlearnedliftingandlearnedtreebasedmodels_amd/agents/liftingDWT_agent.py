@@ -13,11 +13,16 @@ from .. import ops
 from ..graphs.losses.rate_dist import TrainDLoss, TrainRDLoss
 from .. import autograd as ag
 from .. import parallel
+from .. import param_arena
 from ..graphs.models.LiftingBasedDWT_net import (LiftingBasedDWTNetWrapper, byte_extractor, compress_planes,
                                                   forward_planes, forward_planes_train)
 from ..dataloaders.image_dl import ImageDataLoader, SyntheticLoader  # noqa: F401  (SyntheticLoader: re-export)
 from ..loggers import RDLogger
 from .base import BaseAgent
+
+
+# LLDWT_PARAM_ARENA=0: parameters and gradients keep their own tensors (torch.stack per step, one gradient add per parameter)
+_USE_ARENA = os.environ.get("LLDWT_PARAM_ARENA", "1") != "0"
 
 
 class LiftingBasedDWTAgent(BaseAgent):
@@ -83,6 +88,16 @@ class LiftingBasedDWTAgent(BaseAgent):
         if self._bucket is None:
             self._bucket = parallel.FlatGradBucket(self.model.parameters())     # one flat fp32 bucket for RCCL
         self._bucket.zero_()
+        param_arena.set_active(self._bucket if _USE_ARENA else None)            # stacks of per-plane parameters as arena slices
+        try:
+            return self._train_step(x, noise_fn, allreduce)
+        finally:
+            param_arena.set_active(None)
+            groups = param_arena.take_pending()
+            if groups and _USE_ARENA:                                           # first step (or after .to()): learn the layout
+                self._bucket.relayout(list(getattr(self._bucket, "_kept_groups", [])) + groups)
+
+    def _train_step(self, x, noise_fn, allreduce):
         xs = (x - 0.5).contiguous()
         if self.clrch == 1:
             y = ops.rgb_to_ycc(x.contiguous())                                 # :86-87
@@ -96,6 +111,7 @@ class LiftingBasedDWTAgent(BaseAgent):
         if allreduce:
             self._bucket.all_reduce_mean()                                      # data-parallel: mean gradient over ranks
         self.optimizer.step()                                                   # :98
+        self._bucket.bump_version()
         self.current_iteration += 1
         return loss, mse, r1, r2
 

@@ -20,6 +20,7 @@ from ... import autograd as ag
 from ... import ops
 from ...entropy_models import EntropyBottleneck, GaussianConditional
 from ...packed_cache import PackedOwnerMixin, cached
+from ... import param_arena
 from ..layers.lifting_dwt_nets import (DWTPytorchWaveletsLayer, LiftingBasedNeuralWaveletv4, _stack,
                                        decode_planes, encode_planes, lifting_coeff)
 from ..layers.masked_conv2d import MaskedConv2d
@@ -545,7 +546,10 @@ class DWTConditioned2EntropyLayerZTBlock(_EntropyLayerBase):
 # kernels; torch only keeps the tape and un-stacks the per-plane parameter gradients).  Built for the headline
 # configuration: LiftingBasedNeuralWaveletv4 + SubbandAutoEncoder + conditioned2ZTsepSubbands.
 def _tstack(mods, get):
-    return torch.stack([get(m) for m in mods], 0)
+    ts = [get(m) for m in mods]
+    if all(isinstance(t, torch.nn.Parameter) for t in ts):
+        return param_arena.stack_leaf(ts)         # a slice of the parameter arena when the group is laid out (param_arena.py)
+    return torch.stack(ts, 0)
 
 
 def _tconv(mods, x, act=ops.ACT_NONE, upsample2=False):
@@ -612,13 +616,13 @@ def _lift_params(nets):
     nb = len(nets[0].P_blocks)
     # one stack (one copy kernel) per stacked tensor, viewed to its nested shape -- not a stack of stacks of stacks
     P = len(nets)
-    taps = torch.stack([n.preProcessingList[j].weight.reshape(3) for j in range(4) for n in nets], 0).view(4, P, 3)
+    taps = param_arena.stack_leaf([n.preProcessingList[j].weight for j in range(4) for n in nets]).view(4, P, 3)
     Wt = []
     for cn in ("conv1", "conv2", "conv3", "conv4"):
         for attr in ("weight", "bias"):
             flat = [getattr(getattr(getattr(n, kind)[b], cn), attr) for b in range(nb) for kind in ("P_blocks", "U_blocks")
                     for n in nets]
-            Wt.append(torch.stack(flat, 0).view(nb, 2, P, *flat[0].shape))
+            Wt.append(param_arena.stack_leaf(flat).view(nb, 2, P, *flat[0].shape))
     n0 = nets[0]
     meta = dict(levels=n0.waveletLevel, C=n0.depth_scale, K=n0.conv_filter_size, rw=n0.res_connection_weight,
                 linear=n0.linearityflag != 1, different=n0.blockprop != "same")

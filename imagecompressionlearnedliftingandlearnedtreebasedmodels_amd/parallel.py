@@ -133,10 +133,56 @@ class FlatGradBucket:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_p = None                   # parameter arena (relayout): every p.data a view into it
+        self.group_views = {}                # param_arena: group key -> (parameter slice, gradient slice, numel per member)
+        self.rejected = set()                # group keys that cannot be laid out (a member already belongs to another group)
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+
+    def relayout(self, groups):
+        """Lay the given groups of parameters (lists; the members of a group have one shape) out ADJACENT and in order, in the
+        gradient bucket and in a parameter arena (param_arena.py): a stack of a group is then a slice of the arena and its
+        gradient a slice of the bucket.  Gradients and parameter values are carried over; parameters outside any group follow
+        the groups in their old order.  A parameter that appears in several groups stays with the first."""
+        mine = {id(p) for p in self.params}
+        seen, order, kept = set(), [], []
+        for g in groups:
+            g = list(g)
+            if not g or any(id(p) not in mine or id(p) in seen for p in g) or any(p.shape != g[0].shape for p in g):
+                self.rejected.add(tuple(id(p) for p in g))          # never laid out: param_arena stops recording it
+                continue
+            seen.update(id(p) for p in g)
+            order.extend(g)
+            kept.append(g)
+        order.extend(p for p in self.params if id(p) not in seen)
+        n = sum(p.numel() for p in order)
+        flat = torch.zeros(n, dtype=torch.float32, device=self.flat.device)
+        flat_p = torch.empty(n, dtype=torch.float32, device=self.flat.device)
+        off, where = 0, {}
+        with torch.no_grad():
+            for p in order:
+                k = p.numel()
+                flat[off:off + k].copy_(p.grad.reshape(-1))
+                flat_p[off:off + k].copy_(p.data.reshape(-1))
+                p.grad = flat[off:off + k].view_as(p)
+                p.data = flat_p[off:off + k].view_as(p)
+                where[id(p)] = off
+                off += k
+        self.params, self.flat, self.flat_p = order, flat, flat_p
+        self.group_views = {}
+        for g in kept:
+            o, k = where[id(g[0])], g[0].numel()
+            shape = (len(g),) + tuple(g[0].shape)
+            self.group_views[tuple(id(p) for p in g)] = (flat_p[o:o + k * len(g)].view(shape), flat[o:o + k * len(g)].view(shape), k)
+        self._kept_groups = kept
+
+    def bump_version(self):
+        """After the optimizer wrote the parameters through their own views: the arena's version counter (shared by every stack
+        handed out) moves too, so that caches keyed on (data_ptr, _version) of a stacked tensor see the update."""
+        if self.flat_p is not None:
+            torch.autograd.graph.increment_version(self.flat_p)
 
     def zero_(self):
         self.flat.zero_()

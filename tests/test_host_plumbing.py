@@ -481,3 +481,33 @@ def test_bench_refuses_mislabelled_world_sizes():
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+
+
+def test_flat_bucket_relayout_groups_parameters_and_gradients():
+    """FlatGradBucket.relayout (param_arena.py): the members of a group end up adjacent and in order in the gradient bucket and in
+    the parameter arena, values and gradients are carried over, a group sharing a member with an earlier one is rejected, and a
+    stack of a group is a slice of the arena whose gradient slice is what the per-parameter .grad views show."""
+    import torch
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import parallel
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(2, 3)) for _ in range(6)] + [torch.nn.Parameter(torch.randn(5))]
+    b = parallel.FlatGradBucket(ps)
+    for i, p in enumerate(ps):
+        p.grad.fill_(float(i + 1))
+    vals = [p.detach().clone() for p in ps]
+    b.relayout([[ps[4], ps[1], ps[3]], [ps[1], ps[0]], [ps[5], ps[2]], [ps[6], ps[0]]])       # 2nd shares ps[1]; 4th mixes shapes
+    assert b.flat.numel() == b.flat_p.numel() == sum(p.numel() for p in ps)
+    assert [id(p) for p in b.params[:5]] == [id(ps[4]), id(ps[1]), id(ps[3]), id(ps[5]), id(ps[2])]
+    assert len(b.group_views) == 2 and len(b.rejected) == 2
+    for i, p in enumerate(ps):
+        assert torch.equal(p.detach(), vals[i]) and torch.equal(p.grad, torch.full_like(p, float(i + 1)))
+    pv, gv, n = b.group_views[(id(ps[4]), id(ps[1]), id(ps[3]))]
+    assert pv.shape == (3, 2, 3) and n == 6 and torch.equal(pv, torch.stack([vals[4], vals[1], vals[3]]))
+    gv += 1.0                                                           # what a stacked leaf's backward does
+    assert float(ps[1].grad[0, 0]) == 3.0 and float(ps[0].grad[0, 0]) == 1.0
+    with torch.no_grad():
+        ps[3].mul_(2.0)                                                 # what the optimizer does
+    assert torch.equal(pv[2], vals[3] * 2.0)
+    v0 = pv._version
+    b.bump_version()
+    assert pv._version > v0 and pv.detach()._version == pv._version   # caches keyed on a stack's version see the update
