@@ -435,7 +435,7 @@ struct WThinArgs {
 };
 
 template <int K>
-__global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
+__device__ __forceinline__ void wgrad_thin_body(const WThinArgs& a) {
     constexpr int KK = K * K, R = K / 2, NJ = (KK + 15) / 16;
     constexpr int IH = WG_TH + 2 * R, IW = WG_TW + 2 * R, IHW = IH * IW;
     constexpr int NAV = 16 * WG_PX / 4 / 256, NB = (IHW + 255) / 256;
@@ -570,6 +570,15 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) {
         if (tid == 0) atomicAdd(a.db + plane, a.alpha * ((lb[0] + lb[1]) + (lb[2] + lb[3])));
     }
 }
+
+template <int K>
+__global__ __launch_bounds__(256) void k_wgrad_thin(WThinArgs a) { wgrad_thin_body<K>(a); }
+
+// the two thin weight gradients of one lifting step (conv4: X = t3, dY = g; conv1: X = skip, dY = dr) in ONE launch: blockIdx.y picks
+// the problem.  Below level 1 these launches are latency-bound (a few chunks per workgroup), and a step has two of them.
+struct WThinPair { WThinArgs p[2]; };
+template <int K>
+__global__ __launch_bounds__(256) void k_wgrad_thin2(WThinPair a2) { wgrad_thin_body<K>(a2.p[blockIdx.y]); }
 
 // ---- 1x1 convs without channel placement (cgp stack, auto-encoder MLPs): dW[m][n] = sum_px dY[m][px] X[n][px] is a plain
 // "NT" GEMM with K = pixels and no spatial structure, so the image is walked as flat 32-pixel segments (128-byte rows,
@@ -789,6 +798,38 @@ extern "C" int lldwt_conv2d_wgrad(const float* x, const float* dy, float* dw, fl
                                   int64_t planes, int64_t batch, int64_t h, int64_t w_, void* stream) {
     return lldwt_conv2d_wgrad_ex(x, dy, dw, dbias, d, planes, batch, h, w_, 1.0f, 0, stream);
 }
+
+// conv4's and conv1's weight gradients of one lifting step (C = 16, K = 3 or 5, all taps) in one launch of k_wgrad_thin2:
+//   dw4 (planes,1,16,K,K) += alpha sum t3 (x) g,  db4 += alpha sum g;   dw1 (planes,16,1,K,K) += alpha sum dr (x) skip,  db1 += alpha sum dr
+namespace lldwt {
+int wgrad_thin_pair(const float* t3, const float* g, float* dw4, float* db4, const float* skip, const float* dr, float* dw1,
+                    float* db1, int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw, int K, hipStream_t st) {
+    LLDWT_REQUIRE(t3 && g && dw4 && skip && dr && dw1 && (K == 3 || K == 5), "wgrad_thin_pair: bad arguments");
+    LLDWT_REQUIRE(planes > 0 && planes <= 65535 && batch > 0 && h > 0 && w_ > 0, "wgrad_thin_pair: bad dims");
+    const int KK = K * K;
+    WThinPair a2;
+    for (int i = 0; i < 2; ++i) {
+        const bool c4 = i == 0;
+        WThinArgs& w = a2.p[i];
+        w.a16 = c4 ? t3 : dr; w.b1 = c4 ? g : skip; w.dw = c4 ? dw4 : dw1; w.db = c4 ? db4 : db1;
+        w.batch = (int)batch; w.h = (int)h; w.w = (int)w_; w.alpha = alpha; w.flip = c4 ? 1 : 0;
+        w.bias_mode = w.db ? (c4 ? 2 : 1) : 0;
+        for (int t = 0; t < 25; ++t) w.tap_of[t] = t < KK ? (int8_t)(swap_hw ? (t % K) * K + t / K : t) : 0;
+    }
+    const int64_t chunks = batch * cdiv(h, WG_TH) * cdiv(w_, WG_TW);
+    int per_cu = 2;
+    const void* kern = K == 5 ? (const void*)k_wgrad_thin2<5> : (const void*)k_wgrad_thin2<3>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (per_cu > 4) per_cu = 4;
+    int64_t sl = (int64_t)lldwt_num_cus() * per_cu / (planes * 2);       // one resident round over both problems and all planes
+    if (sl > chunks / 4) sl = chunks / 4;
+    if (sl < 1) sl = 1;
+    dim3 grid((unsigned)sl, 2, (unsigned)planes);
+    if (K == 5) hipLaunchKernelGGL(k_wgrad_thin2<5>, grid, dim3(256), 0, st, a2);
+    else hipLaunchKernelGGL(k_wgrad_thin2<3>, grid, dim3(256), 0, st, a2);
+    return check_launch("wgrad_thin_pair");
+}
+}  // namespace lldwt
 
 extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, float* dbias, const lldwt_conv_desc* d,
                                      int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw,

@@ -1634,7 +1634,11 @@ static int launch_step_bwd(lldwt_view g_dst_out, lldwt_view g_dst_in, float* g, 
 namespace lldwt {
 int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, float* slots_ws, int64_t slots_stride, bool slots_ready,
                   int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, const int8_t* tap_of, hipStream_t st);
+int wgrad_thin_pair(const float* t3, const float* g, float* dw4, float* db4, const float* skip, const float* dr, float* dw1,
+                    float* db1, int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw, int K, hipStream_t st);
 }
+// LLDWT_WGRAD_THIN=2 keeps the two separate launches of the thin (1 <-> 16) weight gradients of a step
+static const int g_thin_pair = [] { const char* e = getenv("LLDWT_WGRAD_THIN"); return (e && !strcmp(e, "2")) ? 0 : 1; }();
 // LLDWT_WGRAD16=f32 keeps the fp32-MFMA weight gradient of the 16 -> 16 lifting convs (k_wgrad16<5>); default: split-fp16
 static const int g_wgrad16_f16 = [] { const char* e = getenv("LLDWT_WGRAD16"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
 // smallest batch * h * w per plane at which the split-fp16 kernel takes the 16 -> 16 weight gradients (LLDWT_WGRAD16_MIN overrides)
@@ -1757,8 +1761,12 @@ static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_v
         d.tap_mask = (1u << (K * K)) - 1u; d.oc_block = cout; d.oc_stride = 0; d.oc_off = 0; d.ytot = cout;
         d.ic_block = 0; d.ic_stride = 0; d.ic_off = 0; d.xtot = 0; d.epi = 0;
     };
-    desc(C, 1);
-    if ((r = lldwt_conv2d_wgrad_ex(t3, g, dw4, db4, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    if (g_thin_pair) {          // conv4's and conv1's gradients (both read what the backward-data chain left) in one launch
+        if ((r = wgrad_thin_pair(t3, g, dw4, db4, skip, dr, dw1, db1, planes, batch, h, w, alpha, swap, K, st))) return r;
+    } else {
+        desc(C, 1);
+        if ((r = lldwt_conv2d_wgrad_ex(t3, g, dw4, db4, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    }
     desc(C, C);
     if (wg16) {
         // conv3 / conv2: their inputs t2 / t1 are tanh outputs (|x| <= 1): split-fp16 on the fp16 matrix cores (conv_wgrad_f16x3.hip).
@@ -1775,8 +1783,10 @@ static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_v
         if ((r = lldwt_conv2d_wgrad_ex(t2, dt3, dw3, db3, &d, planes, batch, h, w, alpha, swap, stream))) return r;
         if ((r = lldwt_conv2d_wgrad_ex(t1, dpre2, dw2, db2, &d, planes, batch, h, w, alpha, swap, stream))) return r;
     }
-    desc(1, C);
-    if ((r = lldwt_conv2d_wgrad_ex(skip, dr, dw1, db1, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    if (!g_thin_pair) {
+        desc(1, C);
+        if ((r = lldwt_conv2d_wgrad_ex(skip, dr, dw1, db1, &d, planes, batch, h, w, alpha, swap, stream))) return r;
+    }
     return lldwt_lift_bwd_fin(g, dsk, srcv, g_src, Z, batch, h, w, taps, dtaps, vertical, sign, res_weight, stream);
 }
 
