@@ -1595,7 +1595,10 @@ extern "C" int lldwt_lift_bwd_fin(const float* g, const float* dsk, const float*
                                   float sign, float res_weight, void* stream) {
     LLDWT_REQUIRE(g && dsk && srcv && g_src.p && taps && dtaps && Z > 0 && Z <= 65535 && batch > 0 && h > 0 && w > 0,
                   "lift_bwd_fin: bad arguments");
-    dim3 grid((unsigned)cdiv(w, 256), (unsigned)(h < 64 ? h : 64), (unsigned)Z);
+    // every workgroup ends with three float atomics onto its plane's tap gradients: with 64 row slices a level-0 launch sent 1 024
+    // atomics to each of nine addresses (they serialise in L2 and took longer than the 63 MB the kernel moves); 16 slices
+    static const int fin_rows = [] { const char* e = getenv("LLDWT_FIN_ROWS"); const int v = e ? atoi(e) : 16; return v > 0 ? v : 16; }();
+    dim3 grid((unsigned)cdiv(w, 256), (unsigned)(h < fin_rows ? h : fin_rows), (unsigned)Z);
     hipLaunchKernelGGL(k_lift_bwd_fin, grid, dim3(256), 0, (hipStream_t)stream, g, dsk, srcv, g_src, (int)batch, (int)h,
                        (int)w, taps, dtaps, vertical, sign, res_weight);
     return check_launch("lift_bwd_fin");
