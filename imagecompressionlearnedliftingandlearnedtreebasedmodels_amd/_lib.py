@@ -138,6 +138,9 @@ SIGNATURES = {
     "lldwt_cgp_bwd_packed_floats": (_i64, [_i, _i, _i, _i, _i]),
     "lldwt_cgp_pack_bwd": (_i, [_p] * 5 + [_i64, _i, _i, _i, _i, _i, _p]),
     "lldwt_cgp_bwd": (_i, [_p] * 9 + [_i64, _i64, _i64, _i, _i, _i, _i, _i, _p]),
+    "lldwt_cgp_rate_train_ctx": (_i, [_p] * 10 + [_i64, _i64, _i64, _i64, _i, _i, C.c_uint32, _i, _i, _i, _i, _p]),
+    "lldwt_cgp_bwd_split": (_i, [_p] * 10 + [_i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _p]),
+    "lldwt_wgrad1x1_split": (_i, [_p] * 5 + [_i64, _i64, _i64, _i, _i, _i, _i, _p]),
     "lldwt_gauss_rate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i64, _p]),
     "lldwt_axpby": (_i, [_p, _p, _p, _i64, _f, _f, _p]),
     "lldwt_ycc_to_rgb_bwd": (_i, [_p, _p, _i64, _i64, _i64, _p]),

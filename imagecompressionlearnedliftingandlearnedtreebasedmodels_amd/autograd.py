@@ -145,6 +145,59 @@ class CgpRateFn(torch.autograd.Function):
         return (dcat, dx, None, None, *grads)
 
 
+class CgpRateCtxFn(torch.autograd.Function):
+    """CgpRateFn without the concatenated input: plc (P,B,G*cplc,h,w) = the tree-context conv's output, xq (P,B,G,h,w) = the
+    quantised subband whose live causal taps (tap_mask of the K x K masked context conv, folded into layer 0 on the host) the
+    kernels gather themselves.  Forward lldwt_cgp_rate_train_ctx; backward lldwt_cgp_bwd_split (input gradient as dplc + dtaps),
+    layer 0's weight gradient from the two sources (lldwt_wgrad1x1_split), d(xq) = the taps' transpose (shifted adds).  The
+    [plc_g | taps_g] tensor of CgpRateFn was 1.75 GB at the level-0 shape of configs[2]: a torch.cat in the forward, and the same
+    copy again for the gradient of plc on the way back."""
+
+    @staticmethod
+    def _taps(K, tap_mask):
+        return [t for t in range(K * K) if (tap_mask >> t) & 1]
+
+    @staticmethod
+    def _gather(xq, K, live):
+        """patches[:, :, g*ntaps + j] = xq[:, :, g] shifted by live tap j, zero outside the image (as _fold_csc_train)."""
+        import torch.nn.functional as F
+        P, B, G, h, w = xq.shape
+        R = K // 2
+        xp = F.pad(xq, (R, R, R, R))
+        taps = [xp[:, :, :, (t // K):(t // K) + h, (t % K):(t % K) + w] for t in live]
+        return torch.stack(taps, dim=3).reshape(P, B, G * len(live), h, w).contiguous()
+
+    @staticmethod
+    def forward(ctx, plc, xq, x, noise, groups, K, tap_mask, *wb):
+        ws, bs = list(wb[0::2]), list(wb[1::2])
+        packed, dims = ops.cgp_pack(ws, bs, groups)
+        bits, params, h1, h2, h3 = ops.cgp_rate_train_ctx(plc, xq, x, packed, dims, noise, K, tap_mask)
+        ctx.save_for_backward(plc, xq, x, noise, params, h1, h2, h3, *ws)
+        ctx.dims, ctx.groups, ctx.K, ctx.tap_mask = dims, groups, K, tap_mask
+        return bits
+
+    @staticmethod
+    def backward(ctx, gbits):
+        plc, xq, x, noise, params, h1, h2, h3, *ws = ctx.saved_tensors
+        dims, G, K = ctx.dims, ctx.groups, ctx.K
+        live = CgpRateCtxFn._taps(K, ctx.tap_mask)
+        nt, R = len(live), K // 2
+        dx, dparams = ops.gauss_rate_bwd(x, params, noise, gbits.contiguous())
+        dplc, dtaps, d1, d2, d3 = ops.cgp_bwd_split(dparams, h1, h2, h3, ops.cgp_pack_bwd(ws, G), dims, G, nt)
+        grads = list(ops.wgrad1x1_split(plc, CgpRateCtxFn._gather(xq, K, live), d1, G))
+        for xin, dy, w in ((h1, d2, ws[1]), (h2, d3, ws[2]), (h3, dparams, ws[3])):
+            dw, db = ops.conv2d_wgrad(xin, dy, tuple(w.shape), 1, groups=G)
+            grads += [dw, db]
+        # d(xq): tap j of pixel p read xq at p + (dy_j - R, dx_j - R) -> its gradient is added there (transpose of the gather)
+        P, B, _, h, w = xq.shape
+        dq = torch.zeros(P, B, G, h + 2 * R, w + 2 * R, device=xq.device, dtype=torch.float32)
+        dt = dtaps.view(P, B, G, nt, h, w)
+        for j, t in enumerate(live):
+            dq[:, :, :, (t // K):(t // K) + h, (t % K):(t % K) + w] += dt[:, :, :, j]
+        dxq = dq[:, :, :, R:R + h, R:R + w].contiguous()
+        return (dplc, dxq, dx, None, None, None, None, *grads)
+
+
 class FactorizedRateFn(torch.autograd.Function):
     """(bits, q) of the factorized model (lldwt_factorized_rate); eb: (P,C,59) packed raw parameters (built by torch.cat
     from the module parameters, so their gradients flow back through the tape)."""

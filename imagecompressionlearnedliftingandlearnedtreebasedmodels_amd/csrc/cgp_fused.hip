@@ -364,7 +364,10 @@ __device__ __forceinline__ void cgp_gate_load(float (&gate)[MT][4][CGP_NPT], con
 template <int MT, bool GATED>
 __device__ __forceinline__ void cgp_store_bwd(float* __restrict__ buf, const float (&gate)[MT][4][CGP_NPT], int M, int wave,
                                               int lane, const floatx4 (&acc)[MT][CGP_NPT], float* __restrict__ out,
-                                              int64_t hw, int64_t p0, bool to_lds) {
+                                              int64_t hw, int64_t p0, bool to_lds, float* __restrict__ out2 = nullptr,
+                                              int split = 1 << 30) {
+    // rows >= split go to a second tensor (out2 = its base minus split rows): the input gradient of the folded layer 0 leaves as
+    // [tree-context channels | gathered taps] without ever having been one tensor
     const int px = lane & 15, kk = lane >> 4;
     const int mpad = (M + 1 + 3) & ~3;       // the packed K of the next layer is M + 1 (its bias row: zero weights here)
 #pragma unroll
@@ -378,7 +381,7 @@ __device__ __forceinline__ void cgp_store_bwd(float* __restrict__ buf, const flo
                     float v = oc < M ? acc[j][n][r] : 0.f;
                     if (GATED) v *= gate[j][r][n] > 0.f ? 1.f : 0.01f;    // LeakyReLU' from the sign of the stored activation
                     if (to_lds) buf[oc * CGP_PS + n * 16 + px] = v;
-                    if (oc < M && p0 + n * 16 + px < hw) out[(int64_t)oc * hw + p0 + n * 16 + px] = v;
+                    if (oc < M && p0 + n * 16 + px < hw) (oc < split ? out : out2)[(int64_t)oc * hw + p0 + n * 16 + px] = v;
                 }
             }
         }
@@ -388,14 +391,14 @@ template <int MT, int MTN, bool GATED>
 __device__ __forceinline__ void cgp_bwd_layer(float* __restrict__ buf, const float* __restrict__ pk, const CgpDims& d, int l,
                                               int wave, int lane, float (&An)[CGP_U][MT], float (&AnNext)[CGP_U][MTN],
                                               const float* __restrict__ h, float* __restrict__ out, int64_t hw, int64_t p0,
-                                              bool last) {
+                                              bool last, float* __restrict__ out2 = nullptr, int split = 1 << 30) {
     floatx4 acc[MT][CGP_NPT];
     float gate[MT][4][CGP_NPT];
     if (GATED) cgp_gate_load<MT>(gate, h, d.c[l + 1], wave, lane, hw, p0);
     cgp_layer<MT>(buf, pk + d.woff[l], d.c[l] + 1, wave, lane, acc, An);
     if (!last) cgp_warm<MTN>(AnNext, pk + d.woff[l + 1], d.c[l + 1] + 1, wave, lane);
     __syncthreads();                       // every wave has read this layer's input
-    cgp_store_bwd<MT, GATED>(buf, gate, d.c[l + 1], wave, lane, acc, out, hw, p0, !last);
+    cgp_store_bwd<MT, GATED>(buf, gate, d.c[l + 1], wave, lane, acc, out, hw, p0, !last, out2, split);
     __syncthreads();
 }
 
@@ -403,7 +406,10 @@ __global__ __launch_bounds__(256, 2) void k_cgp_bwd(const float* __restrict__ dp
                                                  const float* __restrict__ h2, const float* __restrict__ h3,
                                                  const float* __restrict__ packed, float* __restrict__ d1,
                                                  float* __restrict__ d2, float* __restrict__ d3,
-                                                 float* __restrict__ dcat, CgpDims d, int groups, int batch, int64_t hw) {
+                                                 float* __restrict__ dcat, CgpDims d, int groups, int batch, int64_t hw,
+                                                 float* __restrict__ dtaps, int split) {
+    // dtaps != null: the input gradient goes to two tensors, rows < split of every group to dcat (Z, groups*split, hw), the rest to
+    // dtaps (Z, groups*(c0 - split), hw)
     extern __shared__ __attribute__((aligned(16))) float buf[];     // [roundup(max width,4)][CGP_PS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.y;
@@ -419,7 +425,9 @@ __global__ __launch_bounds__(256, 2) void k_cgp_bwd(const float* __restrict__ dp
     float* d3g = d3 + zg * (int64_t)d.c[1] * hw;
     float* d2g = d2 + zg * (int64_t)d.c[2] * hw;
     float* d1g = d1 + zg * (int64_t)d.c[3] * hw;
-    float* dcg = dcat + zg * (int64_t)d.c[4] * hw;
+    float* dcg = dcat + zg * (int64_t)(dtaps ? split : d.c[4]) * hw;
+    float* dtg = dtaps ? dtaps + zg * (int64_t)(d.c[4] - split) * hw - (int64_t)split * hw : nullptr;
+    const int spl = dtaps ? split : (1 << 30);
     const int64_t ntiles = (hw + CGP_PX - 1) / CGP_PX;
     const int64_t t0 = (int64_t)blockIdx.x * CGP_TILES_PER_WG;
     for (int64_t t = t0; t < t0 + CGP_TILES_PER_WG && t < ntiles; ++t) {
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_cgp_bwd(const float* __restrict__ dp
         cgp_bwd_layer<1, 1, true>(buf, pk, d, 0, wave, lane, A0, A1, h3g, d3g, hw, p0, false);
         cgp_bwd_layer<1, CGP_MAXT, true>(buf, pk, d, 1, wave, lane, A1, A2, h2g, d2g, hw, p0, false);
         cgp_bwd_layer<CGP_MAXT, CGP_MAXT, true>(buf, pk, d, 2, wave, lane, A2, A3, h1g, d1g, hw, p0, false);
-        cgp_bwd_layer<CGP_MAXT, CGP_MAXT, false>(buf, pk, d, 3, wave, lane, A3, A3, nullptr, dcg, hw, p0, true);
+        cgp_bwd_layer<CGP_MAXT, CGP_MAXT, false>(buf, pk, d, 3, wave, lane, A3, A3, nullptr, dcg, hw, p0, true, dtg, spl);
     }
 }
 
@@ -545,6 +553,31 @@ extern "C" int lldwt_cgp_rate_ctx(const float* plc, const float* xq, const float
                          cplc + n, c1, c2, c3, groups, cx, stream);
 }
 
+// lldwt_cgp_rate_train with the context as in lldwt_cgp_rate_ctx: rows < cplc of a group from plc (Z, groups*cplc, h, w), the other
+// rows gathered from the quantised subband xq -- no concatenated [plc_g | taps_g] tensor in HBM (1.75 GB at the level-0 shape)
+extern "C" int lldwt_cgp_rate_train_ctx(const float* plc, const float* xq, const float* x, const float* noise, const float* packed,
+                                        float* bits, float* params_out, float* h1, float* h2, float* h3, int64_t planes,
+                                        int64_t batch, int64_t h, int64_t w_, int cplc, int K, uint32_t tap_mask, int c1, int c2,
+                                        int c3, int groups, void* stream) {
+    LLDWT_REQUIRE(plc && xq && params_out && h1 && h2 && h3 && h > 0 && w_ > 0 && cplc > 0 && (K == 3 || K == 5),
+                  "cgp_rate_train_ctx: bad arguments");
+    LLDWT_REQUIRE(h * w_ < ((int64_t)1 << 31), "cgp_rate_train_ctx: image too large for 32-bit pixel offsets");
+    CgpCtx cx = cgp_no_ctx();
+    cx.xq = xq; cx.cplc = cplc; cx.w = (int)w_; cx.R = K / 2;
+    int n = 0;
+    for (int t = 0; t < K * K; ++t)
+        if ((tap_mask >> t) & 1u) {
+            LLDWT_REQUIRE(n < 16, "cgp_rate_train_ctx: more than 16 live taps");
+            cx.tdy[n] = (int8_t)(t / K);
+            cx.tdx[n] = (int8_t)(t % K);
+            ++n;
+        }
+    LLDWT_REQUIRE(n > 0, "cgp_rate_train_ctx: empty tap mask");
+    cx.npatch = n;
+    return cgp_rate_impl(plc, x, noise, packed, bits, params_out, h1, h2, h3, nullptr, planes, batch, h * w_, cplc + n, c1, c2,
+                         c3, groups, cx, stream);
+}
+
 extern "C" int lldwt_cgp_rate_train(const float* cat, const float* x, const float* noise, const float* packed, float* bits,
                                     float* params_out, float* h1, float* h2, float* h3, int64_t planes, int64_t batch,
                                     int64_t hw, int c0, int c1, int c2, int c3, int groups, void* stream) {
@@ -578,9 +611,29 @@ extern "C" int lldwt_cgp_pack_bwd(const float* w0, const float* w1, const float*
     return check_launch("cgp_pack_bwd");
 }
 
+static int cgp_bwd_impl(const float* dparams, const float* h1, const float* h2, const float* h3, const float* packed_bwd,
+                        float* d1, float* d2, float* d3, float* dcat, float* dtaps, int split, int64_t planes, int64_t batch,
+                        int64_t hw, int c0, int c1, int c2, int c3, int groups, void* stream);
+
 extern "C" int lldwt_cgp_bwd(const float* dparams, const float* h1, const float* h2, const float* h3, const float* packed_bwd,
                              float* d1, float* d2, float* d3, float* dcat, int64_t planes, int64_t batch, int64_t hw, int c0,
                              int c1, int c2, int c3, int groups, void* stream) {
+    return cgp_bwd_impl(dparams, h1, h2, h3, packed_bwd, d1, d2, d3, dcat, nullptr, 0, planes, batch, hw, c0, c1, c2, c3, groups, stream);
+}
+
+// lldwt_cgp_bwd with the input gradient split as lldwt_cgp_rate_train_ctx reads the input: dplc (Z, groups*cplc, hw) = the
+// tree-context channels of every group, dtaps (Z, groups*ntaps, hw) = the gathered taps (c0 = cplc + ntaps)
+extern "C" int lldwt_cgp_bwd_split(const float* dparams, const float* h1, const float* h2, const float* h3, const float* packed_bwd,
+                                   float* d1, float* d2, float* d3, float* dplc, float* dtaps, int64_t planes, int64_t batch,
+                                   int64_t hw, int cplc, int ntaps, int c1, int c2, int c3, int groups, void* stream) {
+    LLDWT_REQUIRE(dtaps && cplc > 0 && ntaps > 0, "cgp_bwd_split: bad arguments");
+    return cgp_bwd_impl(dparams, h1, h2, h3, packed_bwd, d1, d2, d3, dplc, dtaps, cplc, planes, batch, hw, cplc + ntaps, c1, c2, c3,
+                        groups, stream);
+}
+
+static int cgp_bwd_impl(const float* dparams, const float* h1, const float* h2, const float* h3, const float* packed_bwd,
+                        float* d1, float* d2, float* d3, float* dcat, float* dtaps, int split, int64_t planes, int64_t batch,
+                        int64_t hw, int c0, int c1, int c2, int c3, int groups, void* stream) {
     int r = cgp_bwd_dims_ok("cgp_bwd", c0, c1, c2, c3, groups);
     if (r) return r;
     LLDWT_REQUIRE(dparams && h1 && h2 && h3 && packed_bwd && d1 && d2 && d3 && dcat && planes > 0 && batch > 0 && hw > 0 &&
@@ -597,6 +650,6 @@ extern "C" int lldwt_cgp_bwd(const float* dparams, const float* h1, const float*
     }
     dim3 grid((unsigned)cdiv(cdiv(hw, CGP_PX), CGP_TILES_PER_WG), (unsigned)groups, (unsigned)(planes * batch));
     hipLaunchKernelGGL(k_cgp_bwd, grid, dim3(256), shmem, (hipStream_t)stream, dparams, h1, h2, h3, packed_bwd, d1, d2, d3,
-                       dcat, d, groups, (int)batch, hw);
+                       dcat, d, groups, (int)batch, hw, dtaps, split);
     return check_launch("cgp_bwd");
 }

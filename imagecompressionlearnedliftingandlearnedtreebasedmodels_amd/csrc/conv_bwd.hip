@@ -593,6 +593,8 @@ struct W1Args {
     int batch, cin, cout, groups;
     int64_t hw;
     float alpha;
+    const float* x2;    // split input (lldwt_wgrad1x1_split): rows >= split of every group come from x2 (Z, groups*(cin_g - split), hw),
+    int split;          // rows < split from x (Z, groups*split, hw); x2 == null: one tensor (Z, cin, hw)
 };
 constexpr int W1_KC = 32;           // pixels per chunk
 constexpr int W1_PS = W1_KC + 2;    // LDS row stride: == 2 (mod 32) dwords, 8-byte aligned rows
@@ -626,7 +628,9 @@ __global__ __launch_bounds__(256) void k_wgrad1x1(W1Args a) {
         const int64_t p0 = (int64_t)(q - b * cpi) * W1_KC;
         const int64_t z = (int64_t)plane * a.batch + b;
         const float* dyz = a.dy + (z * a.cout + (int64_t)g * cout_g + m0) * hw + p0;
-        const float* xz = a.x + (z * a.cin + (int64_t)g * cin_g) * hw + p0;
+        const int csp = a.x2 ? a.split : cin_g + 1;                  // rows >= csp: second source
+        const float* xz = a.x2 ? a.x + (z * a.groups + g) * (int64_t)a.split * hw + p0 : a.x + (z * a.cin + (int64_t)g * cin_g) * hw + p0;
+        const float* xz2 = a.x2 ? a.x2 + (z * a.groups + g) * (int64_t)(cin_g - a.split) * hw + p0 - (int64_t)a.split * hw : xz;
         const int npx = (int)(hw - p0 < W1_KC ? hw - p0 : W1_KC);     // valid pixels of this chunk
         f4u raw[NV];
 #pragma unroll
@@ -636,8 +640,8 @@ __global__ __launch_bounds__(256) void k_wgrad1x1(W1Args a) {
             const bool isa = row < MR;
             const int ch = isa ? row : row - MR;
             const bool ok = (isa ? m0 + ch < cout_g : ch < cin_g) && v4 + 3 < npx;
-            const float* src = isa ? dyz : xz;
-            raw[r] = *reinterpret_cast<const f4u*>(src + (ok ? (int64_t)ch * hw + v4 : 0));
+            const float* src = isa ? dyz : (ch < csp ? xz : xz2);
+            raw[r] = *reinterpret_cast<const f4u*>(ok ? src + (int64_t)ch * hw + v4 : (isa ? dyz : xz));
         }
         __syncthreads();                                   // the previous chunk's LDS reads are done
 #pragma unroll
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(256) void k_wgrad1x1(W1Args a) {
             const bool ok = chan && v4 + 3 < npx;
             floatx4 v = ok ? floatx4{raw[r].x, raw[r].y, raw[r].z, raw[r].w} : floatx4{0.f, 0.f, 0.f, 0.f};
             if (chan && !ok && v4 < npx) {                 // ragged end of the image
-                const float* src = (isa ? dyz : xz) + (int64_t)ch * hw + v4;
+                const float* src = (isa ? dyz : (ch < csp ? xz : xz2)) + (int64_t)ch * hw + v4;
 #pragma unroll
                 for (int e = 0; e < 3; ++e)
                     if (v4 + e < npx) v[e] = src[e];
@@ -799,6 +803,24 @@ extern "C" int lldwt_conv2d_wgrad(const float* x, const float* dy, float* dw, fl
     return lldwt_conv2d_wgrad_ex(x, dy, dw, dbias, d, planes, batch, h, w_, 1.0f, 0, stream);
 }
 
+// Weight gradient of a grouped 1x1 conv whose input is two tensors side by side per group: rows < ca of group g from xa
+// (planes, batch, groups*ca, hw), the other cb rows from xb (planes, batch, groups*cb, hw) -- layer 0 of the cgp stack with the folded
+// context (LiftingBasedDWT_net.py:282-289,353-359: [tree-context channels | gathered taps]) without the concatenated tensor.
+// dw (planes, cout, ca + cb) += sum dy (x) [xa | xb], dbias (planes, cout) += sum dy (optional).
+extern "C" int lldwt_wgrad1x1_split(const float* xa, const float* xb, const float* dy, float* dw, float* dbias, int64_t planes,
+                                    int64_t batch, int64_t hw, int ca, int cb, int cout, int groups, void* stream) {
+    LLDWT_REQUIRE(xa && xb && dy && dw && planes > 0 && planes <= 65535 && batch > 0 && hw > 0 && ca > 0 && cb > 0 && groups > 0 &&
+                      cout % groups == 0, "wgrad1x1_split: bad arguments");
+    W1Args w;
+    w.x = xa; w.x2 = xb; w.split = ca; w.dy = dy; w.dw = dw; w.db = dbias; w.batch = (int)batch; w.cin = (ca + cb) * groups;
+    w.cout = cout; w.groups = groups; w.hw = hw; w.alpha = 1.f;
+    const int cout_g = cout / groups, nb = ca + cb + (dbias ? 1 : 0);
+    if (cout_g > 64 && nb > 64 && nb <= 192) return launch_wgrad1x1<1, 4, 6, 3>(w, (int)planes, (hipStream_t)stream);
+    if (cout_g > 16 && cout_g <= 64 && nb > 64 && nb <= 192) return launch_wgrad1x1<1, 4, 4, 3>(w, (int)planes, (hipStream_t)stream);
+    set_error("wgrad1x1_split: built for 64 < ca + cb (+1) <= 192 input rows and more than 16 output channels per group (got %d, %d)", nb, cout_g);
+    return LLDWT_EINVAL;
+}
+
 // conv4's and conv1's weight gradients of one lifting step (C = 16, K = 3 or 5, all taps) in one launch of k_wgrad_thin2:
 //   dw4 (planes,1,16,K,K) += alpha sum t3 (x) g,  db4 += alpha sum g;   dw1 (planes,16,1,K,K) += alpha sum dr (x) skip,  db1 += alpha sum dr
 namespace lldwt {
@@ -864,7 +886,7 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
     if (d->K == 1 && !d->upsample2 && d->oc_block >= d->cout && d->oc_off == 0 && d->ytot == d->cout && d->ic_block == 0) {
         W1Args w;
         w.x = x; w.dy = dy; w.dw = dw; w.db = dbias; w.batch = (int)batch; w.cin = d->cin; w.cout = d->cout;
-        w.groups = d->groups; w.hw = h * w_; w.alpha = alpha;
+        w.groups = d->groups; w.hw = h * w_; w.alpha = alpha; w.x2 = nullptr; w.split = 0;
         const int nb = cin_g + (dbias ? 1 : 0);
         // 96 x 192 tile (the 162 x 162 layer takes two row blocks: a 192 x 192 tile needs 144 accumulator registers per
         // lane and leaves no room for the staging vectors at 2 waves per SIMD), 64 x 192 for the 54-row layers

@@ -12,6 +12,8 @@ wavefront schedule on the GPU (entropy_coding.py) and the range coder is the C-A
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -545,6 +547,10 @@ class DWTConditioned2EntropyLayerZTBlock(_EntropyLayerBase):
 # Same maths as the eval path, but every op is a differentiable autograd.Function (forward AND backward are HIP
 # kernels; torch only keeps the tape and un-stacks the per-plane parameter gradients).  Built for the headline
 # configuration: LiftingBasedNeuralWaveletv4 + SubbandAutoEncoder + conditioned2ZTsepSubbands.
+# LLDWT_CGP_TRAIN=cat keeps the concatenated [plc_g | taps_g] input of the training cgp stack (CgpRateFn instead of CgpRateCtxFn)
+_CGP_TRAIN_CTX = os.environ.get("LLDWT_CGP_TRAIN", "ctx") != "cat"
+
+
 def _tstack(mods, get):
     ts = [get(m) for m in mods]
     if all(isinstance(t, torch.nn.Parameter) for t in ts):
@@ -670,9 +676,10 @@ def _fold_csc_into_cgp(convs, cs, G):
     return packed, dims, packed16
 
 
-def _fold_csc_train(cg, cs, xq):
+def _fold_csc_train(cg, cs, xq, want_patches=True):
     """Differentiable version of _fold_csc_into_cgp for the training path.  Returns the folded layer-0 weight
-    (P, G*c1, cpl + ntaps, 1, 1), bias (P, G*c1) and the gathered taps of xq as a (P,B,G*ntaps,h,w) tensor."""
+    (P, G*c1, cpl + ntaps, 1, 1), bias (P, G*c1) and the gathered taps of xq as a (P,B,G*ntaps,h,w) tensor (None when
+    want_patches is False: the kernels of CgpRateCtxFn gather them themselves)."""
     for m in cs:
         m.apply_mask_()
     K = cs[0].kernel_size[0]
@@ -692,6 +699,8 @@ def _fold_csc_train(cg, cs, xq):
     Wf = torch.matmul(W0g[..., cpl:], Wcg)                                          # (P, G, c1, ntaps)
     w0f = torch.cat([W0g[..., :cpl], Wf], dim=3).reshape(P, G * c1, cpl + len(live), 1, 1)
     b0f = (b0.reshape(P, G, c1) + torch.matmul(W0g[..., cpl:], bc.reshape(P, G, cc, 1))[..., 0]).reshape(P, G * c1)
+    if not want_patches:
+        return w0f.contiguous(), b0f.contiguous(), None
     # taps of the quantised subband, zero outside the image: patches[:, :, g*ntaps + j] = xq[:, :, g] shifted by tap j
     Pn, B, Gx, h, w = xq.shape
     xp = F.pad(xq, (R, R, R, R))
@@ -725,13 +734,18 @@ def _entropy_train_cond2(em, out_xe, out_xo, rnd):
         # Same fold as the eval path (the masked csc conv is linear into cgp layer 0), written with differentiable tensor
         # ops on the PARAMETERS (tiny matmuls) and on the 12-tap patch gather (data movement), so autograd carries the
         # gradients of the fused kernels back to W0, the csc weights / bias and the quantised subband by itself.
-        w0f, b0f, patches = _fold_csc_train(cg, cs, xo_q)
         G = cg[0][0].groups
-        pl, pa = plc.chunk(G, dim=2), patches.chunk(G, dim=2)
-        t = torch.cat([z_ for g_ in range(G) for z_ in (pl[g_], pa[g_])], dim=2)      # per subband [plc_g | taps_g]
+        no_cat = _CGP_TRAIN_CTX and xo_q.shape[-1] * xo_q.shape[-2] < (1 << 31)
+        w0f, b0f, patches = _fold_csc_train(cg, cs, xo_q, want_patches=not no_cat)
         wb = [w0f, b0f] + [p for n in (2, 4, 6) for p in (_tstack([s_[n] for s_ in cg], lambda m: m.weight),
                                                           _tstack([s_[n] for s_ in cg], lambda m: m.bias))]
-        si_list.append(ag.CgpRateFn.apply(t.contiguous(), out_xo[i], rnd(out_xo[i]), G, *wb))
+        if no_cat:      # the kernels read plc and gather the taps of xo_q themselves: no [plc_g | taps_g] tensor (1.75 GB at level 0)
+            si_list.append(ag.CgpRateCtxFn.apply(plc.contiguous(), xo_q.contiguous(), out_xo[i], rnd(out_xo[i]), G,
+                                                 cs[0].kernel_size[0], cs[0].tap_bits(), *wb))
+        else:
+            pl, pa = plc.chunk(G, dim=2), patches.chunk(G, dim=2)
+            t = torch.cat([z_ for g_ in range(G) for z_ in (pl[g_], pa[g_])], dim=2)      # per subband [plc_g | taps_g]
+            si_list.append(ag.CgpRateFn.apply(t.contiguous(), out_xo[i], rnd(out_xo[i]), G, *wb))
         q_list.append(xo_q)
         parent = xo_q
     q_list.reverse()

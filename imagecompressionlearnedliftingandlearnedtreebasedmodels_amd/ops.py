@@ -681,6 +681,49 @@ def cgp_rate_train(cat, x, packed, dims, noise):
     return bits, params, hs[0], hs[1], hs[2]
 
 
+def cgp_rate_train_ctx(plc, xq, x, packed, dims, noise, K, tap_mask):
+    """Training forward of the fused cgp stack reading its input as the eval path does (lldwt_cgp_rate_train_ctx): plc
+    (P,B,G*cplc,h,w) + the live taps of the quantised subband xq (P,B,G,h,w) gathered in the kernel -- no concatenated tensor.
+    dims[0] = cplc + number of live taps.  -> (bits, params (P,B,2G,h,w), h1, h2, h3)."""
+    P, B, G, h, w = x.shape
+    ntaps = bin(int(tap_mask)).count("1")
+    cplc = dims[0] - ntaps
+    if plc.shape != (P, B, G * cplc, h, w) or xq.shape != (P, B, G, h, w):
+        raise _lib.LLDWTError("cgp_rate_train_ctx: shapes %r %r %r" % (tuple(plc.shape), tuple(xq.shape), tuple(x.shape)))
+    bits = torch.empty_like(x)
+    params = torch.empty(P, B, 2 * G, h, w, device=x.device, dtype=torch.float32)
+    hs = [torch.empty(P, B, G * dims[l], h, w, device=x.device, dtype=torch.float32) for l in (1, 2, 3)]
+    check(_lib.load().lldwt_cgp_rate_train_ctx(_chk(plc, "plc"), _chk(xq, "xq"), _chk(x, "x"), _opt(noise), _chk(packed, "packed"),
+                                               _chk(bits), _chk(params), _chk(hs[0]), _chk(hs[1]), _chk(hs[2]), P, B, h, w, cplc,
+                                               K, int(tap_mask), dims[1], dims[2], dims[3], G, _stream()), "cgp_rate_train_ctx")
+    return bits, params, hs[0], hs[1], hs[2]
+
+
+def cgp_bwd_split(dparams, h1, h2, h3, packed_bwd, dims, groups, ntaps):
+    """lldwt_cgp_bwd_split -> (dplc (P,B,G*cplc,h,w), dtaps (P,B,G*ntaps,h,w), d1, d2, d3)."""
+    P, B, _, h, w = dparams.shape
+    cplc = dims[0] - ntaps
+    d1, d2, d3 = torch.empty_like(h1), torch.empty_like(h2), torch.empty_like(h3)
+    dplc = torch.empty(P, B, groups * cplc, h, w, device=dparams.device, dtype=torch.float32)
+    dtaps = torch.empty(P, B, groups * ntaps, h, w, device=dparams.device, dtype=torch.float32)
+    check(_lib.load().lldwt_cgp_bwd_split(_chk(dparams), _chk(h1), _chk(h2), _chk(h3), _chk(packed_bwd), _chk(d1), _chk(d2), _chk(d3),
+                                          _chk(dplc), _chk(dtaps), P, B, h * w, cplc, ntaps, dims[1], dims[2], dims[3], groups,
+                                          _stream()), "cgp_bwd_split")
+    return dplc, dtaps, d1, d2, d3
+
+
+def wgrad1x1_split(xa, xb, dy, groups, want_bias=True):
+    """Weight gradient of a grouped 1x1 conv whose input is [xa rows | xb rows] per group (lldwt_wgrad1x1_split):
+    xa (P,B,G*ca,h,w), xb (P,B,G*cb,h,w), dy (P,B,cout,h,w) -> (dw (P,cout,ca+cb,1,1), db (P,cout) or None)."""
+    P, B, ca_t, h, w = xa.shape
+    ca, cb, cout = ca_t // groups, xb.shape[2] // groups, dy.shape[2]
+    dw = torch.zeros(P, cout, ca + cb, 1, 1, device=xa.device, dtype=torch.float32)
+    db = torch.zeros(P, cout, device=xa.device, dtype=torch.float32) if want_bias else None
+    check(_lib.load().lldwt_wgrad1x1_split(_chk(xa, "xa"), _chk(xb, "xb"), _chk(dy, "dy"), _chk(dw), _opt(db), P, B, h * w, ca, cb,
+                                           cout, groups, _stream()), "wgrad1x1_split")
+    return dw, db
+
+
 def cgp_pack_bwd(ws, groups):
     """The four forward 1x1 weights (P, groups*c_{l+1}, c_l, 1, 1) -> transposed pack for cgp_bwd."""
     lib = _lib.load()

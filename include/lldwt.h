@@ -516,6 +516,24 @@ int lldwt_cgp_pack_bwd(const float* w0, const float* w1, const float* w2, const 
 int lldwt_cgp_bwd(const float* dparams, const float* h1, const float* h2, const float* h3, const float* packed_bwd,
                   float* d1, float* d2, float* d3, float* dcat, int64_t planes, int64_t batch, int64_t hw, int c0, int c1,
                   int c2, int c3, int groups, void* stream);
+/* The training stack WITHOUT the concatenated [tree-context channels | gathered taps] input tensor (1.75 GB at the level-0 shape of
+ * configs[2], written by a torch.cat and read back; its gradient took the same way back):
+ *   lldwt_cgp_rate_train_ctx : lldwt_cgp_rate_train reading its input as lldwt_cgp_rate_ctx does -- plc (Z, groups*cplc, h, w)
+ *                              and the live taps of the quantised subband xq (Z, groups, h, w), gathered in the kernel;
+ *   lldwt_cgp_bwd_split      : lldwt_cgp_bwd with the input gradient as two tensors, dplc (Z, groups*cplc, hw) and
+ *                              dtaps (Z, groups*ntaps, hw) (tap order = ascending live taps of the mask);
+ *   lldwt_wgrad1x1_split     : weight gradient of a grouped 1x1 conv whose input rows are [xa rows | xb rows] per group
+ *                              (layer 0: xa = plc, xb = the gathered taps), dw (planes, cout, ca + cb), dbias (planes, cout).
+ * Autograd of LiftingBasedDWT_net.py:282-289,353-365.                                                                       */
+int lldwt_cgp_rate_train_ctx(const float* plc, const float* xq, const float* x, const float* noise, const float* packed,
+                             float* bits, float* params_out, float* h1, float* h2, float* h3, int64_t planes, int64_t batch,
+                             int64_t h, int64_t w_, int cplc, int K, uint32_t tap_mask, int c1, int c2, int c3, int groups,
+                             void* stream);
+int lldwt_cgp_bwd_split(const float* dparams, const float* h1, const float* h2, const float* h3, const float* packed_bwd,
+                        float* d1, float* d2, float* d3, float* dplc, float* dtaps, int64_t planes, int64_t batch, int64_t hw,
+                        int cplc, int ntaps, int c1, int c2, int c3, int groups, void* stream);
+int lldwt_wgrad1x1_split(const float* xa, const float* xb, const float* dy, float* dw, float* dbias, int64_t planes,
+                         int64_t batch, int64_t hw, int ca, int cb, int cout, int groups, void* stream);
 
 /* Factorized (compressai EntropyBottleneck.forward, call sites LiftingBasedDWT_net.py:225,229,815,818):
  * per channel c of plane p: 5 tiny matrices softplus(_matrix{i}) (1x3,3x3,3x3,3x3,3x1), biases, tanh(_factor).

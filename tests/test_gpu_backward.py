@@ -182,6 +182,49 @@ def test_cgp_fused_forward_backward(dims, hw, PB):
             assert maxdiff(a.grad[p].cpu(), b.grad) < 5e-4 * scale, name
 
 
+@pytest.mark.parametrize("hw,PB", [((9, 13), (2, 2)), ((67, 131), (2, 1)), ((128, 192), (1, 2))])
+def test_cgp_ctx_training_path_equals_the_concatenated_one(hw, PB):
+    """CgpRateCtxFn (lldwt_cgp_rate_train_ctx / lldwt_cgp_bwd_split / lldwt_wgrad1x1_split: the kernels read the tree-context
+    tensor and gather the causal taps of the quantised subband themselves) against CgpRateFn on the explicit [plc_g | taps_g]
+    concatenation with autograd through the gather -- bits, and the gradients of plc, the quantised subband, the coefficients and
+    all eight parameter tensors (LiftingBasedDWT_net.py:282-289,353-365; the 5x5 type-A mask keeps 12 causal taps)."""
+    ag, ops, gu = _mods()
+    g = torch.Generator().manual_seed(hw[0])
+    P, B = PB
+    G, K, cplc = 3, 5, 81
+    live = list(range(12))                                             # rows 0, 1 and the first two taps of row 2
+    tap_mask = sum(1 << t for t in live)
+    h, w = hw
+    c = [cplc + len(live), 162, 54, 18, 2]
+    plc = torch.randn(P, B, G * cplc, h, w, generator=g)
+    xq = torch.round(torch.randn(P, B, G, h, w, generator=g) * 3) + (torch.rand(P, B, G, h, w, generator=g) - 0.5)
+    x = torch.randn(P, B, G, h, w, generator=g) * 2
+    noise = torch.rand(P, B, G, h, w, generator=g) - 0.5
+    ws = [torch.randn(P, G * c[l + 1], c[l], 1, 1, generator=g) * (1.5 / c[l] ** 0.5) for l in range(4)]
+    bs = [torch.randn(P, G * c[l + 1], generator=g) * 0.1 for l in range(4)]
+    bs[3] = bs[3] + torch.tensor([1.0, 0.0] * G)
+    gb = torch.rand(P, B, G, h, w, generator=g)
+    flat = [plc, xq, x] + [t for pair in zip(ws, bs) for t in pair]
+
+    def run(ctx):
+        dv = [gu.dev(t).requires_grad_(True) for t in flat]
+        if ctx:
+            bits = ag.CgpRateCtxFn.apply(dv[0], dv[1], dv[2], gu.dev(noise), G, K, tap_mask, *dv[3:])
+        else:
+            patches = ag.CgpRateCtxFn._gather(dv[1], K, live)          # differentiable torch ops, as _fold_csc_train builds them
+            pl, pa = dv[0].chunk(G, dim=2), patches.chunk(G, dim=2)
+            cat = torch.cat([z for gi in range(G) for z in (pl[gi], pa[gi])], dim=2).contiguous()
+            bits = ag.CgpRateFn.apply(cat, dv[2], gu.dev(noise), G, *dv[3:])
+        bits.backward(gu.dev(gb))
+        return bits.detach(), [t.grad for t in dv]
+    b1, g1 = run(True)
+    b0, g0 = run(False)
+    assert torch.equal(b1, b0)                                          # the same kernel on the same values
+    names = ["plc", "xq", "x"] + ["w%d" % (i // 2) if i % 2 == 0 else "b%d" % (i // 2) for i in range(8)]
+    for a, b, n in zip(g1, g0, names):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(b.abs().max())), n
+
+
 @pytest.mark.parametrize("fused_wgrad", [True, False])
 @pytest.mark.parametrize("C,hw", [(3, (7, 19)), (1, (16, 40)), (3, (72, 100))])
 def test_subband_mlp_fused_forward_backward(C, hw, fused_wgrad, monkeypatch):
