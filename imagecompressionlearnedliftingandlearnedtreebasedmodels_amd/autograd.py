@@ -88,6 +88,7 @@ class GaussRateFn(torch.autograd.Function):
 
 
 _MLP_WGRAD_FUSED = os.environ.get("LLDWT_MLP_WGRAD", "fused") != "gemm"
+_CGP_TRAIN_F16 = os.environ.get("LLDWT_CGP_TRAIN_FWD", "f16x3") != "f32"
 
 
 class SubbandMlpFn(torch.autograd.Function):
@@ -170,8 +171,15 @@ class CgpRateCtxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plc, xq, x, noise, groups, K, tap_mask, *wb):
         ws, bs = list(wb[0::2]), list(wb[1::2])
-        packed, dims = ops.cgp_pack(ws, bs, groups)
-        bits, params, h1, h2, h3 = ops.cgp_rate_train_ctx(plc, xq, x, packed, dims, noise, K, tap_mask)
+        dims = tuple([ws[0].shape[2]] + [w_.shape[1] // groups for w_ in ws[:3]])
+        if _CGP_TRAIN_F16 and dims == (93, 162, 54, 18) and ops.cgp_mode() == "f16x3":
+            # the forward on the eval path's split-fp16 register chain, which also writes the hidden activations (fp32-level accuracy;
+            # 1.4 -> ~3 ms per step against 6.0 for the fp32-MFMA kernel); LLDWT_CGP_TRAIN_FWD=f32 keeps the latter
+            params, h1, h2, h3 = ops.cgp16_params_train(plc, xq, ops.cgp16_pack(ws, bs, groups), K, tap_mask)
+            bits, _ = ops.gauss_rate(x, params, noise)
+        else:
+            packed, dims = ops.cgp_pack(ws, bs, groups)
+            bits, params, h1, h2, h3 = ops.cgp_rate_train_ctx(plc, xq, x, packed, dims, noise, K, tap_mask)
         ctx.save_for_backward(plc, xq, x, noise, params, h1, h2, h3, *ws)
         ctx.dims, ctx.groups, ctx.K, ctx.tap_mask = dims, groups, K, tap_mask
         return bits

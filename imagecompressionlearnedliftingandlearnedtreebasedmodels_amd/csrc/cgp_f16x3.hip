@@ -161,6 +161,9 @@ struct Cgp16Args {
     float* wf_mu;                         // decoder: (Z, groups, wf_n) means of this step
     int64_t wf_ntot, wf_off;
     unsigned long long* stamps;   // diagnostics only (lldwt_set_diagnostics kind 2): [z][group][column][8] s_memtime stamps
+    // TRAIN: the hidden activations after LeakyReLU in the layout of the unfused convs, h1 (Z, groups*162, hw), h2 (Z, groups*54,
+    // hw), h3 (Z, groups*18, hw): what lldwt_cgp_bwd_split gates with and the 1x1 weight-gradient GEMMs read
+    float* h1; float* h2; float* h3;
 };
 #define CGP_STAMP(i)                                                                                                    \
     if (a.stamps && lane == 0)                                                                                          \
@@ -178,8 +181,11 @@ __device__ __forceinline__ void load_bias_scaled(const float* bias_lds, int h, f
 #pragma unroll
     for (int q = 0; q < 16; ++q) bsc[q] = bias_lds[drow(q, h)] * snext;
 }
-template <int PREC>
-__device__ __forceinline__ void next_frags(const floatx16& acc, float k, const float (&bsc)[16], half8 (&bh)[2], half8 (&bl)[2]) {
+// TRAIN: the activation (v / snext: exact, a power of two) also goes to hout[row * hw] for the rows below nrows -- hout = this
+// lane's pixel in channel 0 of the tile, or null for a pixel past the image; a register's 32 lanes of one half write 128 contiguous bytes
+template <int PREC, bool TRAIN = false>
+__device__ __forceinline__ void next_frags(const floatx16& acc, float k, const float (&bsc)[16], half8 (&bh)[2], half8 (&bl)[2],
+                                           float* hout = nullptr, int64_t hw = 0, int h5 = 0, int nrows = 0, float inv_snext = 1.f) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         float v[8];
@@ -187,6 +193,10 @@ __device__ __forceinline__ void next_frags(const floatx16& acc, float k, const f
         for (int j = 0; j < 8; ++j) {
             const float t = __builtin_fmaf(acc[8 * s + j], k, bsc[8 * s + j]);
             v[j] = fmaxf(t, 0.01f * t);
+            if constexpr (TRAIN) {
+                const int row = drow(8 * s + j, h5);
+                if (hout && row < nrows) hout[(int64_t)row * hw] = v[j] * inv_snext;
+            }
         }
         if constexpr (PREC == 0) split8v(v, bh[s], bl[s]);
         else bh[s] = cvt8<PREC>(v);
@@ -196,8 +206,11 @@ __device__ __forceinline__ void next_frags(const floatx16& acc, float k, const f
 // PREC (lldwt_set_precision): 0 = three MFMA products per MAC (split fp16), 1 / 2 = one product on fp16 / bf16 operands
 // WF: one wavefront step of the real entropy coder (see Cgp16Args): the pixel list is the step's anti-diagonal and the epilogue
 // turns (sigma, mu) into CDF index + symbol + dequantised value (LiftingBasedDWT_net.py:458-506: compress_ar's per-pixel work)
-template <int PREC, bool WF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_cgp16(Cgp16Args a) {
+// TRAIN: the training forward -- also writes the hidden activations (see Cgp16Args); always the fp32-accurate PREC 0
+template <int PREC, bool WF = false, bool TRAIN = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRAIN ? 2 : 3, TRAIN ? 2 : 3))) void k_cgp16(Cgp16Args a) {
+    // (TRAIN: two waves per SIMD -- the store addresses do not fit the 168 registers of three)
+    static_assert(!TRAIN || (PREC == 0 && !WF), "the training forward runs the split-fp16 arithmetic on whole images");
     constexpr int SB = PREC == 2 ? STEP_BYTES / 2 : STEP_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h5 = lane >> 5, pl = lane & 31;
@@ -344,7 +357,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             float bsc[16];
             load_bias_scaled(bias0 + 32 * m0, h5, s1, bsc);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) next_frags<PREC>(acc0[nb], inv0 * s1, bsc, b1h[nb], b1l[nb]);
+            for (int nb = 0; nb < NB; ++nb) {
+                if constexpr (TRAIN)
+                    next_frags<PREC, true>(acc0[nb], inv0 * s1, bsc, b1h[nb], b1l[nb],
+                                           valid[nb] ? a.h1 + ((z * a.groups + g) * C1 + 32 * m0) * hw + pix[nb] : nullptr, hw, h5,
+                                           C1 - 32 * m0, 1.f / s1);
+                else next_frags<PREC>(acc0[nb], inv0 * s1, bsc, b1h[nb], b1l[nb]);
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -370,7 +389,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             float bsc[16];
             load_bias_scaled(bias1 + 32 * m1, h5, s2, bsc);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) next_frags<PREC>(acc1[nb][m1], inv1 * s2, bsc, b2h[nb], b2l[nb]);
+            for (int nb = 0; nb < NB; ++nb) {
+                if constexpr (TRAIN)
+                    next_frags<PREC, true>(acc1[nb][m1], inv1 * s2, bsc, b2h[nb], b2l[nb],
+                                           valid[nb] ? a.h2 + ((z * a.groups + g) * C2 + 32 * m1) * hw + pix[nb] : nullptr, hw, h5,
+                                           C2 - 32 * m1, 1.f / s2);
+                else next_frags<PREC>(acc1[nb][m1], inv1 * s2, bsc, b2h[nb], b2l[nb]);
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -393,7 +418,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             float bsc[16];
             load_bias_scaled(bias2, h5, s3, bsc);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) next_frags<PREC>(acc2[nb], inv2 * s3, bsc, b3h[nb], b3l[nb]);
+            for (int nb = 0; nb < NB; ++nb) {
+                if constexpr (TRAIN)
+                    next_frags<PREC, true>(acc2[nb], inv2 * s3, bsc, b3h[nb], b3l[nb],
+                                           valid[nb] ? a.h3 + (z * a.groups + g) * C3 * hw + pix[nb] : nullptr, hw, h5, C3, 1.f / s3);
+                else next_frags<PREC>(acc2[nb], inv2 * s3, bsc, b3h[nb], b3l[nb]);
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -466,14 +496,33 @@ extern "C" int lldwt_cgp16_pack(const float* w0, const float* b0, const float* w
     return check_launch("cgp16_pack");
 }
 
+static int cgp16_params_impl(const float* plc, const float* xq, const void* packed, float* params, float* h1, float* h2, float* h3,
+                             int64_t planes, int64_t batch, int64_t h, int64_t w_, int groups, int K, uint32_t tap_mask, void* stream);
+
 extern "C" int lldwt_cgp16_params(const float* plc, const float* xq, const void* packed, float* params, int64_t planes,
                                   int64_t batch, int64_t h, int64_t w_, int groups, int K, uint32_t tap_mask, void* stream) {
+    return cgp16_params_impl(plc, xq, packed, params, nullptr, nullptr, nullptr, planes, batch, h, w_, groups, K, tap_mask, stream);
+}
+
+// the training forward of the cgp stack on the same register chain (always the fp32-accurate split-fp16 arithmetic): (sigma, mu) as
+// lldwt_cgp16_params + the hidden activations after LeakyReLU, h1 (Z, groups*162, hw), h2 (Z, groups*54, hw), h3 (Z, groups*18, hw) --
+// what lldwt_cgp_rate_train_ctx writes on fp32 MFMA (6.0 ms per training step of configs[2] against 1.4 for the eval chain)
+extern "C" int lldwt_cgp16_params_train(const float* plc, const float* xq, const void* packed, float* params, float* h1, float* h2,
+                                        float* h3, int64_t planes, int64_t batch, int64_t h, int64_t w_, int groups, int K,
+                                        uint32_t tap_mask, void* stream) {
+    LLDWT_REQUIRE(h1 && h2 && h3, "cgp16_params_train: null output");
+    return cgp16_params_impl(plc, xq, packed, params, h1, h2, h3, planes, batch, h, w_, groups, K, tap_mask, stream);
+}
+
+static int cgp16_params_impl(const float* plc, const float* xq, const void* packed, float* params, float* h1, float* h2, float* h3,
+                             int64_t planes, int64_t batch, int64_t h, int64_t w_, int groups, int K, uint32_t tap_mask, void* stream) {
     LLDWT_REQUIRE(plc && xq && packed && params && planes > 0 && batch > 0 && h > 0 && w_ > 0 && groups > 0, "cgp16_params: bad arguments");
     LLDWT_REQUIRE(K == 3 || K == 5, "cgp16_params: K=%d unsupported", K);
     LLDWT_REQUIRE(planes * batch <= 65535 && groups <= 65535, "cgp16_params: grid too large");
     LLDWT_REQUIRE((int64_t)CPLC * h * w_ < ((int64_t)1 << 31), "cgp16_params: image too large for 32-bit offsets");
     Cgp16Args a;
     a.plc = plc; a.xq = xq; a.params = params; a.packed = reinterpret_cast<const uint8_t*>(packed);
+    a.h1 = h1; a.h2 = h2; a.h3 = h3;
     a.batch = (int)batch; a.groups = groups; a.h = (int)h; a.w = (int)w_; a.K = K;
     int n = 0;
     for (int t = 0; t < K * K; ++t)
@@ -492,7 +541,8 @@ extern "C" int lldwt_cgp16_params(const float* plc, const float* xq, const void*
     }
     dim3 grid((unsigned)cdiv(a.cols, 4), (unsigned)groups, (unsigned)(planes * batch));
     const int prec = split_precision();
-    if (prec == 1) hipLaunchKernelGGL((k_cgp16<1, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (h1) hipLaunchKernelGGL((k_cgp16<0, false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (prec == 1) hipLaunchKernelGGL((k_cgp16<1, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (prec == 2) hipLaunchKernelGGL((k_cgp16<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_cgp16<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("cgp16_params");

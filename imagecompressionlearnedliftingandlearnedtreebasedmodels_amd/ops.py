@@ -470,6 +470,18 @@ def cgp16_params(plc, xq, packed16, K, tap_mask):
     return params
 
 
+def cgp16_params_train(plc, xq, packed16, K, tap_mask):
+    """Training forward of the cgp stack on the split-fp16 register chain (lldwt_cgp16_params_train):
+    -> (params (P,B,2G,h,w), h1 (P,B,G*162,h,w), h2 (P,B,G*54,h,w), h3 (P,B,G*18,h,w))."""
+    P, B, G, h, w = xq.shape
+    params = torch.empty(P, B, 2 * G, h, w, device=xq.device, dtype=torch.float32)
+    hs = [torch.empty(P, B, G * c, h, w, device=xq.device, dtype=torch.float32) for c in (162, 54, 18)]
+    check(_lib.load().lldwt_cgp16_params_train(_chk(plc, "plc"), _chk(xq, "xq"), C.c_void_p(packed16.data_ptr()), _chk(params),
+                                              _chk(hs[0]), _chk(hs[1]), _chk(hs[2]), P, B, h, w, G, K, int(tap_mask), _stream()),
+          "cgp16_params_train")
+    return params, hs[0], hs[1], hs[2]
+
+
 def plc_shape():
     """MFMA shape of the split-fp16 3x3 conv kernels in this process: 32 (32x32x16, default) or 16 (LLDWT_PLC_SHAPE=16)."""
     return 16 if _lib.load().lldwt_plc_shape16() else 32

@@ -419,6 +419,13 @@ int lldwt_cgp16_pack(const float* w0, const float* b0, const float* w1, const fl
                      int groups, void* stream);
 int lldwt_cgp16_params(const float* plc, const float* xq, const void* packed, float* params, int64_t planes, int64_t batch,
                        int64_t h, int64_t w_, int groups, int K, uint32_t tap_mask, void* stream);
+/* The training forward on the same register chain (always the fp32-accurate split-fp16 arithmetic, whatever lldwt_set_precision
+ * says): lldwt_cgp16_params + the hidden activations after LeakyReLU in the layout of the unfused convs, h1 (Z, groups*162, hw),
+ * h2 (Z, groups*54, hw), h3 (Z, groups*18, hw) -- what lldwt_cgp_bwd_split gates with and the 1x1 weight-gradient GEMMs read.
+ * The bits follow from lldwt_gauss_rate on (x, params, noise).  Training forward of LiftingBasedDWT_net.py:282-289,357-365.   */
+int lldwt_cgp16_params_train(const float* plc, const float* xq, const void* packed, float* params, float* h1, float* h2, float* h3,
+                             int64_t planes, int64_t batch, int64_t h, int64_t w_, int groups, int K, uint32_t tap_mask,
+                             void* stream);
 /* Real entropy coding of a level with tree context + masked KxK context + cgp (the reference walks its pixels in raster
  * order with a CNN call on a crop each, graphs/models/LiftingBasedDWT_net.py:402-417,440-454,458-556): ONE anti-diagonal
  * wavefront step t = x + (K/2 + 1) * y, all planes / images / subbands / pixels of the step in one launch of the cgp
