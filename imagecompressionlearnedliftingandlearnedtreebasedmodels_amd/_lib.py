@@ -135,6 +135,9 @@ SIGNATURES = {
     "lldwt_cgp16_pack": (_i, [_p] * 9 + [_i64, _i, _i, _i, _i, _i, _p]),
     "lldwt_cgp16_params": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, C.c_uint32, _p]),
     "lldwt_cgp16_params_train": (_i, [_p] * 7 + [_i64, _i64, _i64, _i64, _i, _i, C.c_uint32, _p]),
+    "lldwt_cgp16_bwd_packed_bytes": (_i64, [_i, _i, _i, _i, _i]),
+    "lldwt_cgp16_pack_bwd": (_i, [_p] * 5 + [_i64, _i, _i, _i, _i, _i, _p]),
+    "lldwt_cgp16_bwd": (_i, [_p] * 10 + [_i64, _i64, _i64, _i, _p]),
     "lldwt_cgp_rate_train": (_i, [_p] * 9 + [_i64, _i64, _i64, _i, _i, _i, _i, _i, _p]),
     "lldwt_cgp_bwd_packed_floats": (_i64, [_i, _i, _i, _i, _i]),
     "lldwt_cgp_pack_bwd": (_i, [_p] * 5 + [_i64, _i, _i, _i, _i, _i, _p]),

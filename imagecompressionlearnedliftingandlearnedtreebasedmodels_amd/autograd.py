@@ -89,6 +89,7 @@ class GaussRateFn(torch.autograd.Function):
 
 _MLP_WGRAD_FUSED = os.environ.get("LLDWT_MLP_WGRAD", "fused") != "gemm"
 _CGP_TRAIN_F16 = os.environ.get("LLDWT_CGP_TRAIN_FWD", "f16x3") != "f32"
+_CGP_TRAIN_BWD_F16 = os.environ.get("LLDWT_CGP_TRAIN_BWD", "f16x3") != "f32"
 
 
 class SubbandMlpFn(torch.autograd.Function):
@@ -191,7 +192,11 @@ class CgpRateCtxFn(torch.autograd.Function):
         live = CgpRateCtxFn._taps(K, ctx.tap_mask)
         nt, R = len(live), K // 2
         dx, dparams = ops.gauss_rate_bwd(x, params, noise, gbits.contiguous())
-        dplc, dtaps, d1, d2, d3 = ops.cgp_bwd_split(dparams, h1, h2, h3, ops.cgp_pack_bwd(ws, G), dims, G, nt)
+        if _CGP_TRAIN_BWD_F16 and dims == (93, 162, 54, 18) and nt == 12 and ops.cgp_mode() == "f16x3":
+            # backward-data on the split-fp16 register chain (LLDWT_CGP_TRAIN_BWD=f32 keeps the fp32-MFMA kernel)
+            dplc, dtaps, d1, d2, d3 = ops.cgp16_bwd(dparams, h1, h2, h3, ops.cgp16_pack_bwd(ws, G), G)
+        else:
+            dplc, dtaps, d1, d2, d3 = ops.cgp_bwd_split(dparams, h1, h2, h3, ops.cgp_pack_bwd(ws, G), dims, G, nt)
         grads = list(ops.wgrad1x1_split(plc, CgpRateCtxFn._gather(xq, K, live), d1, G))
         for xin, dy, w in ((h1, d2, ws[1]), (h2, d3, ws[2]), (h3, dparams, ws[3])):
             dw, db = ops.conv2d_wgrad(xin, dy, tuple(w.shape), 1, groups=G)

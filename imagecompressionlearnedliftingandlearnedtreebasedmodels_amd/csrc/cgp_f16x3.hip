@@ -473,6 +473,247 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRAIN ? 2 :
 }
 #undef CGP_STAMP
 
+
+// ================================================================================================================
+// Backward-data of the stack on the same register chain (training; autograd of LiftingBasedDWT_net.py:282-289,357-365).
+//   d3 = lrelu'(h3) . W3^T dparams (2 -> 18),  d2 = lrelu'(h2) . W2^T d3 (18 -> 54),  d1 = lrelu'(h1) . W1^T d2 (54 -> 162),
+//   [dplc | dtaps] = W0^T d1 (162 -> 81 + 12)
+// -- the transposed weights packed in step order with the permuted k order of an accumulator tile used as the next operand, exactly
+// as the forward chain; the layers WIDEN here, so the 162-wide d1 is never held whole: each of its six 32-row tiles is gated, written
+// out, split and at once accumulated into the three output tiles (65 weight steps: 1 + 4 + 6 x (4 + 6)).  The gates come from the
+// SIGN of the stored activations (LeakyReLU: 1 or 0.01), loaded 16 rows per lane -- 128 contiguous bytes per half-wave and channel,
+// like the stores of d1 / d2 / d3 (what the 1x1 weight-gradient GEMMs read).  Operand scales: the wave's max |dparams| and the
+// transposed layers' max row L1 norms (gates <= 1), as the forward bounds.  Replaces k_cgp_bwd (fp32 MFMA, 7.3 ms per training step).
+constexpr int NSTEPB = 1 + 2 * NM1 + NM0 * (2 * NM1 + 2 * 3);                 // 65
+constexpr int HDRB_BYTES = 64 * 4;
+constexpr int GROUPB_BYTES = HDRB_BYTES + (NSTEPB + 3) * STEP_BYTES;
+
+__global__ void k_cgp16_pack_bwd(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
+                                 const float* __restrict__ w3, uint8_t* __restrict__ packed, int groups) {
+    const int plane = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const float* W[4] = {w0 + ((int64_t)plane * groups + g) * C1 * C0, w1 + ((int64_t)plane * groups + g) * C2 * C1,
+                         w2 + ((int64_t)plane * groups + g) * C3 * C2, w3 + ((int64_t)plane * groups + g) * C4 * C3};
+    const int cin[4] = {C0, C1, C2, C3}, cout[4] = {C1, C2, C3, C4};
+    uint8_t* dst = packed + ((int64_t)plane * groups + g) * GROUPB_BYTES;
+    float* hdr = reinterpret_cast<float*>(dst);
+    __shared__ float red[2][4];
+    __shared__ float sc[4][2];           // per forward layer: max |w|, max COLUMN L1 norm (= row norm of the transposed layer)
+    for (int l = 0; l < 4; ++l) {
+        float mw = 0.f, ml1 = 0.f;
+        for (int c = tid; c < cin[l]; c += 256) {
+            float s_ = 0.f;
+            for (int r = 0; r < cout[l]; ++r) {
+                const float v = fabsf(W[l][r * cin[l] + c]);
+                s_ += v;
+                mw = fmaxf(mw, v);
+            }
+            ml1 = fmaxf(ml1, s_);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+            ml1 = fmaxf(ml1, __shfl_xor(ml1, o, 64));
+        }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = mw; red[1][tid >> 6] = ml1; }
+        __syncthreads();
+        if (tid < 2) sc[l][tid] = fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3]));
+        __syncthreads();
+    }
+    // backward layer b uses forward layer 3 - b
+    float sw[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sw[b] = pow2_scale(sc[3 - b][0]);
+    if (tid < 4) {
+        hdr[tid] = sw[tid];                    // [0..3] weight scales of the backward layers
+        hdr[4 + tid] = sc[3 - tid][1];         // [4..7] max row L1 norm of the transposed layers
+    }
+    _Float16* fr = reinterpret_cast<_Float16*>(dst + HDRB_BYTES);
+    for (int i = tid; i < (NSTEPB + 3) * 512; i += 256) {
+        const int j = i & 7, lane = (i >> 3) & 63, step = i >> 9;
+        const int row = lane & 31, h = lane >> 5;
+        const int perm = 8 * (j >> 2) + 4 * h + (j & 3);          // row (inside a 16-row half tile) this k of a chained step holds
+        float v = 0.f;
+        if (step == 0) {                                           // 2 -> 18: natural k order
+            const int out = row, in = 8 * h + j;
+            if (out < C3 && in < C4) v = W[3][in * C3 + out] * sw[0];
+        } else if (step < 1 + 2 * NM1) {                           // 18 -> 54: steps (m2, s)
+            const int r = step - 1, m2 = r / 2, s_ = r % 2;
+            const int out = 32 * m2 + row, in = 16 * s_ + perm;
+            if (out < C2 && in < C3) v = W[2][in * C2 + out] * sw[1];
+        } else if (step < NSTEPB) {
+            const int r = step - 1 - 2 * NM1, m = r / 10, q = r % 10;
+            if (q < 4) {                                           // 54 -> 162, output tile m: steps (t, s)
+                const int t = q / 2, s_ = q % 2;
+                const int out = 32 * m + row, in = 32 * t + 16 * s_ + perm;
+                if (out < C1 && in < C2) v = W[1][in * C1 + out] * sw[2];
+            } else {                                               // 162 -> 93 fed by tile m of d1: steps (s, n)
+                const int s_ = (q - 4) / 3, n = (q - 4) % 3;
+                const int out = 32 * n + row, in = 32 * m + 16 * s_ + perm;
+                if (out < C0 && in < C1) v = W[0][in * C0 + out] * sw[3];
+            }
+        }
+        const _Float16 hi = (_Float16)v;
+        fr[step * 1024 + lane * 8 + j] = hi;
+        fr[step * 1024 + 512 + lane * 8 + j] = (_Float16)(v - (float)hi);
+    }
+}
+
+struct Cgp16BwdArgs {
+    const float* dparams;   // (Z, 2*groups, hw)
+    const float* h1; const float* h2; const float* h3;
+    const uint8_t* packed;
+    float* d1; float* d2; float* d3;
+    float* dplc;            // (Z, groups*81, hw)
+    float* dtaps;           // (Z, groups*12, hw)
+    int batch, groups, cols;
+    int64_t hw;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cgp16_bwd(Cgp16BwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h5 = lane >> 5, pl = lane & 31;
+    const int64_t z = blockIdx.z;
+    const int plane = (int)(z / a.batch), g = blockIdx.y;
+    const int col = blockIdx.x * 4 + wave;
+    if (col >= a.cols) return;                                   // whole wave; no barrier in this kernel
+    const int64_t hw = a.hw;
+    const uint8_t* grp = a.packed + ((int64_t)plane * a.groups + g) * GROUPB_BYTES;
+    const float* hdr = reinterpret_cast<const float*>(grp);
+    const uint8_t* wst = grp + HDRB_BYTES + lane * 16;
+    const int64_t p = (int64_t)col * 32 + pl;
+    const bool valid = p < hw;
+    const int64_t pc = valid ? p : hw - 1;
+    const int64_t zg = z * a.groups + g;
+    const float* dp = a.dparams + zg * 2 * hw;
+    const float v0 = valid ? dp[pc] : 0.f, v1 = valid ? dp[hw + pc] : 0.f;
+    float amax = fmaxf(fabsf(v0), fabsf(v1));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float s_in = pow2_scale(amax);
+    const float bound3 = amax * hdr[4], bound2 = bound3 * hdr[5], bound1 = bound2 * hdr[6];
+    const float s3 = pow2_scale(bound3), s2 = pow2_scale(bound2), s1 = pow2_scale(bound1);
+    const float inv0 = (1.f / s_in) * (1.f / hdr[0]), inv1 = (1.f / s3) * (1.f / hdr[1]);
+    const float inv2 = (1.f / s2) * (1.f / hdr[2]), inv3 = (1.f / s1) * (1.f / hdr[3]);
+
+    half8 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(wst + i * STEP_BYTES);
+        al[i] = *reinterpret_cast<const half8*>(wst + i * STEP_BYTES + 1024);
+    }
+    int step = 0;
+#define CGPB_NEXT()                                                                                   \
+    {                                                                                                 \
+        ah[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * STEP_BYTES);          \
+        al[(step + 3) & 3] = *reinterpret_cast<const half8*>(wst + (step + 3) * STEP_BYTES + 1024);   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+#define CGPB_MMA(ACC, BH, BL)                                                                         \
+    {                                                                                                 \
+        ACC = mma32<0>(al[step & 3], BH, ACC);                                                        \
+        ACC = mma32<0>(ah[step & 3], BL, ACC);                                                        \
+        ACC = mma32<0>(ah[step & 3], BH, ACC);                                                        \
+    }
+    // the stored activations of one tile (rows below nrows; 1 elsewhere: those rows carry zero weights)
+    auto load_h = [&](const float* hbase, int nrows, float (&hv)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = drow(q, h5);
+            hv[q] = row < nrows ? hbase[(int64_t)row * hw + pc] : 1.f;
+        }
+    };
+    // gate, write out (value / snext), split into the next layer's two k-steps
+    auto gate_frags = [&](const floatx16& acc, float k, const float (&hv)[16], float* dbase, int nrows, float inv_snext,
+                          half8 (&bh)[2], half8 (&bl)[2]) {
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = 8 * s_ + j, row = drow(q, h5);
+                v[j] = acc[q] * k * (hv[q] > 0.f ? 1.f : 0.01f);
+                if (valid && row < nrows) dbase[(int64_t)row * hw + pc] = v[j] * inv_snext;
+            }
+            split8v(v, bh[s_], bl[s_]);
+        }
+    };
+    floatx16 zero16;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zero16[q] = 0.f;
+
+    // ---- 2 -> 18
+    float hv3[16];
+    load_h(a.h3 + zg * C3 * hw, C3, hv3);
+    half8 f3h[2], f3l[2];
+    {
+        float vin[8] = {h5 == 0 ? v0 * s_in : 0.f, h5 == 0 ? v1 * s_in : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        half8 bh, bl;
+        split8v(vin, bh, bl);
+        floatx16 acc = zero16;
+        CGPB_NEXT()
+        CGPB_MMA(acc, bh, bl)
+        ++step;
+        gate_frags(acc, inv0 * s3, hv3, a.d3 + zg * C3 * hw, C3, 1.f / s3, f3h, f3l);
+    }
+    // ---- 18 -> 54
+    half8 f2h[NM1][2], f2l[NM1][2];
+#pragma unroll
+    for (int m2 = 0; m2 < NM1; ++m2) {
+        float hv2[16];
+        load_h(a.h2 + (zg * C2 + 32 * m2) * hw, C2 - 32 * m2, hv2);
+        floatx16 acc = zero16;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            CGPB_NEXT()
+            CGPB_MMA(acc, f3h[s_], f3l[s_])
+            ++step;
+        }
+        gate_frags(acc, inv1 * s2, hv2, a.d2 + (zg * C2 + 32 * m2) * hw, C2 - 32 * m2, 1.f / s2, f2h[m2], f2l[m2]);
+    }
+    // ---- 54 -> 162 -> 93, one 32-row tile of d1 at a time
+    floatx16 accO[3] = {zero16, zero16, zero16};
+#pragma unroll
+    for (int m = 0; m < NM0; ++m) {
+        float hv1[16];
+        load_h(a.h1 + (zg * C1 + 32 * m) * hw, C1 - 32 * m, hv1);
+        floatx16 acc = zero16;
+#pragma unroll
+        for (int t = 0; t < NM1; ++t)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                CGPB_NEXT()
+                CGPB_MMA(acc, f2h[t][s_], f2l[t][s_])
+                ++step;
+            }
+        half8 f1h[2], f1l[2];
+        gate_frags(acc, inv2 * s1, hv1, a.d1 + (zg * C1 + 32 * m) * hw, C1 - 32 * m, 1.f / s1, f1h, f1l);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                CGPB_NEXT()
+                CGPB_MMA(accO[n], f1h[s_], f1l[s_])
+                ++step;
+            }
+    }
+#undef CGPB_NEXT
+#undef CGPB_MMA
+    // ---- the input gradient: rows 0..80 -> dplc, rows 81..92 -> dtaps
+    if (valid) {
+        float* dpl = a.dplc + zg * CPLC * hw + pc;
+        float* dtp = a.dtaps + zg * (C0 - CPLC) * hw + pc;
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * n + drow(q, h5);
+                const float v = accO[n][q] * inv3;
+                if (row < CPLC) dpl[(int64_t)row * hw] = v;
+                else if (row < C0) dtp[(int64_t)(row - CPLC) * hw] = v;
+            }
+    }
+}
+
 }  // namespace
 }  // namespace lldwt
 using namespace lldwt;
@@ -614,4 +855,32 @@ extern "C" int lldwt_wavefront_apply(const int* sym, const float* mu, float* yha
     dim3 grid((unsigned)cdiv(n, 64), (unsigned)groups, (unsigned)(planes * batch));
     hipLaunchKernelGGL(k_wf_apply, grid, dim3(64), 0, (hipStream_t)stream, sym, mu, yhat, groups, (int)h, (int)w_, t, slope, y0, n, ntot, off);
     return check_launch("wavefront_apply");
+}
+
+extern "C" int64_t lldwt_cgp16_bwd_packed_bytes(int c0, int c1, int c2, int c3, int groups) {
+    if (c0 != C0 || c1 != C1 || c2 != C2 || c3 != C3 || groups <= 0) return -1;
+    return (int64_t)groups * GROUPB_BYTES;
+}
+
+extern "C" int lldwt_cgp16_pack_bwd(const float* w0, const float* w1, const float* w2, const float* w3, void* packed, int64_t planes,
+                                    int c0, int c1, int c2, int c3, int groups, void* stream) {
+    LLDWT_REQUIRE(lldwt_cgp16_bwd_packed_bytes(c0, c1, c2, c3, groups) > 0, "cgp16_pack_bwd: built for 93 -> 162 -> 54 -> 18 -> 2 (got %d,%d,%d,%d)", c0, c1, c2, c3);
+    LLDWT_REQUIRE(w0 && w1 && w2 && w3 && packed && planes > 0 && planes <= 65535, "cgp16_pack_bwd: bad arguments");
+    hipLaunchKernelGGL(k_cgp16_pack_bwd, dim3((unsigned)groups, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, w0, w1, w2, w3,
+                       reinterpret_cast<uint8_t*>(packed), groups);
+    return check_launch("cgp16_pack_bwd");
+}
+
+extern "C" int lldwt_cgp16_bwd(const float* dparams, const float* h1, const float* h2, const float* h3, const void* packed_bwd,
+                               float* d1, float* d2, float* d3, float* dplc, float* dtaps, int64_t planes, int64_t batch, int64_t hw,
+                               int groups, void* stream) {
+    LLDWT_REQUIRE(dparams && h1 && h2 && h3 && packed_bwd && d1 && d2 && d3 && dplc && dtaps && planes > 0 && batch > 0 && hw > 0 &&
+                      groups > 0 && planes * batch <= 65535 && groups <= 65535, "cgp16_bwd: bad arguments");
+    Cgp16BwdArgs a;
+    a.dparams = dparams; a.h1 = h1; a.h2 = h2; a.h3 = h3; a.packed = reinterpret_cast<const uint8_t*>(packed_bwd);
+    a.d1 = d1; a.d2 = d2; a.d3 = d3; a.dplc = dplc; a.dtaps = dtaps;
+    a.batch = (int)batch; a.groups = groups; a.hw = hw; a.cols = (int)cdiv(hw, 32);
+    dim3 grid((unsigned)cdiv(a.cols, 4), (unsigned)groups, (unsigned)(planes * batch));
+    hipLaunchKernelGGL(k_cgp16_bwd, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("cgp16_bwd");
 }

@@ -482,6 +482,32 @@ def cgp16_params_train(plc, xq, packed16, K, tap_mask):
     return params, hs[0], hs[1], hs[2]
 
 
+def cgp16_pack_bwd(ws, groups):
+    """The four forward 1x1 weights (P, groups*c_{l+1}, c_l, 1, 1) -> the transposed split-fp16 pack of cgp16_bwd (uint8 (P, bytes))."""
+    lib = _lib.load()
+    P = ws[0].shape[0]
+    c = [ws[0].shape[2]] + [w.shape[1] // groups for w in ws]
+    nb = int(lib.lldwt_cgp16_bwd_packed_bytes(c[0], c[1], c[2], c[3], groups))
+    if nb <= 0:
+        raise _lib.LLDWTError("cgp16_pack_bwd: dimensions %s not built (93 -> 162 -> 54 -> 18 -> 2 only)" % (c,))
+    packed = torch.empty(P, nb, device=ws[0].device, dtype=torch.uint8)
+    check(lib.lldwt_cgp16_pack_bwd(*[_chk(w, "w") for w in ws], C.c_void_p(packed.data_ptr()), P, c[0], c[1], c[2], c[3], groups,
+                                   _stream()), "cgp16_pack_bwd")
+    return packed
+
+
+def cgp16_bwd(dparams, h1, h2, h3, packed_bwd16, groups):
+    """Backward-data of the cgp stack on the split-fp16 register chain (lldwt_cgp16_bwd)
+    -> (dplc (P,B,G*81,h,w), dtaps (P,B,G*12,h,w), d1, d2, d3)."""
+    P, B, _, h, w = dparams.shape
+    d1, d2, d3 = torch.empty_like(h1), torch.empty_like(h2), torch.empty_like(h3)
+    dplc = torch.empty(P, B, groups * 81, h, w, device=dparams.device, dtype=torch.float32)
+    dtaps = torch.empty(P, B, groups * 12, h, w, device=dparams.device, dtype=torch.float32)
+    check(_lib.load().lldwt_cgp16_bwd(_chk(dparams), _chk(h1), _chk(h2), _chk(h3), C.c_void_p(packed_bwd16.data_ptr()), _chk(d1),
+                                      _chk(d2), _chk(d3), _chk(dplc), _chk(dtaps), P, B, h * w, groups, _stream()), "cgp16_bwd")
+    return dplc, dtaps, d1, d2, d3
+
+
 def plc_shape():
     """MFMA shape of the split-fp16 3x3 conv kernels in this process: 32 (32x32x16, default) or 16 (LLDWT_PLC_SHAPE=16)."""
     return 16 if _lib.load().lldwt_plc_shape16() else 32

@@ -426,6 +426,17 @@ int lldwt_cgp16_params(const float* plc, const float* xq, const void* packed, fl
 int lldwt_cgp16_params_train(const float* plc, const float* xq, const void* packed, float* params, float* h1, float* h2, float* h3,
                              int64_t planes, int64_t batch, int64_t h, int64_t w_, int groups, int K, uint32_t tap_mask,
                              void* stream);
+/* Backward-data of the stack on the same register chain (replaces lldwt_cgp_bwd_split's fp32-MFMA kernel for the reference's
+ * widths): dparams (Z, 2*groups, hw) = gradient at (sigma, mu); h1 / h2 / h3 = the activations lldwt_cgp16_params_train stored (their
+ * SIGN gates LeakyReLU); -> d1 (Z, groups*162, hw), d2 (Z, groups*54, hw), d3 (Z, groups*18, hw) = gradients at the pre-activation
+ * outputs (the dY of the 1x1 weight-gradient GEMMs) and the input gradient as dplc (Z, groups*81, hw) + dtaps (Z, groups*12, hw).
+ * lldwt_cgp16_pack_bwd: the four forward weights (PyTorch layout, as lldwt_cgp16_pack) -> the transposed pack.                    */
+int64_t lldwt_cgp16_bwd_packed_bytes(int c0, int c1, int c2, int c3, int groups);
+int lldwt_cgp16_pack_bwd(const float* w0, const float* w1, const float* w2, const float* w3, void* packed, int64_t planes, int c0,
+                         int c1, int c2, int c3, int groups, void* stream);
+int lldwt_cgp16_bwd(const float* dparams, const float* h1, const float* h2, const float* h3, const void* packed_bwd, float* d1,
+                    float* d2, float* d3, float* dplc, float* dtaps, int64_t planes, int64_t batch, int64_t hw, int groups,
+                    void* stream);
 /* Real entropy coding of a level with tree context + masked KxK context + cgp (the reference walks its pixels in raster
  * order with a CNN call on a crop each, graphs/models/LiftingBasedDWT_net.py:402-417,440-454,458-556): ONE anti-diagonal
  * wavefront step t = x + (K/2 + 1) * y, all planes / images / subbands / pixels of the step in one launch of the cgp

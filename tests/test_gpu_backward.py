@@ -182,9 +182,9 @@ def test_cgp_fused_forward_backward(dims, hw, PB):
             assert maxdiff(a.grad[p].cpu(), b.grad) < 5e-4 * scale, name
 
 
-@pytest.mark.parametrize("fwd", ["f32", "f16x3"])
+@pytest.mark.parametrize("fwd,bwd", [("f32", "f32"), ("f16x3", "f32"), ("f32", "f16x3"), ("f16x3", "f16x3")])
 @pytest.mark.parametrize("hw,PB", [((9, 13), (2, 2)), ((67, 131), (2, 1)), ((128, 192), (1, 2))])
-def test_cgp_ctx_training_path_equals_the_concatenated_one(hw, PB, fwd, monkeypatch):
+def test_cgp_ctx_training_path_equals_the_concatenated_one(hw, PB, fwd, bwd, monkeypatch):
     """CgpRateCtxFn (lldwt_cgp_rate_train_ctx / lldwt_cgp_bwd_split / lldwt_wgrad1x1_split: the kernels read the tree-context
     tensor and gather the causal taps of the quantised subband themselves) against CgpRateFn on the explicit [plc_g | taps_g]
     concatenation with autograd through the gather -- bits, and the gradients of plc, the quantised subband, the coefficients and
@@ -193,7 +193,9 @@ def test_cgp_ctx_training_path_equals_the_concatenated_one(hw, PB, fwd, monkeypa
     # fwd: CgpRateCtxFn's forward on the fp32-MFMA kernel (the same kernel as CgpRateFn's: bit-identical bits) or on the split-fp16
     # register chain with the hidden activations written out (lldwt_cgp16_params_train + lldwt_gauss_rate, the default): fp32-level
     # accuracy, so bits within 2e-4 and gradients within 2e-4 of each tensor's maximum
+    # bwd: the backward-data chain on the fp32-MFMA kernel (lldwt_cgp_bwd_split) or on the split-fp16 register chain (lldwt_cgp16_bwd)
     monkeypatch.setattr(ag, "_CGP_TRAIN_F16", fwd == "f16x3")
+    monkeypatch.setattr(ag, "_CGP_TRAIN_BWD_F16", bwd == "f16x3")
     g = torch.Generator().manual_seed(hw[0])
     P, B = PB
     G, K, cplc = 3, 5, 81
@@ -231,7 +233,7 @@ def test_cgp_ctx_training_path_equals_the_concatenated_one(hw, PB, fwd, monkeypa
         # rounding of the split arithmetic shows as up to ~1e-3 there; the bars at realistic weights are the oracle tests'
         assert float((b1 - b0).abs().mean()) < 2e-5 and float((b1 - b0).abs().max()) < 3e-3
     names = ["plc", "xq", "x"] + ["w%d" % (i // 2) if i % 2 == 0 else "b%d" % (i // 2) for i in range(8)]
-    tol = 2e-5 if fwd == "f32" else 5e-4
+    tol = 2e-5 if (fwd, bwd) == ("f32", "f32") else 5e-4
     for a, b, n in zip(g1, g0, names):
         assert float((a - b).abs().max()) <= tol * max(1e-6, float(b.abs().max())), n
 
