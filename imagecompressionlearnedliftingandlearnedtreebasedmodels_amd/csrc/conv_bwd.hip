@@ -803,6 +803,9 @@ extern "C" int lldwt_conv2d_wgrad(const float* x, const float* dy, float* dw, fl
     return lldwt_conv2d_wgrad_ex(x, dy, dw, dbias, d, planes, batch, h, w_, 1.0f, 0, stream);
 }
 
+// LLDWT_W1_TALL=0 keeps the 96 x 192 tile for the 162 x 94 weight gradient
+static const int g_w1_tall = [] { const char* e = getenv("LLDWT_W1_TALL"); return e ? atoi(e) : 1; }();
+
 // Weight gradient of a grouped 1x1 conv whose input is two tensors side by side per group: rows < ca of group g from xa
 // (planes, batch, groups*ca, hw), the other cb rows from xb (planes, batch, groups*cb, hw) -- layer 0 of the cgp stack with the folded
 // context (LiftingBasedDWT_net.py:282-289,353-359: [tree-context channels | gathered taps]) without the concatenated tensor.
@@ -815,6 +818,9 @@ extern "C" int lldwt_wgrad1x1_split(const float* xa, const float* xb, const floa
     w.x = xa; w.x2 = xb; w.split = ca; w.dy = dy; w.dw = dw; w.db = dbias; w.batch = (int)batch; w.cin = (ca + cb) * groups;
     w.cout = cout; w.groups = groups; w.hw = hw; w.alpha = 1.f;
     const int cout_g = cout / groups, nb = ca + cb + (dbias ? 1 : 0);
+    // 162 x 94 (layer 0 of the cgp stack): ONE 192 x 96 tile of dW per workgroup (72 accumulator registers) -- both operands are read
+    // once; the 96 x 192 tile read the input rows twice (two row blocks)
+    if (g_w1_tall && cout_g > 96 && cout_g <= 192 && nb > 64 && nb <= 96) return launch_wgrad1x1<2, 2, 6, 3>(w, (int)planes, (hipStream_t)stream);
     if (cout_g > 64 && nb > 64 && nb <= 192) return launch_wgrad1x1<1, 4, 6, 3>(w, (int)planes, (hipStream_t)stream);
     if (cout_g > 16 && cout_g <= 64 && nb > 64 && nb <= 192) return launch_wgrad1x1<1, 4, 4, 3>(w, (int)planes, (hipStream_t)stream);
     set_error("wgrad1x1_split: built for 64 < ca + cb (+1) <= 192 input rows and more than 16 output channels per group (got %d, %d)", nb, cout_g);
