@@ -282,7 +282,7 @@ struct W16Args {
 };
 
 template <int K>
-__global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
+__device__ __forceinline__ void wgrad16_body(const W16Args& a) {
     constexpr int NTH = K * 64, KK = K * K, R = K / 2;
     constexpr int IH = WG_TH + 2 * R, IW = WG_TW + 2 * R, IHW = IH * IW;
     constexpr int PSX = IHW + 2;                       // even (8-byte aligned rows for ds_write_b64), == 18 / 22 (mod 32)
@@ -421,6 +421,16 @@ __global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) {
         if (kk == 0) atomicAdd(a.db + plane * 16 + col, a.alpha * bsum);
     }
 }
+
+template <int K>
+__global__ __launch_bounds__(K * 64) void k_wgrad16(W16Args a) { wgrad16_body<K>(a); }
+
+// conv3's and conv2's 16 -> 16 weight gradients of one lifting step in ONE launch (blockIdx.y picks the problem): below 0.25 Mpixel
+// per plane these launches are latency-bound, and a step has two of them
+struct W16Pair { W16Args p[2]; };
+template <int K>
+__global__ __launch_bounds__(K * 64) void k_wgrad16_2(W16Pair a2) { wgrad16_body<K>(a2.p[blockIdx.y]); }
+
 
 struct WThinArgs {
     const float* a16;   // 16-channel operand (dY of conv1 / X of conv4)
@@ -826,6 +836,35 @@ extern "C" int lldwt_wgrad1x1_split(const float* xa, const float* xb, const floa
     set_error("wgrad1x1_split: built for 64 < ca + cb (+1) <= 192 input rows and more than 16 output channels per group (got %d, %d)", nb, cout_g);
     return LLDWT_EINVAL;
 }
+
+// conv3's (x = t2, dy = dt3) and conv2's (x = t1, dy = dpre2) 16 -> 16 weight gradients of one lifting step in one launch of k_wgrad16_2
+namespace lldwt {
+int wgrad16_pair(const float* x3, const float* dy3, float* dw3, float* db3, const float* x2, const float* dy2, float* dw2, float* db2,
+                 int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw, int K, hipStream_t st) {
+    LLDWT_REQUIRE(x3 && dy3 && dw3 && x2 && dy2 && dw2 && (K == 3 || K == 5), "wgrad16_pair: bad arguments");
+    LLDWT_REQUIRE(planes > 0 && planes <= 65535 && batch > 0 && h > 0 && w_ > 0, "wgrad16_pair: bad dims");
+    const int KK = K * K;
+    W16Pair a2;
+    for (int i = 0; i < 2; ++i) {
+        W16Args& w = a2.p[i];
+        w.x = i ? x2 : x3; w.dy = i ? dy2 : dy3; w.dw = i ? dw2 : dw3; w.db = i ? db2 : db3;
+        w.batch = (int)batch; w.h = (int)h; w.w = (int)w_; w.alpha = alpha;
+        for (int t = 0; t < 25; ++t) w.tap_of[t] = t < KK ? (int8_t)(swap_hw ? (t % K) * K + t / K : t) : 0;
+    }
+    const int64_t chunks = batch * cdiv(h, WG_TH) * cdiv(w_, WG_TW);
+    int per_cu = 2;
+    const void* kern = K == 5 ? (const void*)k_wgrad16_2<5> : (const void*)k_wgrad16_2<3>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, K * 64, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (per_cu > 8) per_cu = 8;
+    int64_t sl = (int64_t)lldwt_num_cus() * per_cu / (planes * 2);       // one resident round over both problems and all planes
+    if (sl > chunks / 4) sl = chunks / 4;
+    if (sl < 1) sl = 1;
+    dim3 grid((unsigned)sl, 2, (unsigned)planes);
+    if (K == 5) hipLaunchKernelGGL(k_wgrad16_2<5>, grid, dim3(320), 0, st, a2);
+    else hipLaunchKernelGGL(k_wgrad16_2<3>, grid, dim3(192), 0, st, a2);
+    return check_launch("wgrad16_pair");
+}
+}  // namespace lldwt
 
 // conv4's and conv1's weight gradients of one lifting step (C = 16, K = 3 or 5, all taps) in one launch of k_wgrad_thin2:
 //   dw4 (planes,1,16,K,K) += alpha sum t3 (x) g,  db4 += alpha sum g;   dw1 (planes,16,1,K,K) += alpha sum dr (x) skip,  db1 += alpha sum dr

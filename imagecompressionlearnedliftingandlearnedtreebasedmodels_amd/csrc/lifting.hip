@@ -1639,7 +1639,11 @@ int wgrad16_f16x3(const float* x, const float* dy, float* dw, float* dbias, floa
                   int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, const int8_t* tap_of, hipStream_t st);
 int wgrad_thin_pair(const float* t3, const float* g, float* dw4, float* db4, const float* skip, const float* dr, float* dw1,
                     float* db1, int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw, int K, hipStream_t st);
+int wgrad16_pair(const float* x3, const float* dy3, float* dw3, float* db3, const float* x2, const float* dy2, float* dw2, float* db2,
+                 int64_t planes, int64_t batch, int64_t h, int64_t w_, float alpha, int swap_hw, int K, hipStream_t st);
 }
+// LLDWT_WGRAD16_PAIR=0 keeps two launches for the fp32 16 -> 16 weight gradients of a step (the small levels)
+static const int g_w16_pair = [] { const char* e = getenv("LLDWT_WGRAD16_PAIR"); return e ? atoi(e) : 1; }();
 // LLDWT_WGRAD_THIN=2 keeps the two separate launches of the thin (1 <-> 16) weight gradients of a step
 static const int g_thin_pair = [] { const char* e = getenv("LLDWT_WGRAD_THIN"); return (e && !strcmp(e, "2")) ? 0 : 1; }();
 // LLDWT_WGRAD16=f32 keeps the fp32-MFMA weight gradient of the 16 -> 16 lifting convs (k_wgrad16<5>); default: split-fp16
@@ -1782,6 +1786,8 @@ static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_v
         if ((r = wgrad16_f16x3(t2, dt3, dw3, db3, slots, ss, slots_ready, planes, batch, h, w, alpha, tap_of, st))) return r;
         if ((r = wgrad16_f16x3(t1, dpre2, dw2, db2, slots + (slots_ready ? 64 : 0), ss, slots_ready, planes, batch, h, w, alpha, tap_of,
                                st))) return r;
+    } else if (g_w16_pair) {
+        if ((r = wgrad16_pair(t2, dt3, dw3, db3, t1, dpre2, dw2, db2, planes, batch, h, w, alpha, swap, K, st))) return r;
     } else {
         if ((r = lldwt_conv2d_wgrad_ex(t2, dt3, dw3, db3, &d, planes, batch, h, w, alpha, swap, stream))) return r;
         if ((r = lldwt_conv2d_wgrad_ex(t1, dpre2, dw2, db2, &d, planes, batch, h, w, alpha, swap, stream))) return r;
