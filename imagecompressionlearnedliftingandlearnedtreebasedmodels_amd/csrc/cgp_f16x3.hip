@@ -672,10 +672,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // ---- 54 -> 162 -> 93, one 32-row tile of d1 at a time
     floatx16 accO[3] = {zero16, zero16, zero16};
+    float hvn[16];                                   // the gates of the NEXT tile: requested a whole tile (10 weight steps) ahead
+    load_h(a.h1 + zg * C1 * hw, C1, hvn);
 #pragma unroll
     for (int m = 0; m < NM0; ++m) {
         float hv1[16];
-        load_h(a.h1 + (zg * C1 + 32 * m) * hw, C1 - 32 * m, hv1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hv1[q] = hvn[q];
+        if (m + 1 < NM0) load_h(a.h1 + (zg * C1 + 32 * (m + 1)) * hw, C1 - 32 * (m + 1), hvn);
         floatx16 acc = zero16;
 #pragma unroll
         for (int t = 0; t < NM1; ++t)
