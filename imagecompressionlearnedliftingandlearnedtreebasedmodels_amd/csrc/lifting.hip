@@ -902,7 +902,12 @@ static inline CView cv(lldwt_view v) { return CView{v.p, v.sz, v.sy, v.sx}; }
 
 // ---- backward helpers of one lifting step -------------------------------------------------------------------
 // g = G[dst_out] (view) copied to a dense (Z,h,w) tensor; G[dst_in] = g ("set": the step passes dst through unchanged)
-__global__ void k_lift_bwd_pre(CView gout, lldwt_view gdin, float* __restrict__ g, int h, int w) {
+__global__ void k_lift_bwd_pre(CView gout, lldwt_view gdin, float* __restrict__ g, int h, int w, float* __restrict__ zero_me,
+                               int nzero) {
+    // zero_me: the |max| slots of the fused backward launch that follows on the stream (128 floats per plane): zeroed here instead of
+    // by a memset launch per step
+    if (zero_me && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero_me[i] = 0.f;
     const int64_t z = blockIdx.z;
     for (int y = blockIdx.y; y < h; y += gridDim.y)
         for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
@@ -1586,7 +1591,8 @@ extern "C" int lldwt_lift_bwd_pre(lldwt_view g_dst_out, lldwt_view g_dst_in, flo
                                   void* stream) {
     LLDWT_REQUIRE(g_dst_out.p && g_dst_in.p && g && Z > 0 && Z <= 65535 && h > 0 && w > 0, "lift_bwd_pre: bad arguments");
     dim3 grid((unsigned)cdiv(w, 256), (unsigned)(h < 1024 ? h : 1024), (unsigned)Z);
-    hipLaunchKernelGGL(k_lift_bwd_pre, grid, dim3(256), 0, (hipStream_t)stream, cv(g_dst_out), g_dst_in, g, (int)h, (int)w);
+    hipLaunchKernelGGL(k_lift_bwd_pre, grid, dim3(256), 0, (hipStream_t)stream, cv(g_dst_out), g_dst_in, g, (int)h, (int)w,
+                       (float*)nullptr, 0);
     return check_launch("lift_bwd_pre");
 }
 
@@ -1742,14 +1748,13 @@ static int lift_step_bwd_impl(lldwt_view g_dst_out, lldwt_view g_dst_in, lldwt_v
     const bool wg16 = K == 5 && !linear && g_wgrad16_f16 && w % 4 == 0 && batch * h * w >= g_wgrad16_min;
     bool slots_ready = false;
     if (packed_bwd && K == LF_K && C == LF_C && !linear && g_bwd_lift_f16 && g_lift_mode == 1) {
-        if ((r = lldwt_lift_bwd_pre(g_dst_out, g_dst_in, g, Z, h, w, stream))) return r;
-        if (wg16) {                     // the fused launch leaves both maxima in the slots: no pass over dt3 / dpre2 for them
-            if (hipMemsetAsync(slots, 0, sizeof(float) * 128 * planes, st) != hipSuccess) {
-                set_error("lift_step_bwd: memset failed");
-                return LLDWT_EHIP;
-            }
-            slots_ready = true;
+        {   // g = G[dst_out], G[dst_in] = g; the same launch zeroes the |max| slots the fused launch fills (no memset per step)
+            dim3 grid((unsigned)cdiv(w, 256), (unsigned)(h < 1024 ? h : 1024), (unsigned)Z);
+            hipLaunchKernelGGL(k_lift_bwd_pre, grid, dim3(256), 0, st, cv(g_dst_out), g_dst_in, g, (int)h, (int)w,
+                               wg16 ? slots : (float*)nullptr, (int)(128 * planes));
+            if ((r = check_launch("lift_bwd_pre"))) return r;
         }
+        slots_ready = wg16;             // the fused launch leaves both maxima in the slots: no pass over dt3 / dpre2 for them
         const LiftF16Bwd bw{g, t1, t2, dt3, dpre2, dr, dsk, slots_ready ? slots : nullptr};
         const PackOff o = pack_off(C, K);
         r = lift_f16_step_bwd(bw, Z, batch, h, w, taps_id, packed_bwd, packed_plane_stride, o.orient, o.f16, vertical, st);
