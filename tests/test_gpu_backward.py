@@ -514,3 +514,31 @@ def test_new_backward_entries_refuse_bad_arguments():
         lib_rc = lib.lldwt_lift_step_bwd_f16(v, v, v, ptr(x), P, 2, 8, 8, ptr(x), ptr(x), ptr(x), 0, *[ptr(x)] * 8, 16, 5, 0.1, 1.0,
                                              1, 0, ptr(x), 1 << 20, None, None, None)
         _lib.check(lib_rc, "lift_step_bwd_f16")
+
+
+def test_late_round3_entries_refuse_bad_arguments():
+    """The entry points added at the end of round 3 fail loudly (LLDWTError), never silently: the register-chain packs for other
+    widths than the reference's, the split weight gradient for a tile plan it is not built for, a tree-conv weight gradient whose
+    |max| slots have the wrong size, null pointers."""
+    import ctypes
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd import _lib, ops
+    from imagecompressionlearnedliftingandlearnedtreebasedmodels_amd._lib import LLDWTError
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    P, G = 1, 3
+    ws = [torch.zeros(P, G * co, ci, 1, 1, device=dev) for co, ci in ((20, 12), (8, 20), (4, 8), (2, 4))]
+    with pytest.raises(LLDWTError, match="93"):
+        ops.cgp16_pack_bwd(ws, G)                                               # the chain is built for 93 -> 162 -> 54 -> 18 -> 2 only
+    assert lib.lldwt_cgp16_bwd_packed_bytes(12, 20, 8, 4, G) == -1
+    xa, xb = torch.zeros(P, 1, G * 8, 4, 4, device=dev), torch.zeros(P, 1, G * 4, 4, 4, device=dev)
+    with pytest.raises(LLDWTError, match="built for"):
+        ops.wgrad1x1_split(xa, xb, torch.zeros(P, 1, G * 20, 4, 4, device=dev), G)   # 12 input rows: below the tile plan
+    x = torch.zeros(P, 1, 64, 8, 8, device=dev)
+    with pytest.raises(LLDWTError, match="slots"):
+        ops.conv3x3_wgrad_f16x3(x, x, (P, 64, 64, 3, 3), x_slots=torch.zeros(P, 32, device=dev))
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.lldwt_cgp16_bwd(ptr(x), ptr(x), ptr(x), ptr(x), None, ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), 1, 1, 64, G, None)
+    assert rc == -1 and b"cgp16_bwd" in lib.lldwt_last_error()                  # LLDWT_EINVAL: null pack
+    rc = lib.lldwt_cgp_rate_train_ctx(ptr(x), None, ptr(x), None, ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), 1, 1, 8, 8, 81, 5,
+                                      0xFFF, 162, 54, 18, G, None)
+    assert rc == -1 and b"cgp_rate_train_ctx" in lib.lldwt_last_error()
