@@ -665,10 +665,13 @@ __device__ __forceinline__ float erfc_fast(float x) {
 // compressai GaussianConditional.forward/_likelihood as called at LiftingBasedDWT_net.py:334,345,364,832
 // grid: x over the pixels of one channel plane (4 per lane when aligned), y over (image, channel) -- no per-element
 // division (the first version's two 64-bit divisions per element cost more than the two erfc)
+// MODE: 1 = training (noise read), 2 = bits written, 4 = q written -- compile-time, so that the loop's waits count its own stores
+template <int MODE>
 __global__ __launch_bounds__(256) void k_gauss_rate(const float* __restrict__ x, const float* __restrict__ params,
                                                     const float* __restrict__ noise, float* __restrict__ bits,
                                                     float* __restrict__ qout, double* __restrict__ bit_sum, int C,
                                                     int64_t hw, int64_t ZC) {
+    constexpr bool train = (MODE & 1) != 0, WB = (MODE & 2) != 0, WQ = (MODE & 4) != 0;
     double local = 0;
     auto one = [&](float xv, float sg, float mu, float nz, bool train, float& b, float& v) {
         v = train ? xv + nz : rintf(xv - mu) + mu;
@@ -684,7 +687,6 @@ __global__ __launch_bounds__(256) void k_gauss_rate(const float* __restrict__ x,
         const float lik = fmaxf(up - lo, 1e-9f);
         b = -__builtin_amdgcn_logf(lik);
     };
-    const bool train = noise != nullptr;
     for (int64_t zc = blockIdx.y; zc < ZC; zc += gridDim.y) {
         const int64_t z = zc / C;
         const int c = (int)(zc - z * C);
@@ -692,47 +694,49 @@ __global__ __launch_bounds__(256) void k_gauss_rate(const float* __restrict__ x,
         const float* pm = ps + hw;
         const float* xp = x + zc * hw;
         const float* np = train ? noise + zc * hw : nullptr;
-        float* bp = bits ? bits + zc * hw : nullptr;
-        float* qp = qout ? qout + zc * hw : nullptr;
+        float* bp = WB ? bits + zc * hw : nullptr;
+        float* qp = WQ ? qout + zc * hw : nullptr;
         const bool vec = (hw & 3) == 0 && ((((uintptr_t)xp) | ((uintptr_t)ps) | ((uintptr_t)(bp ? bp : xp)) |
                                             ((uintptr_t)(qp ? qp : xp)) | ((uintptr_t)(np ? np : xp))) & 15) == 0;
         if (vec) {
-            // two 16-byte groups per lane and iteration: the six (eight) loads of both are issued before the first erfc
+            // one 16-byte group per lane and iteration, the NEXT group's three (four) loads issued before this group's arithmetic:
+            // a launch at the BASELINE batch is a single resident round whose waves all start together, so without the look-ahead
+            // the chip spends a load phase (no arithmetic) and then an arithmetic phase (no loads) -- the sum of the two, not the max
             const int64_t n4 = hw >> 2, stride = (int64_t)gridDim.x * blockDim.x;
-            for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n4; p += 2 * stride) {
-                const int64_t p1 = p + stride;
-                const bool two = p1 < n4;
-                const int64_t pb = two ? p1 : p;
-                const float4 xa = reinterpret_cast<const float4*>(xp)[p], xb = reinterpret_cast<const float4*>(xp)[pb];
-                const float4 sa = reinterpret_cast<const float4*>(ps)[p], sb = reinterpret_cast<const float4*>(ps)[pb];
-                const float4 ma = reinterpret_cast<const float4*>(pm)[p], mb = reinterpret_cast<const float4*>(pm)[pb];
-                float4 na = {0.f, 0.f, 0.f, 0.f}, nb = na;
-                if (train) { na = reinterpret_cast<const float4*>(np)[p]; nb = reinterpret_cast<const float4*>(np)[pb]; }
+            int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+            float4 xa = {0.f, 0.f, 0.f, 0.f}, sa = xa, ma = xa, na = xa;
+            if (p < n4) {
+                xa = reinterpret_cast<const float4*>(xp)[p];
+                sa = reinterpret_cast<const float4*>(ps)[p];
+                ma = reinterpret_cast<const float4*>(pm)[p];
+                if (train) na = reinterpret_cast<const float4*>(np)[p];
+            }
+            while (p < n4) {
+                const int64_t pn = p + stride;
+                float4 xb = xa, sb = sa, mb = ma, nb = na;
+                if (pn < n4) {
+                    xb = reinterpret_cast<const float4*>(xp)[pn];
+                    sb = reinterpret_cast<const float4*>(ps)[pn];
+                    mb = reinterpret_cast<const float4*>(pm)[pn];
+                    if (train) nb = reinterpret_cast<const float4*>(np)[pn];
+                }
                 float4 b, v;
                 one(xa.x, sa.x, ma.x, na.x, train, b.x, v.x);
                 one(xa.y, sa.y, ma.y, na.y, train, b.y, v.y);
                 one(xa.z, sa.z, ma.z, na.z, train, b.z, v.z);
                 one(xa.w, sa.w, ma.w, na.w, train, b.w, v.w);
-                if (bp) reinterpret_cast<float4*>(bp)[p] = b;
-                if (qp) reinterpret_cast<float4*>(qp)[p] = v;
-                float part = (b.x + b.y) + (b.z + b.w);
-                if (two) {
-                    one(xb.x, sb.x, mb.x, nb.x, train, b.x, v.x);
-                    one(xb.y, sb.y, mb.y, nb.y, train, b.y, v.y);
-                    one(xb.z, sb.z, mb.z, nb.z, train, b.z, v.z);
-                    one(xb.w, sb.w, mb.w, nb.w, train, b.w, v.w);
-                    if (bp) reinterpret_cast<float4*>(bp)[p1] = b;
-                    if (qp) reinterpret_cast<float4*>(qp)[p1] = v;
-                    part += (b.x + b.y) + (b.z + b.w);
-                }
-                local += (double)part;             // eight values of at most ~30 bits each: fp32 partial, fp64 running sum
+                if (WB) reinterpret_cast<float4*>(bp)[p] = b;
+                if (WQ) reinterpret_cast<float4*>(qp)[p] = v;
+                local += (double)((b.x + b.y) + (b.z + b.w));      // four values of at most ~30 bits each: fp32 partial, fp64 running sum
+                xa = xb; sa = sb; ma = mb; na = nb;
+                p = pn;
             }
         } else {
             for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
                 float b, v;
                 one(xp[p], ps[p], pm[p], train ? np[p] : 0.f, train, b, v);
-                if (bp) bp[p] = b;
-                if (qp) qp[p] = v;
+                if (WB) bp[p] = b;
+                if (WQ) qp[p] = v;
                 local += (double)b;
             }
         }
@@ -857,6 +861,8 @@ __global__ __launch_bounds__(256) void k_factorized_table(const float* __restric
         threadIdx.x < 2 * EB_TR + 1 ? eb_bits(e, (float)((int)threadIdx.x - EB_TR) + e[58]) : 0.f;
 }
 
+// WB / WQ: bits / q written -- compile-time, so that the eval loop's waits count its own stores
+template <bool WB, bool WQ>
 __global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict__ x, const float* __restrict__ eb,
                                                          const float* __restrict__ noise, float* __restrict__ bits,
                                                          float* __restrict__ qout, double* __restrict__ bit_sum,
@@ -865,6 +871,14 @@ __global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict
     const int c = blockIdx.y;
     const int64_t z = blockIdx.z;
     const int plane = (int)(z / batch);
+    // eval, 16-byte path: the first group of the stream is requested BEFORE the parameter / table prologue (a global round trip, the
+    // softplus / tanh of the parameters and a barrier that would otherwise stand in front of the first load of every workgroup)
+    const int64_t base0 = (z * C + c) * hw;
+    const bool vec = (hw & 3) == 0 && ((((uintptr_t)(x + base0)) | ((uintptr_t)(WB ? bits + base0 : x + base0)) |
+                                        ((uintptr_t)(WQ ? qout + base0 : x + base0))) & 15) == 0;
+    const int64_t n4 = hw >> 2, p0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    float4 xa = {0.f, 0.f, 0.f, 0.f};
+    if (!noise && vec && p0 < n4) xa = reinterpret_cast<const float4*>(x + base0)[p0];
     eb_process(eb + ((int64_t)plane * C + c) * LLDWT_EB_FLOATS, e);
     constexpr int TR = EB_TR;
     __shared__ float tab[2 * TR + 1];
@@ -888,38 +902,41 @@ __global__ __launch_bounds__(256) void k_factorized_rate(const float* __restrict
             q = r + med;
             b = fabsf(r) <= (float)TR ? tab[(int)r + TR] : bits_of(q);
         };
-        const bool vec = (hw & 3) == 0 && ((((uintptr_t)(x + base)) | ((uintptr_t)(bits ? bits + base : x + base)) |
-                                            ((uintptr_t)(qout ? qout + base : x + base))) & 15) == 0;
         if (vec) {
             const float4* x4 = reinterpret_cast<const float4*>(x + base);
-            float4* b4 = bits ? reinterpret_cast<float4*>(bits + base) : nullptr;
-            float4* q4 = qout ? reinterpret_cast<float4*>(qout + base) : nullptr;
-            for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < (hw >> 2); p += (int64_t)gridDim.x * blockDim.x) {
-                const float4 xv = x4[p];
+            float4* b4 = WB ? reinterpret_cast<float4*>(bits + base) : nullptr;
+            float4* q4 = WQ ? reinterpret_cast<float4*>(qout + base) : nullptr;
+            const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+            for (int64_t p = p0; p < n4;) {                      // the next group's load in flight under this group's look-ups
+                const int64_t pn = p + stride;
+                float4 xb = xa;
+                if (pn < n4) xb = x4[pn];
                 float4 b, q;
-                one(xv.x, b.x, q.x);
-                one(xv.y, b.y, q.y);
-                one(xv.z, b.z, q.z);
-                one(xv.w, b.w, q.w);
-                if (b4) b4[p] = b;
-                if (q4) q4[p] = q;
+                one(xa.x, b.x, q.x);
+                one(xa.y, b.y, q.y);
+                one(xa.z, b.z, q.z);
+                one(xa.w, b.w, q.w);
+                if (WB) b4[p] = b;
+                if (WQ) q4[p] = q;
                 local += (double)b.x + (double)b.y + (double)b.z + (double)b.w;
+                xa = xb;
+                p = pn;
             }
         } else {
-            for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+            for (int64_t p = p0; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
                 float b, q;
                 one(x[base + p], b, q);
-                if (bits) bits[base + p] = b;
-                if (qout) qout[base + p] = q;
+                if (WB) bits[base + p] = b;
+                if (WQ) qout[base + p] = q;
                 local += (double)b;
             }
         }
     } else {
-        for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t p = p0; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
             const float v = x[base + p] + noise[base + p];
             const float b = bits_of(v);
-            if (bits) bits[base + p] = b;
-            if (qout) qout[base + p] = v;
+            if (WB) bits[base + p] = b;
+            if (WQ) qout[base + p] = v;
             local += (double)b;
         }
     }
@@ -1247,15 +1264,25 @@ extern "C" int lldwt_gauss_rate(const float* x, const float* params, const float
                                 double* bit_sum, int64_t Z, int C, int64_t hw, void* stream) {
     LLDWT_REQUIRE(x && params && Z > 0 && C > 0 && hw > 0, "gauss_rate: bad arguments");
     const int64_t ZC = Z * C;
-    // at most 16 workgroups per CU in all (each ends in one double atomic on bit_sum: thousands of them on one address
-    // serialise), every lane with two or more 16-byte loads per operand to issue
+    // Many short workgroups: their start times spread by themselves, so the loads of some overlap the ~100 vector instructions per
+    // coefficient of others (one 16-byte group per lane; a launch of a few long-lived workgroups runs in step -- a load phase, then
+    // an arithmetic phase: 16.3 vs 18.2 us at the BASELINE batch).  With bit_sum every workgroup ends in one double atomic on ONE
+    // address (thousands of them serialise at the memory side): at most 16 workgroups per CU then, every lane taking k groups with the
+    // next one's loads in flight.
     int64_t gy = ZC > 65535 ? 65535 : ZC;
-    int64_t gx = cdiv(hw, 2048);                           // two 16-byte groups per lane
-    const int64_t cap = (int64_t)lldwt_num_cus() * 16;
-    if (gx * gy > cap) gx = cdiv(cap, gy);
+    const int64_t cap = (int64_t)lldwt_num_cus() * (bit_sum ? 16 : 128);
+    int64_t gx = cdiv(hw, 1024);
+    for (int k = 2; gx * gy > cap && gx > 1; ++k) gx = cdiv(hw, 1024 * (int64_t)k);   // k iterations for every lane alike
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
-    hipLaunchKernelGGL(k_gauss_rate, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, x, params, noise, bits, qout,
-                       bit_sum, C, hw, ZC);
+    const int mode = (noise ? 1 : 0) | (bits ? 2 : 0) | (qout ? 4 : 0);
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+#define LLDWT_GR_LAUNCH(M) \
+    case M: hipLaunchKernelGGL(k_gauss_rate<M>, grid, dim3(256), 0, (hipStream_t)stream, x, params, noise, bits, qout, bit_sum, C, hw, ZC); break;
+    switch (mode) {
+        LLDWT_GR_LAUNCH(0) LLDWT_GR_LAUNCH(1) LLDWT_GR_LAUNCH(2) LLDWT_GR_LAUNCH(3)
+        LLDWT_GR_LAUNCH(4) LLDWT_GR_LAUNCH(5) LLDWT_GR_LAUNCH(6) LLDWT_GR_LAUNCH(7)
+    }
+#undef LLDWT_GR_LAUNCH
     return check_launch("gauss_rate");
 }
 extern "C" int lldwt_quantize(const float* x, const float* noise, float* q, int64_t n, void* stream) {
@@ -1273,8 +1300,13 @@ extern "C" int lldwt_factorized_rate(const float* x, const float* eb, const floa
     int64_t gx = noise ? cdiv(hw, 256) : cdiv(hw, 8192);
     if (gx > 1024) gx = 1024;
     dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
-    hipLaunchKernelGGL(k_factorized_rate, grid, dim3(256), 0, (hipStream_t)stream, x, eb, noise, bits, qout, bit_sum,
-                       (int)batch, C, hw, (const float*)nullptr);
+    {
+        const dim3 blk(256);
+        if (bits && qout) hipLaunchKernelGGL((k_factorized_rate<true, true>), grid, blk, 0, (hipStream_t)stream, x, eb, noise, bits, qout, bit_sum, (int)batch, C, hw, (const float*)nullptr);
+        else if (bits) hipLaunchKernelGGL((k_factorized_rate<true, false>), grid, blk, 0, (hipStream_t)stream, x, eb, noise, bits, qout, bit_sum, (int)batch, C, hw, (const float*)nullptr);
+        else if (qout) hipLaunchKernelGGL((k_factorized_rate<false, true>), grid, blk, 0, (hipStream_t)stream, x, eb, noise, bits, qout, bit_sum, (int)batch, C, hw, (const float*)nullptr);
+        else hipLaunchKernelGGL((k_factorized_rate<false, false>), grid, blk, 0, (hipStream_t)stream, x, eb, noise, bits, qout, bit_sum, (int)batch, C, hw, (const float*)nullptr);
+    }
     return check_launch("factorized_rate");
 }
 extern "C" int lldwt_factorized_table(const float* eb, float* table, int64_t planes, int C, void* stream) {
@@ -1286,14 +1318,25 @@ extern "C" int lldwt_factorized_rate_tab(const float* x, const float* eb, const 
                                          double* bit_sum, int64_t planes, int64_t batch, int C, int64_t hw, void* stream) {
     LLDWT_REQUIRE(x && eb && table && planes > 0 && batch > 0 && C > 0 && hw > 0, "factorized_rate_tab: bad arguments");
     LLDWT_REQUIRE(planes * batch <= 65535 && C <= 65535, "factorized_rate_tab: grid too large");
-    // no table to build per workgroup: smaller slices (two 16-byte loads per lane), about 8 workgroups per CU in all
-    int64_t gx = cdiv(hw, 2048);
-    const int64_t cap = (int64_t)lldwt_num_cus() * 8, rows = (int64_t)C * planes * batch;
-    if (gx * rows > cap) gx = cdiv(cap, rows);
+    // A workgroup pays a prologue (parameters, table row, barrier) before it streams: eight 16-byte groups per lane behind it
+    // (sweep at 72 and 864 rows of 64 K coefficients: 1 / 2 / 4 / 8 / 64 groups -> 15.2 / 12.4 / 11.6 / 10.9 / - us and
+    // 179 / 125 / - / 124 / 142 us), fewer while that leaves the chip under three workgroups per CU; with bit_sum (one double
+    // atomic per workgroup on ONE address) at most 8 per CU.
+    const int64_t cus = lldwt_num_cus(), rows = (int64_t)C * planes * batch;
+    int k = 8;
+    int64_t gx = cdiv(hw, 1024 * (int64_t)k);
+    while (k > 1 && gx * rows < 3 * cus) gx = cdiv(hw, 1024 * (int64_t)--k);
+    if (bit_sum)
+        while (gx * rows > 8 * cus && gx > 1) gx = cdiv(hw, 1024 * (int64_t)++k);
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
     dim3 grid((unsigned)gx, (unsigned)C, (unsigned)(planes * batch));
-    hipLaunchKernelGGL(k_factorized_rate, grid, dim3(256), 0, (hipStream_t)stream, x, eb, (const float*)nullptr, bits, qout,
-                       bit_sum, (int)batch, C, hw, table);
+    {
+        const dim3 blk(256);
+        if (bits && qout) hipLaunchKernelGGL((k_factorized_rate<true, true>), grid, blk, 0, (hipStream_t)stream, x, eb, (const float*)nullptr, bits, qout, bit_sum, (int)batch, C, hw, table);
+        else if (bits) hipLaunchKernelGGL((k_factorized_rate<true, false>), grid, blk, 0, (hipStream_t)stream, x, eb, (const float*)nullptr, bits, qout, bit_sum, (int)batch, C, hw, table);
+        else if (qout) hipLaunchKernelGGL((k_factorized_rate<false, true>), grid, blk, 0, (hipStream_t)stream, x, eb, (const float*)nullptr, bits, qout, bit_sum, (int)batch, C, hw, table);
+        else hipLaunchKernelGGL((k_factorized_rate<false, false>), grid, blk, 0, (hipStream_t)stream, x, eb, (const float*)nullptr, bits, qout, bit_sum, (int)batch, C, hw, table);
+    }
     return check_launch("factorized_rate_tab");
 }
 extern "C" int lldwt_sq_err_sum(const float* a, const float* b, int64_t n, double* out, void* stream) {
