@@ -203,25 +203,27 @@ constexpr float DEC_LO[10] = {0.0f, 0.037828455507264f, -0.023849465019557f, -0.
                               0.037828455507264f};
 constexpr float DEC_HI[10] = {0.0f, -0.064538882628697f, 0.040689417609164f, 0.418092273221617f, -0.788485616405583f,
                               0.418092273221617f, 0.040689417609164f, -0.064538882628697f, 0.0f, 0.0f};
-constexpr int CHP = CIN / 2 + 2;           // pitch of the even / odd column planes (38: even, rows 8-byte aligned)
-constexpr int CLP = CT + 2;                // pitch of the width-pass outputs (34)
-
+// TY x TX: the subband tile of a workgroup (rows x columns); its input patch is (2 TY + 8) x (2 TX + 8)
+template <int TY, int TX>
 __global__ __launch_bounds__(256) void k_cdf97_fwd_level_v(V3 in, V3 ll, V3 lh, V3 hl, V3 vhh, int h, int w) {
+    constexpr int CINY = 2 * TY + 8, CINX = 2 * TX + 8;
+    constexpr int CHP = CINX / 2 + 2;          // pitch of the even / odd column planes (38 at TX = 32: even, rows 8-byte aligned)
+    constexpr int CLP = TX + 2;                // pitch of the width-pass outputs (34)
     // sL / sH overlay the even / odd planes (the width-pass results wait in registers across a barrier): 21.9 KB of LDS per
-    // workgroup, 7 workgroups per CU instead of 3
-    __shared__ __attribute__((aligned(16))) float smem[2 * CIN * CHP];
+    // workgroup at 32 x 32, 7 workgroups per CU instead of 3
+    __shared__ __attribute__((aligned(16))) float smem[2 * CINY * CHP];
     float (*se)[CHP] = reinterpret_cast<float (*)[CHP]>(smem);
-    float (*so)[CHP] = reinterpret_cast<float (*)[CHP]>(smem + CIN * CHP);
+    float (*so)[CHP] = reinterpret_cast<float (*)[CHP]>(smem + CINY * CHP);
     float (*sL)[CLP] = reinterpret_cast<float (*)[CLP]>(smem);
-    float (*sH)[CLP] = reinterpret_cast<float (*)[CLP]>(smem + CIN * CLP);
+    float (*sH)[CLP] = reinterpret_cast<float (*)[CLP]>(smem + CINY * CLP);
     static_assert(CLP <= CHP, "overlay");
-    const TilePos tp = tile_pos((h / 2 + CT - 1) / CT, (w / 2 + CT - 1) / CT);
+    const TilePos tp = tile_pos((h / 2 + TY - 1) / TY, (w / 2 + TX - 1) / TX);
     const int64_t z = tp.z;
-    const int ky0 = tp.by * CT, kx0 = tp.bx * CT;
+    const int ky0 = tp.by * TY, kx0 = tp.bx * TX;
     const int tid = threadIdx.x;
     const float* inz = in.p + z * in.sz;
-    constexpr int VR = CIN / 4;                        // vectors per patch row (18)
-    constexpr int NLV = (CIN * VR + 255) / 256;        // 6
+    constexpr int VR = CINX / 4;                       // vectors per patch row (18)
+    constexpr int NLV = (CINY * VR + 255) / 256;       // 6 at 32 x 32
     f4u v[NLV];
 #pragma unroll
     for (int r = 0; r < NLV; ++r) {
@@ -230,12 +232,12 @@ __global__ __launch_bounds__(256) void k_cdf97_fwd_level_v(V3 in, V3 ll, V3 lh, 
         int gy = 2 * ky0 - 4 + ly, gx = 2 * kx0 - 4 + 4 * vx;
         gy += gy < 0 ? h : (gy >= h ? -h : 0);
         gx += gx < 0 ? w : (gx >= w ? -w : 0);
-        v[r] = *reinterpret_cast<const f4u*>(inz + (i < CIN * VR ? (int64_t)gy * in.sy + gx : 0));
+        v[r] = *reinterpret_cast<const f4u*>(inz + (i < CINY * VR ? (int64_t)gy * in.sy + gx : 0));
     }
 #pragma unroll
     for (int r = 0; r < NLV; ++r) {
         const int i = tid + r * 256;
-        if (i < CIN * VR) {
+        if (i < CINY * VR) {
             const int ly = i / VR, vx = i - ly * VR;
             *reinterpret_cast<floatx2*>(&se[ly][2 * vx]) = floatx2{v[r].x, v[r].z};
             *reinterpret_cast<floatx2*>(&so[ly][2 * vx]) = floatx2{v[r].y, v[r].w};
@@ -244,13 +246,13 @@ __global__ __launch_bounds__(256) void k_cdf97_fwd_level_v(V3 in, V3 ll, V3 lh, 
     __syncthreads();
     // width pass, two adjacent outputs per thread: lo/hi[ly][c] = sum_m dec[m] * patch[ly][2c + 9 - m];
     // column 2c+9-m is even column c+4-(m-1)/2 for odd m, odd column c+4-m/2 for even m
-    constexpr int NWV = (CIN * (CT / 2) + 255) / 256;  // 5 (the last one half empty: it recomputes the last item)
+    constexpr int NWV = (CINY * (TX / 2) + 255) / 256; // 5 at 32 x 32 (the last one half empty: it recomputes the last item)
     floatx2 wa[NWV], wd[NWV];
 #pragma unroll
     for (int q = 0; q < NWV; ++q) {
         const int i0 = tid + q * 256;
-        const int i = i0 < CIN * (CT / 2) ? i0 : CIN * (CT / 2) - 1;
-        const int ly = i / (CT / 2), c = 2 * (i - ly * (CT / 2));
+        const int i = i0 < CINY * (TX / 2) ? i0 : CINY * (TX / 2) - 1;
+        const int ly = i / (TX / 2), c = 2 * (i - ly * (TX / 2));
         float e[6], o[6];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -274,8 +276,8 @@ __global__ __launch_bounds__(256) void k_cdf97_fwd_level_v(V3 in, V3 ll, V3 lh, 
 #pragma unroll
     for (int q = 0; q < NWV; ++q) {
         const int i = tid + q * 256;
-        if (i < CIN * (CT / 2)) {
-            const int ly = i / (CT / 2), c = 2 * (i - ly * (CT / 2));
+        if (i < CINY * (TX / 2)) {
+            const int ly = i / (TX / 2), c = 2 * (i - ly * (TX / 2));
             *reinterpret_cast<floatx2*>(&sL[ly][c]) = wa[q];
             *reinterpret_cast<floatx2*>(&sH[ly][c]) = wd[q];
         }
@@ -283,8 +285,8 @@ __global__ __launch_bounds__(256) void k_cdf97_fwd_level_v(V3 in, V3 ll, V3 lh, 
     __syncthreads();
     // height pass, two adjacent columns per thread
     const int hh = h / 2, wh = w / 2;
-    for (int i = tid; i < CT * (CT / 2); i += 256) {
-        const int r = i / (CT / 2), c = 2 * (i - r * (CT / 2));
+    for (int i = tid; i < TY * (TX / 2); i += 256) {
+        const int r = i / (TX / 2), c = 2 * (i - r * (TX / 2));
         const int ky = ky0 + r, kx = kx0 + c;
         if (ky >= hh || kx >= wh) continue;
         floatx2 a0 = {0.f, 0.f}, d0 = {0.f, 0.f}, a1 = {0.f, 0.f}, d1 = {0.f, 0.f};
@@ -547,7 +549,7 @@ static int cdf_args(const char* who, int64_t Z, int64_t H, int64_t W, int levels
                       who, levels - 1, (long)smallest);
     }
     LLDWT_REQUIRE(ws, "%s: null workspace", who);
-    LLDWT_REQUIRE(Z * cdiv(H / 2, CT) * cdiv(W / 2, CT) < (1ll << 31), "%s: too many tiles for one grid", who);
+    LLDWT_REQUIRE(Z * cdiv(H / 2, 8) * cdiv(W / 2, CT) < (1ll << 31), "%s: too many tiles for one grid", who);
     if (ws_bytes < lldwt_cdf97_ws_bytes(Z, H, W)) {
         set_error("%s: workspace %ld < %ld bytes", who, (long)ws_bytes, (long)lldwt_cdf97_ws_bytes(Z, H, W));
         return LLDWT_EWS;
@@ -579,10 +581,22 @@ extern "C" int lldwt_cdf97_forward_ex(const float* x, float* ll, float* const* y
         V3 vLL{llout, sub, wh, 1}, vLH{y, 3 * sub, wh, 1}, vHL{y + sub, 3 * sub, wh, 1}, vHH{y + 2 * sub, 3 * sub, wh, 1};
         if (!adj) {       // fused level: one read of the input, one write of the four subbands
             dim3 grid((unsigned)(cdiv(wh, CT) * cdiv(hh, CT) * Z));
+            // Tile of a workgroup: 16 x 32 subband samples (8 x 32 for a level of under 200 tiles of 32 x 32), not 32 x 32: twice
+            // (four times) the workgroups, each with half (a quarter of) the load -> LDS -> two passes -> store chain that a level's
+            // duration consists of when its tiles are one resident round -- 25.7 -> 22.7 us for the four levels at the BASELINE batch,
+            // 168 -> 167 us at batch 96 (LLDWT_CDF_TILE=32 keeps the square tile for an A/B; 16 x 16: no better than 32 x 32)
+            static const bool tile32 = getenv("LLDWT_CDF_TILE") && atoi(getenv("LLDWT_CDF_TILE")) == 32;
             // one conditional wrap per index is enough from 64 samples up (the 72-wide patch of the last tile ends below 2 h)
-            if (h >= 2 * CT && w >= 2 * CT && w % 4 == 0 && in.sx == 1)
-                hipLaunchKernelGGL(k_cdf97_fwd_level_v, grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
-            else
+            if (h >= 2 * CT && w >= 2 * CT && w % 4 == 0 && in.sx == 1) {
+                if (tile32)
+                    hipLaunchKernelGGL((k_cdf97_fwd_level_v<CT, CT>), grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
+                else if ((int64_t)grid.x < 200)
+                    hipLaunchKernelGGL((k_cdf97_fwd_level_v<8, 32>), dim3((unsigned)(cdiv(wh, 32) * cdiv(hh, 8) * Z)), dim3(256), 0, st,
+                                       in, vLL, vLH, vHL, vHH, (int)h, (int)w);
+                else
+                    hipLaunchKernelGGL((k_cdf97_fwd_level_v<16, 32>), dim3((unsigned)(cdiv(wh, 32) * cdiv(hh, 16) * Z)), dim3(256), 0, st,
+                                       in, vLL, vLH, vHL, vHH, (int)h, (int)w);
+            } else
                 hipLaunchKernelGGL(k_cdf97_fwd_level, grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
         } else {
             hipLaunchKernelGGL(k_afb, grid2d(h, wh, Z), dim3(256), 0, st, in, lw, hw_, (int)h, (int)w, 1, adj);
