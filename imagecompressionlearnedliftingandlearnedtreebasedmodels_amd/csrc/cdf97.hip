@@ -396,23 +396,25 @@ constexpr float REC_LO[10] = {0.0f, -0.064538882628697f, -0.040689417609164f, 0.
 constexpr float REC_HI[10] = {0.0f, -0.037828455507264f, -0.023849465019557f, 0.110624404418437f, 0.377402855612831f,
                               -0.852698679008894f, 0.377402855612831f, 0.110624404418437f, -0.023849465019557f,
                               -0.037828455507264f};
-constexpr int CSP = CS + 2;                // 38: even pitch
-
+// TY x TX: the subband tile of a workgroup (rows x columns); it reconstructs 2 TY x 2 TX pixels from (TY + 4) x (TX + 4) patches
+template <int TY, int TX>
 __global__ __launch_bounds__(256) void k_cdf97_inv_level_v(V3 ll, V3 lh, V3 hl, V3 vhh, V3 out, int h, int w) {
-    // sLw / sHw overlay the four subband patches: 21.9 KB of LDS per workgroup, 7 workgroups per CU instead of 3
-    __shared__ __attribute__((aligned(16))) float smem[4 * CS * CSP];
-    float (*s4)[CS][CSP] = reinterpret_cast<float (*)[CS][CSP]>(smem);
+    constexpr int CSY = TY + 4, CSX = TX + 4;
+    constexpr int CSP = CSX + 2;               // 38 at TX = 32: even pitch
+    // sLw / sHw overlay the four subband patches: 21.9 KB of LDS per workgroup at 32 x 32, 7 workgroups per CU instead of 3
+    __shared__ __attribute__((aligned(16))) float smem[4 * CSY * CSP];
+    float (*s4)[CSY][CSP] = reinterpret_cast<float (*)[CSY][CSP]>(smem);
     float (*sLw)[CSP] = reinterpret_cast<float (*)[CSP]>(smem);
-    float (*sHw)[CSP] = reinterpret_cast<float (*)[CSP]>(smem + 2 * CT * CSP);
-    static_assert(2 * 2 * CT * CSP <= 4 * CS * CSP, "overlay");
-    const TilePos tp = tile_pos((h + 2 * CT - 1) / (2 * CT), (w + 2 * CT - 1) / (2 * CT));
+    float (*sHw)[CSP] = reinterpret_cast<float (*)[CSP]>(smem + 2 * TY * CSP);
+    static_assert(2 * 2 * TY * CSP <= 4 * CSY * CSP, "overlay");
+    const TilePos tp = tile_pos((h + 2 * TY - 1) / (2 * TY), (w + 2 * TX - 1) / (2 * TX));
     const int64_t z = tp.z;
-    const int y0 = tp.by * 2 * CT, x0 = tp.bx * 2 * CT;
+    const int y0 = tp.by * 2 * TY, x0 = tp.bx * 2 * TX;
     const int hh = h / 2, wh = w / 2;
     const int tid = threadIdx.x;
     const float* sp[4] = {ll.p + z * ll.sz, lh.p + z * lh.sz, hl.p + z * hl.sz, vhh.p + z * vhh.sz};
-    constexpr int VR = CS / 2;                          // float2 per patch row (18)
-    constexpr int NLV = (CS * VR + 255) / 256;          // 3
+    constexpr int VR = CSX / 2;                         // float2 per patch row (18)
+    constexpr int NLV = (CSY * VR + 255) / 256;         // 3 at 32 x 32
     f2u v[4][NLV];
 #pragma unroll
     for (int r = 0; r < NLV; ++r) {
@@ -421,14 +423,14 @@ __global__ __launch_bounds__(256) void k_cdf97_inv_level_v(V3 ll, V3 lh, V3 hl, 
         int gy = y0 / 2 - 2 + lk, gx = x0 / 2 - 2 + 2 * vx;
         gy += gy < 0 ? hh : (gy >= hh ? -hh : 0);
         gx += gx < 0 ? wh : (gx >= wh ? -wh : 0);
-        const int64_t off = i < CS * VR ? (int64_t)gy * ll.sy + gx : 0;      // the four subbands share the row stride
+        const int64_t off = i < CSY * VR ? (int64_t)gy * ll.sy + gx : 0;      // the four subbands share the row stride
 #pragma unroll
         for (int b = 0; b < 4; ++b) v[b][r] = *reinterpret_cast<const f2u*>(sp[b] + off);
     }
 #pragma unroll
     for (int r = 0; r < NLV; ++r) {
         const int i = tid + r * 256;
-        if (i < CS * VR) {
+        if (i < CSY * VR) {
             const int lk = i / VR, vx = i - lk * VR;
 #pragma unroll
             for (int b = 0; b < 4; ++b) *reinterpret_cast<floatx2*>(&s4[b][lk][2 * vx]) = floatx2{v[b][r].x, v[b][r].y};
@@ -437,12 +439,12 @@ __global__ __launch_bounds__(256) void k_cdf97_inv_level_v(V3 ll, V3 lh, V3 hl, 
     __syncthreads();
     // height synthesis: rows dn = 2j + par, base row j + 4; taps t = 2u + par at input row base - u
     // (results wait in registers across a barrier: sLw / sHw overlay the subband patches)
-    constexpr int NHS = (CT * VR + 255) / 256;          // 3 (the last one a quarter full: it recomputes the last item)
+    constexpr int NHS = (TY * VR + 255) / 256;          // 3 at 32 x 32 (the last one a quarter full: it recomputes the last item)
     floatx2 ra0[NHS], ra1[NHS], rb0[NHS], rb1[NHS];
 #pragma unroll
     for (int r = 0; r < NHS; ++r) {
         const int i0 = tid + r * 256;
-        const int i = i0 < CT * VR ? i0 : CT * VR - 1;
+        const int i = i0 < TY * VR ? i0 : TY * VR - 1;
         const int j = i / VR, lc = 2 * (i - j * VR);
         floatx2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, b0 = {0.f, 0.f}, b1 = {0.f, 0.f};
 #pragma unroll
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256) void k_cdf97_inv_level_v(V3 ll, V3 lh, V3 hl, 
 #pragma unroll
     for (int r = 0; r < NHS; ++r) {
         const int i = tid + r * 256;
-        if (i < CT * VR) {
+        if (i < TY * VR) {
             const int j = i / VR, lc = 2 * (i - j * VR);
             *reinterpret_cast<floatx2*>(&sLw[2 * j][lc]) = ra0[r];
             *reinterpret_cast<floatx2*>(&sLw[2 * j + 1][lc]) = ra1[r];
@@ -490,8 +492,8 @@ __global__ __launch_bounds__(256) void k_cdf97_inv_level_v(V3 ll, V3 lh, V3 hl, 
     __syncthreads();
     // width synthesis: four consecutive pixels dm = 4q .. 4q+3 from columns 2q .. 2q+5 of both half-rows
     float* oz = out.p + z * out.sz;
-    for (int i = tid; i < 2 * CT * (CT / 2); i += 256) {
-        const int dn = i / (CT / 2), q = i - dn * (CT / 2);
+    for (int i = tid; i < 2 * TY * (TX / 2); i += 256) {
+        const int dn = i / (TX / 2), q = i - dn * (TX / 2);
         const int gy = y0 + dn, gx = x0 + 4 * q;
         if (gy >= h || gx >= w) continue;
         float L[6], H[6];
@@ -584,11 +586,12 @@ extern "C" int lldwt_cdf97_forward_ex(const float* x, float* ll, float* const* y
             // Tile of a workgroup: 16 x 32 subband samples (8 x 32 for a level of under 200 tiles of 32 x 32), not 32 x 32: twice
             // (four times) the workgroups, each with half (a quarter of) the load -> LDS -> two passes -> store chain that a level's
             // duration consists of when its tiles are one resident round -- 25.7 -> 22.7 us for the four levels at the BASELINE batch,
-            // 168 -> 167 us at batch 96 (LLDWT_CDF_TILE=32 keeps the square tile for an A/B; 16 x 16: no better than 32 x 32)
+            // batch 96 unchanged within 1 % (LLDWT_CDF_TILE=32 / 1632 force the square / the 16 x 32 tile for an A/B; 16 x 16: no better than 32 x 32)
             static const bool tile32 = getenv("LLDWT_CDF_TILE") && atoi(getenv("LLDWT_CDF_TILE")) == 32;
+            static const bool tile16 = getenv("LLDWT_CDF_TILE") && atoi(getenv("LLDWT_CDF_TILE")) == 1632;
             // one conditional wrap per index is enough from 64 samples up (the 72-wide patch of the last tile ends below 2 h)
             if (h >= 2 * CT && w >= 2 * CT && w % 4 == 0 && in.sx == 1) {
-                if (tile32)
+                if (tile32 || (!tile16 && (int64_t)grid.x >= 4096))      // many rounds of tiles: the square tile streams better
                     hipLaunchKernelGGL((k_cdf97_fwd_level_v<CT, CT>), grid, dim3(256), 0, st, in, vLL, vLH, vHL, vHH, (int)h, (int)w);
                 else if ((int64_t)grid.x < 200)
                     hipLaunchKernelGGL((k_cdf97_fwd_level_v<8, 32>), dim3((unsigned)(cdiv(wh, 32) * cdiv(hh, 8) * Z)), dim3(256), 0, st,
@@ -635,8 +638,17 @@ extern "C" int lldwt_cdf97_inverse_ex(const float* ll, const float* const* yh, f
             dim3 grid((unsigned)(cdiv(w, 2 * CT) * cdiv(h, 2 * CT) * Z));
             // the same for the 36-wide subband patches from 32 samples up
             if (hh >= CT && wh >= CT && wh % 2 == 0)
-                hipLaunchKernelGGL(k_cdf97_inv_level_v, grid, dim3(256), 0, st, vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
-            else
+            {
+                static const int inv_tile = getenv("LLDWT_CDF_TILE") ? atoi(getenv("LLDWT_CDF_TILE")) : 0;   // 32 | 1632 (A/B)
+                // as in the forward transform: the 16 x 32 tile while a level is a few resident rounds at most (28.7 -> 26.0 us for
+                // the four levels at the BASELINE batch); from 4 096 square tiles up the square tile streams better (192 vs 201 us
+                // at batch 96)
+                if (inv_tile == 32 || (inv_tile == 0 && (int64_t)grid.x >= 4096))
+                    hipLaunchKernelGGL((k_cdf97_inv_level_v<CT, CT>), grid, dim3(256), 0, st, vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
+                else
+                    hipLaunchKernelGGL((k_cdf97_inv_level_v<16, 32>), dim3((unsigned)(cdiv(w, 64) * cdiv(h, 32) * Z)), dim3(256), 0, st,
+                                       vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
+            } else
                 hipLaunchKernelGGL(k_cdf97_inv_level, grid, dim3(256), 0, st, vLL, vLH, vHL, vHH, vo, (int)h, (int)w);
         } else {
             hipLaunchKernelGGL(k_sfb, grid2d(h, wh, Z), dim3(256), 0, st, vLL, vLH, lw, (int)h, (int)wh, 0, adj);
