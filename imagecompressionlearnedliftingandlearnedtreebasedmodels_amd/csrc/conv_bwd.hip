@@ -732,12 +732,22 @@ static int launch_wgrad1x1(const W1Args& a, int planes, hipStream_t st) {
     return check_launch("conv2d_wgrad");
 }
 
+__device__ __forceinline__ float act_bwd_one(float g, float yv, int act) {
+    return act == LLDWT_ACT_TANH ? g * (1.f - yv * yv)
+                                 : (act == LLDWT_ACT_LRELU ? (yv > 0.f ? g : 0.01f * g) : (act == LLDWT_ACT_RELU ? (yv > 0.f ? g : 0.f) : g));
+}
 __global__ void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, int64_t n,
                           int act) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float yv = y[i], g = dy[i];
-        dx[i] = act == LLDWT_ACT_TANH ? g * (1.f - yv * yv)
-                                     : (act == LLDWT_ACT_LRELU ? (yv > 0.f ? g : 0.01f * g) : (act == LLDWT_ACT_RELU ? (yv > 0.f ? g : 0.f) : g));
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = act_bwd_one(dy[i], y[i], act);
+}
+// 16 bytes per lane (n4 = n / 4 groups; the launcher checks the alignment), one group per lane and workgroup: many short workgroups
+__global__ __launch_bounds__(256) void k_act_bwd4(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                  float4* __restrict__ dx, int64_t n4, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 g = dy[i], yv = y[i];
+        dx[i] = float4{act_bwd_one(g.x, yv.x, act), act_bwd_one(g.y, yv.y, act), act_bwd_one(g.z, yv.z, act),
+                       act_bwd_one(g.w, yv.w, act)};
     }
 }
 
@@ -1007,7 +1017,14 @@ extern "C" int lldwt_conv2d_wgrad_ex(const float* x, const float* dy, float* dw,
 extern "C" int lldwt_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, void* stream) {
     LLDWT_REQUIRE(dy && y && dx && n >= 0, "act_bwd: bad arguments");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_act_bwd, dim3(ew_grid2(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, act);
+    static const bool scalar = getenv("LLDWT_ACT_BWD") && atoi(getenv("LLDWT_ACT_BWD")) == 1;     // A/B: the 4-byte kernel
+    if (!scalar && (n & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dx)) & 15) == 0) {
+        const int64_t n4 = n >> 2, g = cdiv(n4, 256), cap = (int64_t)lldwt_num_cus() * 128;
+        hipLaunchKernelGGL(k_act_bwd4, dim3((unsigned)(g > cap ? cap : g)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(y), reinterpret_cast<float4*>(dx), n4, act);
+    } else {
+        hipLaunchKernelGGL(k_act_bwd, dim3(ew_grid2(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, act);
+    }
     return check_launch("act_bwd");
 }
 
