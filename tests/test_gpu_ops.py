@@ -325,3 +325,22 @@ def test_cdf97_fast_kernels_near_their_size_limit(shape, levels):
     for i in range(levels):
         assert maxdiff(yh[i][0].cpu(), oyh[i]) < 5e-5, i
     assert maxdiff(ops.cdf97_inverse(ll, yh).cpu(), x) < 5e-5
+
+
+def test_cdf97_tile_shapes_agree_across_batch_sizes():
+    """The tile kernels choose their tile by a level's tile count: 32 x 32 from 4 096 square tiles per level up (large batches), 16 x 32
+    below, 8 x 32 (forward) under 200 -- one arithmetic per sample, so a plane transformed inside a large batch (level 0 on square tiles,
+    the deeper levels on 16 x 32) must equal the same plane transformed alone (16 x 32 / 8 x 32 tiles) BIT FOR BIT, both directions."""
+    ops, gu = _ops()
+    g = torch.Generator().manual_seed(97)
+    big = gu.dev(torch.rand(1, 64, 1, 512, 512, generator=g) - 0.5)            # level 0: 64 * 8 * 8 = 4 096 square tiles
+    one = big[:, 17:18].contiguous()
+    ll_b, yh_b = ops.cdf97_forward(big, 4)
+    ll_1, yh_1 = ops.cdf97_forward(one, 4)
+    assert torch.equal(ll_b[:, 17:18], ll_1)
+    for a, b in zip(yh_b, yh_1):
+        assert torch.equal(a[:, 17:18], b)
+    xb = ops.cdf97_inverse(ll_b, yh_b)
+    x1 = ops.cdf97_inverse(ll_1, yh_1)
+    assert torch.equal(xb[:, 17:18], x1)
+    assert maxdiff(xb.cpu(), big.cpu()) < 5e-5

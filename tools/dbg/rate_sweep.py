@@ -1,4 +1,5 @@
-"""Sweep a process-wide switch of the HBM-bound kernels: python tools/dbg/rate_sweep.py LLDWT_GR_WGS 16 6 4 (one child process per value,
+"""Sweep a process-wide switch of the HBM-bound kernels: python tools/dbg/rate_sweep.py LLDWT_CDF_TILE 32 1632 default (one child process per value;
+several switches at once: A,B 1,2 3,4;
 the secondary roofline block of bench.py in each)."""
 import json
 import os
